@@ -1,0 +1,85 @@
+"""``OfflineRenderer`` — host-side mirror of the reference's offline-render caller.
+
+Follows js/packages/offline-renderer/index.ts:11-186 (``initialize`` option names and defaults
+:20-27, the block loop of ``process`` :87-133 which always renders FULL blocks and zero-pads a
+short input, ``setCurrentTime`` :179-185) on top of any engine with the ``CRuntime`` surface.
+The engine is injected (``engine_factory(sample_rate, block_size) -> CRuntime``) so the same
+caller drives the HIP engine in production and the CPU checkers in tests.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+
+class OfflineRenderer:
+    def __init__(self, engine_factory: Callable[[float, int], Any]):
+        self._factory = engine_factory
+        self._rt: Any = None
+
+    def initialize(self, num_input_channels: int = 0, num_output_channels: int = 2, sample_rate: float = 44100,
+                   block_size: int = 512, virtual_file_system: Optional[Dict[str, np.ndarray]] = None) -> None:
+        self.num_in = int(num_input_channels)
+        self.num_out = int(num_output_channels)
+        self.block_size = int(block_size)
+        self.sample_rate = float(sample_rate)
+        self._rt = self._factory(self.sample_rate, self.block_size)
+        self._time = 0
+        for k, v in (virtual_file_system or {}).items():
+            self._rt.add_shared_resource(k, v)
+
+    @property
+    def runtime(self) -> Any:
+        return self._rt
+
+    def render(self, *roots: Any) -> Dict[str, Any]:
+        stats = self._rt.render(*roots)
+        if stats["result"] != 0:
+            raise RuntimeError(f"render failed: code {stats['result']}")
+        return stats
+
+    def create_ref(self, kind: str, props: Dict[str, Any], children: Sequence[Any]):
+        return self._rt.renderer.create_ref(kind, props, children)
+
+    def process(self, inputs: Sequence[np.ndarray], outputs: Sequence[np.ndarray]) -> None:
+        if len(inputs) != self.num_in:
+            raise ValueError(f"Invalid input data; expected {self.num_in} buffers.")
+        if len(outputs) != self.num_out:
+            raise ValueError(f"Invalid output data; expected {self.num_out} buffers.")
+        if self.num_out == 0:
+            return
+        bs = self.block_size
+        total = len(outputs[0])
+        for k in range(0, total, bs):
+            block_in = None
+            if self.num_in:
+                block_in = np.zeros((self.num_in, bs), dtype=np.float32)
+                for i, buf in enumerate(inputs):
+                    seg = np.asarray(buf[k:k + bs], dtype=np.float32)
+                    block_in[i, :len(seg)] = seg
+            out = self._rt.process(block_in, self.num_out, bs, sample_time=self._time)
+            self._time += bs
+            for i, buf in enumerate(outputs):
+                m = min(bs, len(buf) - k)
+                if m > 0:
+                    buf[k:k + m] = out[i, :m]
+
+    def update_virtual_file_system(self, vfs: Dict[str, np.ndarray]) -> None:
+        for k, v in vfs.items():
+            self._rt.add_shared_resource(k, v)
+
+    def prune_virtual_file_system(self) -> None:
+        self._rt.prune_shared_resources()
+
+    def reset(self) -> None:
+        self._rt.reset()
+
+    def gc(self) -> List[int]:
+        return self._rt.gc()
+
+    def set_current_time(self, t: int) -> None:
+        self._time = int(t)
+
+    def set_current_time_ms(self, ms: float) -> None:
+        self._time = int(ms * 0.001 * self.sample_rate)
