@@ -1,0 +1,148 @@
+// abi.cpp — the extern "C" surface declared in include/elemhip.h.
+#include <atomic>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/elemhip.h"
+#include "engine.h"
+
+using elemhip::Engine;
+using elemhip::Value;
+
+struct elemhip_s { Engine engine; elemhip_s(double sr, int bs, int dev) : engine(sr, bs, dev) {} };
+
+static std::atomic<int> g_lastCreateError{0};
+
+extern "C" {
+
+elemhip_t* elemhip_create(double sampleRate, int blockSize, int deviceOrdinal) {
+    elemhip_s* h = new (std::nothrow) elemhip_s(sampleRate, blockSize, deviceOrdinal);
+    if (!h) { g_lastCreateError = elemhip::kHipError; return nullptr; }
+    if (h->engine.initError()) { g_lastCreateError = h->engine.initError(); delete h; return nullptr; }
+    g_lastCreateError = 0;
+    return h;
+}
+
+void elemhip_destroy(elemhip_t* h) { delete h; }
+int elemhip_last_create_error(void) { return g_lastCreateError.load(); }
+
+int elemhip_apply_instructions_json(elemhip_t* h, const char* json, size_t len) {
+    if (!h || !json) return elemhip::kInvalidInstructionFormat;
+    Value v;
+    elemhip::JsonParser parser(json, len);
+    if (!parser.parse(v)) return elemhip::kJsonParseError;
+    return h->engine.apply(v);
+}
+
+static int applyOne(elemhip_t* h, Value&& instr) {
+    Value batch; batch.type = Value::Array;
+    batch.arr.push_back(std::move(instr));
+    return h->engine.apply(batch);
+}
+
+int elemhip_create_node(elemhip_t* h, int32_t id, const char* type) {
+    if (!h || !type) return elemhip::kInvalidInstructionFormat;
+    Value i; i.type = Value::Array;
+    i.arr = {Value::number(0), Value::number(id), Value::string(type)};
+    return applyOne(h, std::move(i));
+}
+
+int elemhip_append_child(elemhip_t* h, int32_t parent, int32_t child, int32_t ch) {
+    if (!h) return elemhip::kInvalidInstructionFormat;
+    Value i; i.type = Value::Array;
+    i.arr = {Value::number(2), Value::number(parent), Value::number(child), Value::number(ch)};
+    return applyOne(h, std::move(i));
+}
+
+int elemhip_set_property_json(elemhip_t* h, int32_t id, const char* key, const char* json, size_t len) {
+    if (!h || !key || !json) return elemhip::kInvalidInstructionFormat;
+    // a bare scalar is valid here, so wrap it to reuse the array parser
+    std::string wrapped = "[" + std::string(json, len) + "]";
+    Value v;
+    elemhip::JsonParser parser(wrapped.data(), wrapped.size());
+    if (!parser.parse(v) || v.arr.size() != 1) return elemhip::kJsonParseError;
+    Value i; i.type = Value::Array;
+    i.arr = {Value::number(3), Value::number(id), Value::string(key), v.arr[0]};
+    return applyOne(h, std::move(i));
+}
+
+// ACTIVATE_ROOTS and COMMIT_UPDATES only rebuild when they share a batch (Runtime.h:172,199-205),
+// so the typed path keeps the pair together: activate stages the ids, commit sends [4,...],[5].
+static thread_local std::vector<int32_t> t_stagedRoots;
+static thread_local bool t_haveStaged = false;
+
+int elemhip_activate_roots(elemhip_t* h, const int32_t* ids, size_t n) {
+    if (!h || (!ids && n)) return elemhip::kInvalidInstructionFormat;
+    t_stagedRoots.assign(ids, ids + n);
+    t_haveStaged = true;
+    return elemhip::kOk;
+}
+
+int elemhip_commit(elemhip_t* h) {
+    if (!h) return elemhip::kInvalidInstructionFormat;
+    Value batch; batch.type = Value::Array;
+    if (t_haveStaged) {
+        Value roots; roots.type = Value::Array;
+        for (int32_t id : t_stagedRoots) roots.arr.push_back(Value::number(id));
+        Value a; a.type = Value::Array;
+        a.arr = {Value::number(4), roots};
+        batch.arr.push_back(std::move(a));
+        t_haveStaged = false;
+    }
+    Value c; c.type = Value::Array; c.arr = {Value::number(5)};
+    batch.arr.push_back(std::move(c));
+    return h->engine.apply(batch);
+}
+
+int elemhip_process(elemhip_t* h, const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t st) {
+    if (!h) return elemhip::kInvalidInstructionFormat;
+    return h->engine.process(in, nIn, out, nOut, n, st);
+}
+
+int elemhip_process_blocks(elemhip_t* h, const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t st) {
+    if (!h) return elemhip::kInvalidInstructionFormat;
+    return h->engine.processBlocks(inDev, nIn, outDev, nOut, numBlocks, st);
+}
+
+int elemhip_add_shared_resource(elemhip_t* h, const char* name, const float* const* ch, size_t nCh, size_t nSamples) {
+    if (!h || !name) return 0;
+    return h->engine.addSharedResource(name, ch, nCh, nSamples) ? 1 : 0;
+}
+
+void elemhip_prune_shared_resources(elemhip_t* h) { if (h) h->engine.pruneSharedResources(); }
+size_t elemhip_gc(elemhip_t* h, int32_t* out, size_t cap) { return h ? h->engine.gc(out, cap) : 0; }
+void elemhip_reset(elemhip_t* h) { if (h) h->engine.reset(); }
+const char* elemhip_describe(int code) { return elemhip::describe(code); }
+
+int elemhip_get_stats(elemhip_t* h, elemhip_stats* out) {
+    if (!h || !out) return elemhip::kInvalidInstructionFormat;
+    const elemhip::Stats& s = h->engine.stats();
+    out->blocks_rendered = s.blocksRendered; out->plans_built = s.plansBuilt; out->last_plan_build_ms = s.lastPlanBuildMs;
+    out->num_islands = s.numIslands; out->num_levels = s.numLevels; out->num_tasks = s.numTasks;
+    out->num_nodes_in_plan = s.numNodesInPlan; out->max_lds_bytes = s.maxLdsBytes; out->num_hbm_buffers = s.numHbmBuffers;
+    out->graph_replays = s.graphReplays; out->graph_captures = s.graphCaptures;
+    return elemhip::kOk;
+}
+
+// Debug/test hook: JSON description of the current render plan. Returns bytes needed.
+size_t elemhip_describe_plan(elemhip_t* h, char* buf, size_t cap) {
+    if (!h) return 0;
+    const std::string s = h->engine.describePlan();
+    if (buf && cap) { const size_t n = s.size() < cap - 1 ? s.size() : cap - 1; std::memcpy(buf, s.data(), n); buf[n] = 0; }
+    return s.size() + 1;
+}
+
+int elemhip_set_stream(elemhip_t* h, void* stream) {
+    if (!h) return elemhip::kInvalidInstructionFormat;
+    h->engine.setStream(static_cast<hipStream_t>(stream));
+    return elemhip::kOk;
+}
+
+int elemhip_set_option(elemhip_t* h, const char* key, double value) {
+    if (!h || !key) return elemhip::kInvalidInstructionFormat;
+    return h->engine.setOption(key, value);
+}
+
+} // extern "C"

@@ -1,0 +1,157 @@
+// device.h — plan encoding shared by the host graph compiler (plan.cpp) and the HIP
+// block-render kernels (kernels.hip).
+//
+// Vocabulary
+//   node record  : 32 dwords of persistent per-node device storage: [0..7] params written by
+//                  the host on setProperty (the reference's per-node atomics / SPSC queues,
+//                  e.g. builtins/Core.h:165-166, Delays.h:59-95), [8..31] DSP state that only
+//                  the render kernels touch (phasor phase, filter z's, ...).  Records outlive
+//                  plan rebuilds and root deactivation; they die in gc() (Runtime.h:220-272).
+//   island       : a connected cluster of nodes rendered by ONE workgroup with all of its
+//                  intermediate block buffers in LDS; only buffers consumed by another island
+//                  are exported to the HBM buffer arena.
+//   task         : a group of 1..64 same-opcode nodes of one island stage. Stateless ops run
+//                  sample-parallel (64 lanes x samples); stateful recurrences run lane-per-node.
+#pragma once
+#include <stdint.h>
+
+namespace elemhip {
+
+enum : uint32_t {
+    kRecDwords   = 32,     // dwords per node record
+    kParam0      = 0,      // first param dword
+    kState0      = 8,      // first state dword
+    kWaves       = 4,      // waves per island workgroup
+    kThreads     = 256,
+    kSlotWords   = 514,    // LDS words per block-buffer slot (512 + pad, keeps 8-byte alignment)
+    kMaxBlock    = 512,    // max frames per block the LDS slots are sized for
+    kMaxHostIn   = 32,     // host input channels addressable by leaf nodes (Types.h:142 uses 32 too)
+    kNone        = 0xFFFFFFFFu,
+};
+
+// Operand encoding: [31:30] kind, [29:0] value
+enum : uint32_t {
+    kOpLds   = 0u << 30,   // value = LDS word offset of a block buffer (stride 1)
+    kOpConst = 1u << 30,   // value = LDS word offset of one broadcast cell (stride 0)
+    kOpHbm   = 2u << 30,   // value = buffer index in the HBM buffer arena (index * blockStride)
+    kOpZero  = 3u << 30,   // reads as 0.0f
+    kOpKindMask = 3u << 30,
+    kOpValMask  = ~(3u << 30),
+};
+
+// Opcodes. The first block mirrors the registry names of runtime/elem/DefaultNodeTypes.h:49-144
+// (hot-path subset) plus the wasm-host nodes time/metro/convolve (wasm/Main.cpp:47-61).
+enum Op : uint16_t {
+    OP_INVALID = 0,
+    OP_CONST, OP_SR, OP_IN,
+    OP_SIN, OP_COS, OP_TAN, OP_TANH, OP_ASINH, OP_LN, OP_LOG, OP_LOG2,
+    OP_CEIL, OP_FLOOR, OP_ROUND, OP_SQRT, OP_EXP, OP_ABS,
+    OP_LE, OP_LEQ, OP_GE, OP_GEQ, OP_POW, OP_EQ, OP_AND, OP_OR,
+    OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MOD, OP_MIN, OP_MAX,
+    OP_ROOT, OP_PHASOR, OP_SPHASOR, OP_COUNTER, OP_ACCUM, OP_LATCH, OP_MAXHOLD, OP_ONCE, OP_SEQ, OP_RAND,
+    OP_DELAY, OP_SDELAY, OP_Z, OP_POLE, OP_ENV, OP_BIQUAD, OP_PREWARP, OP_MM1P, OP_SVF, OP_SVFSHELF,
+    OP_TAPIN, OP_TAPOUT, OP_SAMPLESEQ, OP_BLEPSAW, OP_BLEPSQUARE, OP_BLEPTRIANGLE,
+    OP_TIME, OP_METRO, OP_CONVOLVE,
+    // plan pseudo-ops
+    OP_COPY,          // out = in0 (import HBM->LDS, export LDS->HBM)
+    OP_COUNT_
+};
+
+// One node of a task.
+struct Member {
+    uint32_t rec;        // node record index
+    uint32_t opnd;       // first operand (index into Plan::operands)
+    uint32_t nin;        // operand count; kNone => leaf: operands are host inputs 0..nIn-1
+    uint32_t outLds;     // LDS word offset of the output slot, or kNone
+    uint32_t outHbm;     // HBM arena buffer index to (also) write, or kNone
+    uint32_t scratch;    // LDS word offset of op scratch (svf coefficients, ...), or kNone
+};
+
+struct Task {
+    uint16_t opcode;
+    uint8_t  stage;      // barrier epoch inside the island
+    uint8_t  wave;       // executing wave (0..kWaves-1)
+    uint16_t s0, s1;     // sample range [s0, s1) for sample-parallel tasks
+    uint32_t first;      // first member (index into Plan::members)
+    uint32_t count;      // members in this task
+};
+
+struct Island {
+    uint32_t taskBegin, taskEnd;   // into Plan::tasks, sorted by (stage, wave)
+    uint32_t rootRec;              // record of the RootNode whose render sequence owns the island
+    uint32_t constBegin, constEnd; // into Plan::constCells: LDS broadcast cells to fill at start
+    uint32_t numStages;
+    uint32_t ldsWords;
+    uint32_t pad_;
+};
+
+struct ConstCell {
+    uint32_t ldsWord;    // destination LDS word
+    uint32_t rec;        // source record (param dword 0 holds the value)
+};
+
+// Root bookkeeping for the epilogue (GraphRenderSequence.h:227-231, 297-308).
+struct RootEntry {
+    uint32_t rec;        // root record: p0 channel, p1 target gain, p2 step, s8 current gain
+    uint32_t hbm;        // HBM arena buffer holding the root's faded output
+};
+
+struct TapEntry {
+    uint32_t rec;        // tapOut record: p0/p1 shared tap buffer ptr, p2/p3 private delay buffer ptr
+    uint32_t rootRec;    // owning root (promotion only while that root is active)
+};
+
+// Engine-wide block state kept on the device so a block's launch sequence is replayable.
+struct Globals {
+    int64_t  sampleTime;   // wasm/Main.cpp:206-215 userData
+    uint32_t numSamples;   // frames in the current block (<= blockSize)
+    uint32_t numIn;        // host input channels this block
+    uint32_t numOut;       // host output channels this block
+    uint32_t blockSlot;    // which slot of the output ring the epilogue writes
+    uint32_t ringSlots;
+    uint32_t blockStride;  // floats between arena buffers (= blockSize)
+    float    sampleRateF;
+    uint32_t pad_;
+    double   sampleRate;
+};
+
+// Device view of a compiled plan (all pointers are device pointers).
+struct PlanView {
+    const Island*    islands;
+    const uint32_t*  levelIslands;   // island indices grouped by launch level
+    const Task*      tasks;
+    const Member*    members;
+    const uint32_t*  operands;
+    const ConstCell* constCells;
+    const RootEntry* roots;          // in render-sequence order
+    const TapEntry*  taps;           // in render-sequence order
+    uint32_t numRoots;
+    uint32_t numTaps;
+};
+
+struct Patch {
+    uint32_t kind;       // 0: recs[index] = value; 1: once-arm (Core.h:352-363); 2: globals dword
+    uint32_t index;      // dword index into the record arena / globals
+    uint32_t value;
+    uint32_t pad_;
+};
+
+// Record layouts (dword offsets). Doubles sit on even dwords.
+namespace rec {
+enum : uint32_t {
+    // generic
+    P0 = 0, P1 = 1, P2 = 2, P3 = 3, P4 = 4, P5 = 5, P6 = 6, P7 = 7,
+    S0 = 8, S1 = 9, S2 = 10, S3 = 11, S4 = 12, S5 = 13, S6 = 14, S7 = 15,
+    // root (Core.h:15-83, helpers/GainFade.h)
+    ROOT_CHANNEL = P0, ROOT_TARGET = P1, ROOT_STEP = P2, ROOT_HASIN = P3, ROOT_GAIN = S0,
+    // delay / sdelay rings: device pointer (2 dwords), size, length, reset-pending flag
+    RING_PTR = P0, RING_SIZE = P2, RING_LEN = P3, RING_RESET = P4, RING_WRITE = S0,
+    // seq (Core.h:407-573)
+    SEQ_HOLD = P0, SEQ_LOOP = P1, SEQ_OFFSET = P2, SEQ_PTR = P4, SEQ_LEN = P6, SEQ_PENDING = P7,
+    SEQ_INDEX = S0, SEQ_HOLDVAL = S1, SEQ_FIRST = S2, SEQ_CHANGE = S3, SEQ_RCHANGE = S4, SEQ_HAVE = S5,
+    // taps (Feedback.h)
+    TAP_SHARED = P0, TAP_PRIVATE = P2,
+};
+}
+
+} // namespace elemhip

@@ -1,0 +1,853 @@
+// engine.cpp — instruction interpreter, node table, device-resident node records and the
+// per-block launch sequence. See engine.h for the mapping onto runtime/elem/Runtime.h.
+#include "engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "launch.h"
+
+namespace elemhip {
+
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    std::fprintf(stderr, "[elemhip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return kHipError; } } while (0)
+#define HIP_WARN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    std::fprintf(stderr, "[elemhip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
+
+const char* describe(int c) {
+    switch (c) {   // 0..8: runtime/elem/Types.h:62-85
+        case 0: return "Ok";
+        case 1: return "Node type not recognized";
+        case 2: return "Node not found";
+        case 3: return "Attempting to create a node that already exists";
+        case 4: return "Attempting to create a node type that already exists";
+        case 5: return "Invalid value type for the given node property";
+        case 6: return "Invalid value for the given node property";
+        case 7: return "Invariant violation";
+        case 8: return "Invalid instruction format";
+        case kHipError: return "HIP runtime error";
+        case kNoDevice: return "No HIP device available";
+        case kBlockTooLarge: return "numSamples exceeds the block size the runtime was created with";
+        case kTooManyChannels: return "Too many host channels";
+        case kUnsupportedGraph: return "Graph uses a construct the HIP engine does not support";
+        case kJsonParseError: return "Failed to parse json string";
+        default: return "Return code not recognized";
+    }
+}
+
+// Registry: reference node-type names (DefaultNodeTypes.h:49-144, wasm/Main.cpp:47-61) -> opcode
+static const std::unordered_map<std::string, uint16_t>& opTable() {
+    static const std::unordered_map<std::string, uint16_t> t = {
+        {"in", OP_IN}, {"sin", OP_SIN}, {"cos", OP_COS}, {"tan", OP_TAN}, {"tanh", OP_TANH}, {"asinh", OP_ASINH},
+        {"ln", OP_LN}, {"log", OP_LOG}, {"log2", OP_LOG2}, {"ceil", OP_CEIL}, {"floor", OP_FLOOR}, {"round", OP_ROUND},
+        {"sqrt", OP_SQRT}, {"exp", OP_EXP}, {"abs", OP_ABS},
+        {"le", OP_LE}, {"leq", OP_LEQ}, {"ge", OP_GE}, {"geq", OP_GEQ}, {"pow", OP_POW}, {"eq", OP_EQ}, {"and", OP_AND}, {"or", OP_OR},
+        {"add", OP_ADD}, {"sub", OP_SUB}, {"mul", OP_MUL}, {"div", OP_DIV}, {"mod", OP_MOD}, {"min", OP_MIN}, {"max", OP_MAX},
+        {"root", OP_ROOT}, {"const", OP_CONST}, {"phasor", OP_PHASOR}, {"sphasor", OP_SPHASOR}, {"sr", OP_SR}, {"seq", OP_SEQ},
+        {"counter", OP_COUNTER}, {"accum", OP_ACCUM}, {"latch", OP_LATCH}, {"maxhold", OP_MAXHOLD}, {"once", OP_ONCE}, {"rand", OP_RAND},
+        {"delay", OP_DELAY}, {"sdelay", OP_SDELAY}, {"z", OP_Z},
+        {"pole", OP_POLE}, {"env", OP_ENV}, {"biquad", OP_BIQUAD}, {"prewarp", OP_PREWARP}, {"mm1p", OP_MM1P}, {"svf", OP_SVF}, {"svfshelf", OP_SVFSHELF},
+        {"tapIn", OP_TAPIN}, {"tapOut", OP_TAPOUT},
+        {"blepsaw", OP_BLEPSAW}, {"blepsquare", OP_BLEPSQUARE}, {"bleptriangle", OP_BLEPTRIANGLE},
+        {"time", OP_TIME}, {"metro", OP_METRO},
+    };
+    return t;
+}
+
+static inline uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+static int bitceil(int n) {   // builtins/helpers/BitUtils.h:9-20
+    if ((n & (n - 1)) == 0) return n;
+    int o = 1;
+    while (o < n) o <<= 1;
+    return o;
+}
+
+static inline float clampf(float v, float lo, float hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }
+
+static double msToStep(double sr, double ms) {   // helpers/GainFade.h:10-12
+    return ms > 1e-6 ? 1.0 / (sr * ms / 1000.0) : 1.0;
+}
+
+Plan::~Plan() {
+    if (graphExec) (void)hipGraphExecDestroy(graphExec);
+    if (dev.ptr) (void)hipFree(dev.ptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), device(dev) {
+    auto fail = [&](int code) { initErr = code; };
+    if (bs <= 0 || bs > (int)kMaxBlock) { fail(kBlockTooLarge); return; }
+    if (dev == -1) {
+        // "dry" engine: host logic only (instruction decode, graph mutation, plan build, gc) with
+        // no device behind it. It cannot render: process() returns kNoDevice. Used by CPU-only tests.
+        dry = true;
+        hGlobals = Globals{};
+        hGlobals.numSamples = (uint32_t)bs; hGlobals.ringSlots = 1; hGlobals.blockStride = (uint32_t)bs;
+        hGlobals.sampleRateF = (float)sr; hGlobals.sampleRate = sr;
+        return;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { fail(kNoDevice); return; }
+    if (dev < 0 || dev >= count) { fail(kNoDevice); return; }
+    if (hipSetDevice(dev) != hipSuccess) { fail(kHipError); return; }
+    if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { fail(kHipError); return; }
+    ownStream = true;
+
+    recCapacity = 8192;
+    if (hipMalloc(&dRecs, (size_t)recCapacity * kRecDwords * 4) != hipSuccess) { fail(kHipError); return; }
+    (void)hipMemset(dRecs, 0, (size_t)recCapacity * kRecDwords * 4);
+    shadow.reserve((size_t)recCapacity * kRecDwords);
+
+    patchCap = 1u << 16;
+    if (hipHostMalloc((void**)&hPatches, sizeof(Patch) * patchCap, hipHostMallocDefault) != hipSuccess) { fail(kHipError); return; }
+
+    hGlobals = Globals{};
+    hGlobals.sampleTime = 0;
+    hGlobals.numSamples = (uint32_t)bs;
+    hGlobals.ringSlots = 1;
+    hGlobals.blockStride = (uint32_t)bs;
+    hGlobals.sampleRateF = (float)sr;
+    hGlobals.sampleRate = sr;
+    if (hipMalloc(&dGlobals, sizeof(Globals)) != hipSuccess) { fail(kHipError); return; }
+    (void)hipMemcpy(dGlobals, &hGlobals, sizeof(Globals), hipMemcpyHostToDevice);
+
+    // LCG jump-ahead table for `rand` (Noise.h:28-32): s_k = A[k]*s_0 + C[k] (mod 2^32)
+    std::vector<uint32_t> lcg(2 * (kMaxBlock + 1));
+    uint32_t A = 1, Cc = 0;
+    for (uint32_t k = 0; k <= kMaxBlock; ++k) {
+        lcg[2 * k] = A; lcg[2 * k + 1] = Cc;
+        A = 214013u * A; Cc = 214013u * Cc + 2531011u;
+    }
+    if (hipMalloc(&dLcg, lcg.size() * 4) != hipSuccess) { fail(kHipError); return; }
+    (void)hipMemcpy(dLcg, lcg.data(), lcg.size() * 4, hipMemcpyHostToDevice);
+
+    if (ensureHbm(kMaxHostIn + 64) != kOk) { fail(kHipError); return; }
+    if (ensureOutRing((size_t)8 * bs) != kOk) { fail(kHipError); return; }
+    if (const char* e = std::getenv("ELEMHIP_NO_GRAPH")) useGraph = !(e[0] == '1');
+}
+
+Engine::~Engine() {
+    if (dry) {
+        for (auto& kv : nodes) std::free(kv.second.ring.ptr);
+        for (auto& kv : resources) std::free(kv.second->dev.ptr);
+        return;
+    }
+    if (stream) (void)hipStreamSynchronize(stream);
+    current.reset(); pending.reset();
+    for (auto& kv : nodes) if (kv.second.ring.ptr) (void)hipFree(kv.second.ring.ptr);
+    for (auto& kv : resources) if (kv.second->dev.ptr) (void)hipFree(kv.second->dev.ptr);
+    freeDeferred();
+    if (dRecs) (void)hipFree(dRecs);
+    if (dGlobals) (void)hipFree(dGlobals);
+    if (dLcg) (void)hipFree(dLcg);
+    if (dHbm) (void)hipFree(dHbm);
+    if (dOutRing) (void)hipFree(dOutRing);
+    if (hPatches) (void)hipHostFree(hPatches);
+    if (hOut) (void)hipHostFree(hOut);
+    if (hIn) (void)hipHostFree(hIn);
+    if (ownStream && stream) (void)hipStreamDestroy(stream);
+}
+
+void Engine::setStream(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (dry) return;
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (ownStream && stream) (void)hipStreamDestroy(stream);
+    stream = s; ownStream = false;
+    if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
+}
+
+void Engine::freeDeferred() {
+    for (void* p : deferredFree) (void)hipFree(p);
+    deferredFree.clear();
+}
+
+int Engine::ensureHbm(size_t buffers) {
+    if (buffers <= hbmBuffers) return kOk;
+    size_t want = std::max(buffers, hbmBuffers * 2);
+    float* nb = nullptr;
+    HIP_OK(hipMalloc(&nb, want * blockSize * sizeof(float)));
+    HIP_OK(hipMemset(nb, 0, want * blockSize * sizeof(float)));
+    if (dHbm) deferredFree.push_back(dHbm);
+    dHbm = nb; hbmBuffers = want;
+    return kOk;
+}
+
+int Engine::ensureOutRing(size_t floats) {
+    if (floats <= outRingFloats) return kOk;
+    float* nb = nullptr;
+    HIP_OK(hipMalloc(&nb, floats * sizeof(float)));
+    HIP_OK(hipMemset(nb, 0, floats * sizeof(float)));
+    if (dOutRing) deferredFree.push_back(dOutRing);
+    dOutRing = nb; outRingFloats = floats;
+    if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
+    return kOk;
+}
+
+uint32_t Engine::allocRec() {
+    uint32_t r;
+    if (!freeRecs.empty()) { r = freeRecs.back(); freeRecs.pop_back(); }
+    else r = nextRec++;
+    if (shadow.size() < (size_t)(r + 1) * kRecDwords) shadow.resize((size_t)(r + 1) * kRecDwords, 0u);
+    std::fill(shadow.begin() + (size_t)r * kRecDwords, shadow.begin() + (size_t)(r + 1) * kRecDwords, 0u);
+    if (freshFlag.size() <= r) freshFlag.resize((size_t)r + 1, 0);
+    freshFlag[r] = 1;
+    freshRecs.push_back(r);
+    return r;
+}
+
+void Engine::writeParam(Node& n, uint32_t dword, uint32_t value) {
+    const uint32_t idx = n.rec * kRecDwords + dword;
+    shadow[idx] = value;
+    // a record that has not been uploaded yet travels whole; otherwise patch the one dword
+    if (!freshFlag[n.rec])
+        patches.push_back(Patch{0u, idx, value, 0u});
+}
+
+void Engine::writeParamPtr(Node& n, uint32_t dword, const void* p) {
+    const uint64_t v = (uint64_t)reinterpret_cast<uintptr_t>(p);
+    writeParam(n, dword, (uint32_t)(v & 0xFFFFFFFFu));
+    writeParam(n, dword + 1, (uint32_t)(v >> 32));
+}
+
+int Engine::allocRing(Node& n, size_t floats) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(floats, 1) * sizeof(float);
+    if (dry) {
+        p = std::calloc(1, bytes);
+        std::free(n.ring.ptr);
+        n.ring.ptr = p; n.ring.bytes = bytes;
+        return kOk;
+    }
+    HIP_OK(hipMalloc(&p, bytes));
+    HIP_OK(hipMemset(p, 0, bytes));
+    if (n.ring.ptr) deferredFree.push_back(n.ring.ptr);
+    n.ring.ptr = p; n.ring.bytes = bytes;
+    return kOk;
+}
+
+int Engine::ensureResourceOnDevice(const ResourcePtr& r) {
+    if (r->dev.ptr) return kOk;
+    const size_t have = r->channels.empty() ? 0 : r->channels[0].size();
+    const size_t floats = std::max<size_t>(have, (size_t)blockSize);
+    void* p = nullptr;
+    if (dry) { r->dev.ptr = std::calloc(floats, sizeof(float)); r->dev.bytes = floats * sizeof(float); return kOk; }
+    HIP_OK(hipMalloc(&p, floats * sizeof(float)));
+    HIP_OK(hipMemset(p, 0, floats * sizeof(float)));
+    if (have) HIP_OK(hipMemcpy(p, r->channels[0].data(), have * sizeof(float), hipMemcpyHostToDevice));
+    r->dev.ptr = p; r->dev.bytes = floats * sizeof(float);
+    return kOk;
+}
+
+// SharedResourceMap::getTapResource (SharedResource.h:79-92)
+ResourcePtr Engine::tapResource(const std::string& name) {
+    auto it = resources.find(name);
+    if (it != resources.end()) return it->second;
+    auto r = std::make_shared<Resource>();
+    r->channels.emplace_back((size_t)blockSize, 0.0f);
+    r->isTap = true;
+    resources.emplace(name, r);
+    return r;
+}
+
+// GainFade::updateCurrentStep (helpers/GainFade.h:107-109)
+void Engine::rootUpdateStep(Node& n) {
+    n.step = (n.gain > n.target) ? n.outStep : n.inStep;
+    writeParamF(n, rec::ROOT_TARGET, n.target);
+    writeParamF(n, rec::ROOT_STEP, n.step);
+}
+
+// ---- instructions ------------------------------------------------------------------------------
+int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293-313
+    auto it = opTable().find(type);
+    if (it == opTable().end()) return kUnknownNodeType;
+    if (nodes.find(id) != nodes.end()) return kNodeAlreadyExists;
+    Node n;
+    n.id = id; n.op = it->second; n.rec = allocRec();
+    uint32_t* r = shadow.data() + (size_t)n.rec * kRecDwords;
+    switch (n.op) {
+        case OP_CONST: r[rec::P0] = fbits(1.0f); break;                           // Core.h:166
+        case OP_SR:    r[rec::P0] = fbits((float)sampleRate); break;              // Core.h:178
+        case OP_IN:    r[rec::P0] = 0u; break;                                    // Math.h:125
+        case OP_ROOT: {                                                           // Core.h:80-82
+            n.gain = 0.0f; n.target = 1.0f; n.channel = -1;
+            n.inStep = (float)msToStep(sampleRate, 20);
+            n.outStep = (float)((double)(-1.0f) * msToStep(sampleRate, 20));
+            n.step = (n.gain > n.target) ? n.outStep : n.inStep;
+            r[rec::ROOT_CHANNEL] = (uint32_t)-1; r[rec::ROOT_TARGET] = fbits(n.target);
+            r[rec::ROOT_STEP] = fbits(n.step); r[rec::ROOT_GAIN] = fbits(n.gain);
+            break;
+        }
+        case OP_MAXHOLD: r[rec::P0] = 0xFFFFFFFFu; break;                         // Core.h:336
+        case OP_SEQ:     r[rec::SEQ_HOLD] = 0; r[rec::SEQ_LOOP] = 1; break;       // Core.h:566-568
+        case OP_RAND:    r[rec::S0] = (uint32_t)std::rand(); break;               // Noise.h:42
+        case OP_METRO: {                                                          // wasm/Metro.h:15
+            const int64_t is = (int64_t)std::max(2.0, 1000.0 * 0.001 * sampleRate);
+            r[rec::P0] = (uint32_t)((uint64_t)is & 0xFFFFFFFFu); r[rec::P1] = (uint32_t)((uint64_t)is >> 32);
+            n.props["interval"] = Value::number(1000.0);
+            break;
+        }
+        default: break;
+    }
+    auto ins = nodes.emplace(id, std::move(n));
+    Node& nn = ins.first->second;
+    int rc = kOk;
+    if (nn.op == OP_DELAY || nn.op == OP_SDELAY) {                                // Delays.h:56, 183
+        rc = setProperty(id, "size", Value::number((double)blockSize));
+    } else if (nn.op == OP_TAPOUT) {                                              // Feedback.h:66-67
+        rc = allocRing(nn, (size_t)blockSize);
+        if (rc == kOk) writeParamPtr(nn, rec::TAP_PRIVATE, nn.ring.ptr);
+    }
+    return rc;
+}
+
+int Engine::appendChild(int32_t parent, int32_t child, int32_t channel) {   // Runtime.h:335-366
+    auto p = nodes.find(parent);
+    if (p == nodes.end()) return kNodeNotFound;
+    auto c = nodes.find(child);
+    if (c == nodes.end()) return kNodeNotFound;
+    p->second.inlets.push_back(Inlet{child, (uint32_t)channel});
+    c->second.outlets.push_back(Outlet{parent, (uint32_t)channel});
+    return kOk;
+}
+
+int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   // Runtime.h:315-333
+    auto it = nodes.find(id);
+    if (it == nodes.end()) return kNodeNotFound;
+    Node& n = it->second;
+    switch (n.op) {
+        case OP_CONST:                                             // Core.h:142-152
+            if (key == "value") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                writeParamF(n, rec::P0, (float)v.num);
+            }
+            break;
+        case OP_IN:                                                // Math.h:95-105
+            if (key == "channel") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                writeParam(n, rec::P0, (uint32_t)(int)v.num);
+            }
+            break;
+        case OP_ROOT:                                              // Core.h:33-64
+            if (key == "active") {
+                if (!v.isBool()) return kInvalidPropertyType;
+                n.target = v.b ? 1.0f : 0.0f;                      // fadeIn / fadeOut
+                rootUpdateStep(n);
+            }
+            if (key == "channel") {
+                if (!v.isNumber()) return kInvalidPropertyType;    // (reference: bad_variant_access)
+                n.channel = (int)v.num;
+                writeParam(n, rec::ROOT_CHANNEL, (uint32_t)n.channel);
+            }
+            if (key == "fadeInMs") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                n.inStep = (float)msToStep(sampleRate, v.num);
+                rootUpdateStep(n);
+            }
+            if (key == "fadeOutMs") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                n.outStep = (float)((double)(-1.0f) * msToStep(sampleRate, v.num));
+                rootUpdateStep(n);
+            }
+            break;
+        case OP_MAXHOLD:                                           // Core.h:292-303
+            if (key == "hold") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                const double h = sampleRate * 0.001 * v.num;
+                writeParam(n, rec::P0, (uint32_t)h);
+            }
+            break;
+        case OP_ONCE:                                              // Core.h:352-366
+            if (key == "arm") {
+                if (!v.isBool()) return kInvalidPropertyType;
+                if (v.b) {
+                    const uint32_t idx = n.rec * kRecDwords + rec::S2;
+                    if (freshFlag[n.rec]) shadow[idx] = fbits(1.0f);
+                    else patches.push_back(Patch{1u, idx, fbits(1.0f), 0u});
+                }
+            }
+            break;
+        case OP_SEQ:                                               // Core.h:411-458
+            if (key == "hold") { if (!v.isBool()) return kInvalidPropertyType; writeParam(n, rec::SEQ_HOLD, v.b ? 1u : 0u); }
+            if (key == "loop") { if (!v.isBool()) return kInvalidPropertyType; writeParam(n, rec::SEQ_LOOP, v.b ? 1u : 0u); }
+            if (key == "offset") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                if (v.num < 0.0) return kInvalidPropertyValue;
+                writeParam(n, rec::SEQ_OFFSET, (uint32_t)(uint64_t)v.num);
+            }
+            if (key == "seq") {
+                if (!v.isArray()) return kInvalidPropertyType;
+                std::vector<float> data(v.arr.size());
+                for (size_t i = 0; i < v.arr.size(); ++i) {
+                    if (!v.arr[i].isNumber()) return kInvalidPropertyType;
+                    data[i] = (float)v.arr[i].num;
+                }
+                int rc = allocRing(n, data.size());
+                if (rc != kOk) return rc;
+                if (!data.empty() && dry) std::memcpy(n.ring.ptr, data.data(), data.size() * 4);
+                if (!data.empty() && !dry) HIP_OK(hipMemcpy(n.ring.ptr, data.data(), data.size() * 4, hipMemcpyHostToDevice));
+                writeParamPtr(n, rec::SEQ_PTR, n.ring.ptr);
+                writeParam(n, rec::SEQ_LEN, (uint32_t)data.size());
+                writeParam(n, rec::SEQ_PENDING, 1u);
+            }
+            break;
+        case OP_RAND:                                              // Noise.h:13-23
+            if (key == "seed") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                writeParam(n, rec::S0, (uint32_t)(int64_t)v.num);
+            }
+            break;
+        case OP_DELAY:                                             // Delays.h:59-82
+            if (key == "size") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                const int size = (int)v.num;
+                if (size < 0) return kInvalidPropertyValue;
+                int rc = allocRing(n, (size_t)size);
+                if (rc != kOk) return rc;
+                writeParamPtr(n, rec::RING_PTR, n.ring.ptr);
+                writeParam(n, rec::RING_SIZE, (uint32_t)size);
+                writeParam(n, rec::RING_RESET, 1u);
+            }
+            break;
+        case OP_SDELAY:                                            // Delays.h:186-216
+            if (key == "size") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                const int len = (int)v.num;
+                const int size = bitceil(len + blockSize);
+                if (size < 0) return kInvalidPropertyValue;
+                int rc = allocRing(n, (size_t)size);
+                if (rc != kOk) return rc;
+                writeParamPtr(n, rec::RING_PTR, n.ring.ptr);
+                writeParam(n, rec::RING_SIZE, (uint32_t)size);
+                writeParam(n, rec::RING_LEN, (uint32_t)len);
+                writeParam(n, rec::RING_RESET, 1u);
+            }
+            break;
+        case OP_SVF:                                               // filters/SVF.h:30-46
+            if (key == "mode") {
+                if (!v.isString()) return kInvalidPropertyType;
+                int m = -1;
+                if (v.str == "lowpass") m = 0; if (v.str == "bandpass") m = 1; if (v.str == "highpass") m = 2;
+                if (v.str == "notch") m = 3; if (v.str == "allpass") m = 4;
+                if (m >= 0) writeParam(n, rec::P0, (uint32_t)m);
+            }
+            break;
+        case OP_SVFSHELF:                                          // filters/SVFShelf.h:29-42
+            if (key == "mode") {
+                if (!v.isString()) return kInvalidPropertyType;
+                int m = -1;
+                if (v.str == "lowshelf") m = 0; if (v.str == "highshelf") m = 1;
+                if (v.str == "bell" || v.str == "peak") m = 2;
+                if (m >= 0) writeParam(n, rec::P0, (uint32_t)m);
+            }
+            break;
+        case OP_MM1P:                                              // filters/MultiMode1p.h:48-62
+            if (key == "mode") {
+                if (!v.isString()) return kInvalidPropertyType;
+                int m = -1;
+                if (v.str == "lowpass") m = 0; if (v.str == "highpass") m = 2; if (v.str == "allpass") m = 4;
+                if (m >= 0) writeParam(n, rec::P0, (uint32_t)m);
+            }
+            break;
+        case OP_TAPIN: case OP_TAPOUT:                             // Feedback.h:24-38, 70-84
+            if (key == "name") {
+                if (!v.isString()) return kInvalidPropertyType;
+                ResourcePtr r = tapResource(v.str);
+                int rc = ensureResourceOnDevice(r);
+                if (rc != kOk) return rc;
+                n.res = r;
+                writeParamPtr(n, rec::TAP_SHARED, r->dev.ptr);
+            }
+            break;
+        case OP_METRO:                                             // wasm/Metro.h:18-34
+            if (key == "interval") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                if (0 >= v.num) return kInvalidPropertyValue;
+                const double is = v.num * 0.001 * sampleRate;
+                const int64_t iv = (int64_t)std::max(2.0, is);
+                writeParam(n, rec::P0, (uint32_t)((uint64_t)iv & 0xFFFFFFFFu));
+                writeParam(n, rec::P1, (uint32_t)((uint64_t)iv >> 32));
+            }
+            break;
+        default: break;
+    }
+    n.props[key] = v;   // GraphNode::setProperty (GraphNode.h:108-111)
+    return kOk;
+}
+
+int Engine::activateRoots(const std::vector<int32_t>& ids) {   // Runtime.h:368-433
+    std::set<int32_t> active;
+    for (int32_t id : ids) {
+        auto it = nodes.find(id);
+        if (it == nodes.end()) return kNodeNotFound;
+        if (it->second.op == OP_ROOT) {
+            setProperty(id, "active", Value::boolean(true));
+            active.insert(id);
+        }
+    }
+    for (int32_t id : currentRoots) {
+        auto it = nodes.find(id);
+        if (it == nodes.end() || it->second.op != OP_ROOT) continue;
+        Node& n = it->second;
+        if (active.count(id) == 0) setProperty(id, "active", Value::boolean(false));
+        const bool on = n.target > 0.5f;
+        const bool settled = std::fabs(n.target - n.gain) <= 1e-6f;
+        if (on || !settled) active.insert(id);          // stillRunning(): keep fading roots
+    }
+    currentRoots.swap(active);
+    shouldRebuild = true;
+    return kOk;
+}
+
+int Engine::commit() {   // Runtime.h:202-206
+    if (shouldRebuild) {
+        auto t0 = std::chrono::steady_clock::now();
+        auto p = buildPlan();
+        if (!p) return kUnsupportedGraph;
+        pending = p;
+        shouldRebuild = false;
+        st.plansBuilt++;
+        st.lastPlanBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return kOk;
+}
+
+int Engine::apply(const Value& batch) {   // Runtime.h:170-218
+    std::lock_guard<std::mutex> lock(mu);
+    if (!dry && hipSetDevice(device) != hipSuccess) return kHipError;
+    if (!batch.isArray()) return kInvalidInstructionFormat;
+    shouldRebuild = false;   // a local in the reference: ACTIVATE_ROOTS and COMMIT must share a batch
+    for (const Value& next : batch.arr) {
+        if (!next.isArray()) return kInvalidInstructionFormat;
+        const auto& ar = next.arr;
+        if (ar.empty() || !ar[0].isNumber()) return kInvalidInstructionFormat;
+        const int cmd = (int)ar[0].num;
+        int res = kOk;
+        static const Value undef;
+        auto arg = [&](size_t i) -> const Value& { return i < ar.size() ? ar[i] : undef; };
+        switch (cmd) {
+            case 0:   // CREATE_NODE
+                if (!arg(1).isNumber() || !arg(2).isString()) { res = kInvalidInstructionFormat; break; }
+                res = createNode((int32_t)arg(1).num, arg(2).str);
+                break;
+            case 3:   // SET_PROPERTY
+                if (!arg(1).isNumber() || !arg(2).isString()) { res = kInvalidInstructionFormat; break; }
+                res = setProperty((int32_t)arg(1).num, arg(2).str, arg(3));
+                break;
+            case 2:   // APPEND_CHILD
+                if (!arg(1).isNumber() || !arg(2).isNumber() || !arg(3).isNumber()) { res = kInvalidInstructionFormat; break; }
+                res = appendChild((int32_t)arg(1).num, (int32_t)arg(2).num, (int32_t)arg(3).num);
+                break;
+            case 4: { // ACTIVATE_ROOTS
+                if (!arg(1).isArray()) { res = kInvalidInstructionFormat; break; }
+                std::vector<int32_t> ids;
+                bool bad = false;
+                for (const Value& v : arg(1).arr) { if (!v.isNumber()) { bad = true; break; } ids.push_back((int32_t)v.num); }
+                // the reference activates the roots preceding a malformed id before failing
+                res = activateRoots(ids);
+                if (res == kOk && bad) res = kInvalidInstructionFormat;
+                shouldRebuild = true;
+                break;
+            }
+            case 5:   // COMMIT_UPDATES
+                res = commit();
+                break;
+            default: break;
+        }
+        if (res != kOk) return res;
+    }
+    return kOk;
+}
+
+// ---- gc / resources -------------------------------------------------------------------------------
+size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
+    std::lock_guard<std::mutex> lock(mu);
+    if (!dry) (void)hipSetDevice(device);
+    std::vector<int32_t> pruned;
+    for (auto it = nodes.begin(); it != nodes.end(); ++it) {
+        const int32_t id = it->first;
+        const bool held = (current && current->nodeIds.count(id)) || (pending && pending->nodeIds.count(id));
+        if (!held) pruned.push_back(id);
+    }
+    std::set<int32_t> prunedSet(pruned.begin(), pruned.end());
+    for (int32_t id : pruned) {
+        Node& n = nodes.at(id);
+        for (auto& inlet : n.inlets) {
+            auto c = nodes.find(inlet.source);
+            if (c == nodes.end() || prunedSet.count(inlet.source)) continue;
+            auto& o = c->second.outlets;
+            o.erase(std::remove_if(o.begin(), o.end(), [&](const Outlet& x) { return x.dest == id; }), o.end());
+        }
+    }
+    for (int32_t id : pruned) {
+        Node& n = nodes.at(id);
+        if (n.ring.ptr) { if (dry) std::free(n.ring.ptr); else (void)hipFree(n.ring.ptr); }   // device is idle whenever `mu` is free
+        // drop queued writes aimed at the record before it is recycled
+        const uint32_t lo = n.rec * kRecDwords, hi = lo + kRecDwords;
+        patches.erase(std::remove_if(patches.begin(), patches.end(), [&](const Patch& p) { return p.kind != 2 && p.index >= lo && p.index < hi; }), patches.end());
+        if (freshFlag[n.rec]) { freshRecs.erase(std::remove(freshRecs.begin(), freshRecs.end(), n.rec), freshRecs.end()); freshFlag[n.rec] = 0; }
+        freeRecs.push_back(n.rec);
+        nodes.erase(id);
+    }
+    std::sort(pruned.begin(), pruned.end());
+    size_t k = 0;
+    for (int32_t id : pruned) { if (out && k < cap) out[k] = id; ++k; }
+    return k;
+}
+
+void Engine::reset() {}   // Runtime.h:448-458: only SampleNode (out of scope) reacts to reset()
+
+bool Engine::addSharedResource(const std::string& name, const float* const* ch, size_t nCh, size_t nSamples) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (resources.count(name)) return false;                 // insert-only (SharedResource.h:61-63)
+    auto r = std::make_shared<Resource>();
+    for (size_t c = 0; c < nCh; ++c) r->channels.emplace_back(ch[c], ch[c] + nSamples);
+    resources.emplace(name, r);
+    return true;
+}
+
+void Engine::pruneSharedResources() {   // SharedResource.h:94-102
+    std::lock_guard<std::mutex> lock(mu);
+    if (!dry) (void)hipSetDevice(device);
+    for (auto it = resources.begin(); it != resources.end();) {
+        if (it->second.use_count() == 1) {
+            if (it->second->dev.ptr) { if (dry) std::free(it->second->dev.ptr); else (void)hipFree(it->second->dev.ptr); }
+            it = resources.erase(it);
+        } else ++it;
+    }
+}
+
+int Engine::setOption(const std::string& key, double value) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
+    if (key == "graph_blocks") { graphBlocks = std::max(1, (int)value); if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; } return kOk; }
+    return kInvalidPropertyValue;
+}
+
+// ---- block rendering ----------------------------------------------------------------------------------
+void Engine::flushPending() {
+    if (nextRec > recCapacity) {   // grow the record arena (device idle: we hold `mu` and sync every call)
+        uint32_t cap = recCapacity;
+        while (cap < nextRec) cap *= 2;
+        uint32_t* nr = nullptr;
+        if (hipMalloc(&nr, (size_t)cap * kRecDwords * 4) == hipSuccess) {
+            (void)hipMemset(nr, 0, (size_t)cap * kRecDwords * 4);
+            (void)hipMemcpy(nr, dRecs, (size_t)recCapacity * kRecDwords * 4, hipMemcpyDeviceToDevice);
+            (void)hipFree(dRecs);
+            dRecs = nr; recCapacity = cap;
+            if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
+        }
+    }
+    if (!freshRecs.empty()) {
+        std::sort(freshRecs.begin(), freshRecs.end());
+        size_t i = 0;
+        while (i < freshRecs.size()) {
+            size_t j = i + 1;
+            while (j < freshRecs.size() && freshRecs[j] == freshRecs[j - 1] + 1) ++j;
+            const uint32_t first = freshRecs[i];
+            const size_t count = j - i;
+            HIP_WARN(hipMemcpyAsync(dRecs + (size_t)first * kRecDwords, shadow.data() + (size_t)first * kRecDwords,
+                                    count * kRecDwords * 4, hipMemcpyHostToDevice, stream));
+            i = j;
+        }
+        HIP_WARN(hipStreamSynchronize(stream));   // `shadow` is pageable; keep it stable until copied
+        for (uint32_t r : freshRecs) freshFlag[r] = 0;
+        freshRecs.clear();
+    }
+    size_t off = 0;
+    while (off < patches.size()) {
+        const size_t cnt = std::min<size_t>(patchCap, patches.size() - off);
+        std::memcpy(hPatches, patches.data() + off, cnt * sizeof(Patch));
+        launch_patches(stream, hPatches, (uint32_t)cnt, dRecs, reinterpret_cast<uint32_t*>(dGlobals));
+        off += cnt;
+        if (off < patches.size()) HIP_WARN(hipStreamSynchronize(stream));
+    }
+    if (!patches.empty()) {
+        // the staging buffer is reused by the next call; kernels of this call run after the patch kernel
+        patches.clear();
+    }
+}
+
+int Engine::setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime) {
+    auto patchG = [&](size_t byteOff, uint32_t v) { patches.push_back(Patch{2u, (uint32_t)(byteOff / 4), v, 0u}); };
+    if (hGlobals.numSamples != (uint32_t)n) { hGlobals.numSamples = (uint32_t)n; patchG(offsetof(Globals, numSamples), (uint32_t)n); }
+    if (hGlobals.numIn != (uint32_t)nIn) { hGlobals.numIn = (uint32_t)nIn; patchG(offsetof(Globals, numIn), (uint32_t)nIn); }
+    if (hGlobals.numOut != (uint32_t)nOut) { hGlobals.numOut = (uint32_t)nOut; patchG(offsetof(Globals, numOut), (uint32_t)nOut); }
+    if (hGlobals.sampleTime != sampleTime) {
+        hGlobals.sampleTime = sampleTime;
+        patchG(offsetof(Globals, sampleTime), (uint32_t)((uint64_t)sampleTime & 0xFFFFFFFFu));
+        patchG(offsetof(Globals, sampleTime) + 4, (uint32_t)((uint64_t)sampleTime >> 32));
+    }
+    return kOk;
+}
+
+int Engine::swapInPending() {   // Runtime.h:277-285: newest sequence wins
+    if (pending) {
+        current = pending;
+        pending.reset();
+        st.numIslands = (uint32_t)current->islands.size();
+        st.numLevels = (uint32_t)current->levelOffsets.size() - 1;
+        st.numTasks = (uint32_t)current->tasks.size();
+        st.numNodesInPlan = (uint32_t)current->nodeIds.size();
+        st.maxLdsBytes = current->maxLdsBytes;
+        st.numHbmBuffers = current->numHbmBuffers;
+    }
+    if (!current) return kOk;
+    int rc = ensureHbm(current->numHbmBuffers);
+    if (rc != kOk) return rc;
+    if (current->maxLdsBytes > maxLdsConfigured) {
+        HIP_OK(configure_kernels(current->maxLdsBytes));
+        maxLdsConfigured = current->maxLdsBytes;
+    }
+    return kOk;
+}
+
+void Engine::enqueueBlock(const Plan& p) {
+    const size_t L = p.levelOffsets.size() - 1;
+    for (size_t l = 0; l < L; ++l) {
+        const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
+        if (e > b) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l]);
+    }
+    launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, dOutRing);
+}
+
+// Host mirror of what the epilogue kernel does to each root's fade (GainFade.h:56-72), so that
+// activateRoots()/gc() can evaluate stillRunning() without a device read-back.
+void Engine::mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn) {
+    for (int32_t id : p.rootIds) {
+        auto it = nodes.find(id);
+        if (it == nodes.end()) continue;
+        Node& r = it->second;
+        const bool on = r.target > 0.5f;
+        const bool settled = std::fabs(r.target - r.gain) <= 1e-6f;
+        if (!((on || !settled) && r.channel >= 0 && (uint32_t)r.channel < nOut)) continue;
+        if (r.gain != r.target && (!r.inlets.empty() || nIn > 0))
+            r.gain = clampf(r.gain + r.step * (float)(int)n, 0.0f, 1.0f);
+    }
+}
+
+int Engine::process(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (dry) return kNoDevice;
+    if (hipSetDevice(device) != hipSuccess) return kHipError;
+    if (n > (size_t)blockSize) return kBlockTooLarge;
+    if (nIn > kMaxHostIn || nOut > 64) return kTooManyChannels;
+    int rc = swapInPending();
+    if (rc != kOk) return rc;
+    if (!current) return kOk;   // no render sequence yet: outputs untouched (Runtime.h:287-289)
+    const Plan& p = *current;
+
+    if (hGlobals.ringSlots != 1 || hGlobals.blockSlot != 0) {
+        hGlobals.ringSlots = 1; hGlobals.blockSlot = 0;
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, ringSlots) / 4), 1u, 0u});
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, blockSlot) / 4), 0u, 0u});
+    }
+    setGlobalsFor(nIn, nOut, n, sampleTime);
+    rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize);
+    if (rc != kOk) return rc;
+
+    if (nIn > 0) {
+        const size_t floats = nIn * (size_t)blockSize;
+        if (floats > hInFloats) {
+            if (hIn) (void)hipHostFree(hIn);
+            HIP_OK(hipHostMalloc((void**)&hIn, floats * sizeof(float), hipHostMallocDefault));
+            hInFloats = floats;
+        }
+        for (size_t c = 0; c < nIn; ++c) {
+            std::memcpy(hIn + c * blockSize, in[c], n * sizeof(float));
+            if (n < (size_t)blockSize) std::memset(hIn + c * blockSize + n, 0, (blockSize - n) * sizeof(float));
+        }
+        HIP_OK(hipMemcpyAsync(dHbm, hIn, floats * sizeof(float), hipMemcpyHostToDevice, stream));
+    }
+    flushPending();
+    enqueueBlock(p);
+    if (nOut > 0) {
+        const size_t floats = nOut * (size_t)blockSize;
+        if (floats > hOutFloats) {
+            if (hOut) (void)hipHostFree(hOut);
+            HIP_OK(hipHostMalloc((void**)&hOut, floats * sizeof(float), hipHostMallocDefault));
+            hOutFloats = floats;
+        }
+        HIP_OK(hipMemcpyAsync(hOut, dOutRing, floats * sizeof(float), hipMemcpyDeviceToHost, stream));
+    }
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipGetLastError());
+    for (size_t c = 0; c < nOut; ++c) std::memcpy(out[c], hOut + c * blockSize, n * sizeof(float));
+    mirrorRootFades(p, (uint32_t)n, (uint32_t)nOut, (uint32_t)nIn);
+    hGlobals.sampleTime += (int64_t)n;
+    st.blocksRendered++;
+    freeDeferred();
+    return kOk;
+}
+
+int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (dry) return kNoDevice;
+    if (hipSetDevice(device) != hipSuccess) return kHipError;
+    if (nIn > kMaxHostIn || nOut > 64) return kTooManyChannels;
+    int rc = swapInPending();
+    if (rc != kOk) return rc;
+    if (!current || numBlocks == 0) return kOk;
+    Plan& p = *current;
+    const size_t bs = (size_t)blockSize;
+    const bool graphOk = useGraph && nIn == 0;
+    const size_t G = graphOk ? (size_t)graphBlocks : 1;
+    rc = ensureOutRing(std::max<size_t>(nOut, 1) * bs * G);
+    if (rc != kOk) return rc;
+
+    setGlobalsFor(nIn, nOut, bs, sampleTime);
+    size_t done = 0;
+    while (done < numBlocks) {
+        const size_t chunk = std::min(G, numBlocks - done);
+        // ring geometry for this chunk
+        if (hGlobals.ringSlots != (uint32_t)G || hGlobals.blockSlot != 0) {
+            hGlobals.ringSlots = (uint32_t)G; hGlobals.blockSlot = 0;
+            patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, ringSlots) / 4), (uint32_t)G, 0u});
+            patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, blockSlot) / 4), 0u, 0u});
+        }
+        flushPending();
+        if (graphOk && chunk == G) {
+            if (!p.graphExec || p.graphBlocks != (int)G) {
+                if (p.graphExec) { (void)hipGraphExecDestroy(p.graphExec); p.graphExec = nullptr; }
+                hipGraph_t graph = nullptr;
+                HIP_OK(hipStreamSynchronize(stream));
+                HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                for (size_t b = 0; b < G; ++b) enqueueBlock(p);
+                HIP_OK(hipStreamEndCapture(stream, &graph));
+                HIP_OK(hipGraphInstantiate(&p.graphExec, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                p.graphBlocks = (int)G;
+                st.graphCaptures++;
+            }
+            HIP_OK(hipGraphLaunch(p.graphExec, stream));
+            st.graphReplays++;
+        } else {
+            for (size_t b = 0; b < chunk; ++b) {
+                if (nIn > 0 && inDev)
+                    HIP_OK(hipMemcpyAsync(dHbm, inDev + (done + b) * nIn * bs, nIn * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
+                enqueueBlock(p);
+            }
+        }
+        if (outDev && nOut > 0)
+            HIP_OK(hipMemcpyAsync(outDev + done * nOut * bs, dOutRing, chunk * nOut * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        // host mirrors of device-side block state
+        for (size_t b = 0; b < chunk; ++b) mirrorRootFades(p, (uint32_t)bs, (uint32_t)nOut, (uint32_t)nIn);
+        hGlobals.sampleTime += (int64_t)(chunk * bs);
+        hGlobals.blockSlot = (uint32_t)((hGlobals.blockSlot + chunk) % G);
+        done += chunk;
+        st.blocksRendered += chunk;
+    }
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipGetLastError());
+    freeDeferred();
+    return kOk;
+}
+
+} // namespace elemhip

@@ -1,0 +1,199 @@
+// engine.h — host side of the HIP block-render engine.
+//
+// `Engine` re-creates the behaviour of `elem::Runtime<float>` (runtime/elem/Runtime.h:39-153) on
+// top of device-resident node records and compiled render plans:
+//   applyInstructions  -> Engine::apply        (Runtime.h:170-218)
+//   process            -> Engine::process      (Runtime.h:274-290)
+//   gc / reset / shared resources              (Runtime.h:220-272, 448-477)
+// The render sequence the reference builds as a list of closures (Runtime.h:520-577,
+// GraphRenderSequence.h:107-187) becomes a `Plan`: islands of nodes rendered by one workgroup
+// each, grouped into launch levels (plan.cpp).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "device.h"
+#include "json.h"
+
+namespace elemhip {
+
+// Return codes 0..8 are the reference's (runtime/elem/Types.h:51-86); >= 100 are ours.
+enum ReturnCode : int {
+    kOk = 0, kUnknownNodeType = 1, kNodeNotFound = 2, kNodeAlreadyExists = 3, kNodeTypeAlreadyExists = 4,
+    kInvalidPropertyType = 5, kInvalidPropertyValue = 6, kInvariantViolation = 7, kInvalidInstructionFormat = 8,
+    kHipError = 100, kNoDevice = 101, kBlockTooLarge = 102, kTooManyChannels = 103, kUnsupportedGraph = 104,
+    kJsonParseError = 105,
+};
+const char* describe(int code);
+
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+// Shared resource = immutable float channel arrays (SharedResource.h:15-24, AudioBufferResource.h),
+// mirrored into device memory on first use.
+struct Resource {
+    std::vector<std::vector<float>> channels;
+    DevBuf dev;                 // channel 0, uploaded lazily
+    bool isTap = false;         // created by getTapResource (mutable feedback buffer)
+};
+using ResourcePtr = std::shared_ptr<Resource>;
+
+struct Inlet  { int32_t source; uint32_t channel; };
+struct Outlet { int32_t dest; uint32_t channel; };
+
+struct Node {
+    int32_t id = 0;
+    uint16_t op = OP_INVALID;
+    uint32_t rec = kNone;
+    std::vector<Inlet> inlets;
+    std::vector<Outlet> outlets;
+    std::map<std::string, Value> props;
+    // RootNode / GainFade host mirror (helpers/GainFade.h): the device advances the same floats
+    float gain = 0.0f, target = 1.0f, step = 0.0f, inStep = 0.0f, outStep = 0.0f;
+    int channel = -1;
+    // device-side resources owned by the node
+    DevBuf ring;                // delay / sdelay ring, tapOut private buffer, seq data
+    ResourcePtr res;            // tap buffer / sample data held by the node
+};
+
+struct Plan;   // plan.cpp
+
+struct Stats {
+    uint64_t blocksRendered = 0;
+    uint64_t plansBuilt = 0;
+    double   lastPlanBuildMs = 0.0;
+    uint32_t numIslands = 0, numLevels = 0, numTasks = 0, numNodesInPlan = 0, maxLdsBytes = 0, numHbmBuffers = 0;
+    uint64_t graphReplays = 0, graphCaptures = 0;
+};
+
+class Engine {
+public:
+    Engine(double sampleRate, int blockSize, int device);
+    ~Engine();
+    int initError() const { return initErr; }
+
+    int apply(const Value& batch);
+    int createNode(int32_t id, const std::string& type);
+    int appendChild(int32_t parent, int32_t child, int32_t channel);
+    int setProperty(int32_t id, const std::string& key, const Value& v);
+    int activateRoots(const std::vector<int32_t>& ids);
+    int commit();
+
+    // one block, host buffers (Runtime::process)
+    int process(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime);
+    // numBlocks consecutive full blocks, device-resident output `outDev[block][nOut][blockSize]`
+    // (may be null: render only) and optional device-resident input `inDev[block][nIn][blockSize]`
+    int processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime);
+
+    bool addSharedResource(const std::string& name, const float* const* ch, size_t nCh, size_t nSamples);
+    void pruneSharedResources();
+    size_t gc(int32_t* out, size_t cap);
+    void reset();
+    void setStream(hipStream_t s);
+    const Stats& stats() const { return st; }
+    // dry-engine introspection for host-logic tests: adopt the pending plan and describe it as JSON
+    std::string describePlan();
+    int setOption(const std::string& key, double value);
+
+private:
+    friend struct PlanBuilder;
+    int initErr = 0;
+    bool dry = false;                      // device == -1: host logic only, cannot render
+    double sampleRate;
+    int blockSize;
+    int device;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    std::mutex mu;
+    Stats st;
+
+    std::unordered_map<int32_t, Node> nodes;
+    std::set<int32_t> currentRoots;
+    std::unordered_map<std::string, ResourcePtr> resources;
+    bool shouldRebuild = false;
+
+    // record arena
+    uint32_t* dRecs = nullptr;
+    uint32_t recCapacity = 0;
+    std::vector<uint32_t> shadow;          // host copy of every record as last written by the host
+    std::vector<uint32_t> freeRecs;
+    uint32_t nextRec = 0;
+    std::vector<uint32_t> freshRecs;       // records to upload whole before the next block
+    std::vector<uint8_t> freshFlag;        // freshFlag[rec] != 0 while rec is in freshRecs
+    std::vector<Patch> patches;            // param patches to apply before the next block
+    Patch* hPatches = nullptr;             // pinned staging
+    uint32_t patchCap = 0;
+
+    // device globals, host mirror
+    Globals* dGlobals = nullptr;
+    Globals hGlobals{};
+    uint32_t* dLcg = nullptr;
+
+    // buffers
+    float* dHbm = nullptr; size_t hbmBuffers = 0;
+    float* dOutRing = nullptr; size_t outRingFloats = 0;
+    float* hOut = nullptr; size_t hOutFloats = 0;     // pinned
+    float* hIn = nullptr; size_t hInFloats = 0;       // pinned
+    std::vector<void*> deferredFree;
+
+    std::shared_ptr<Plan> current, pending;
+    uint32_t maxLdsConfigured = 0;
+    bool useGraph = true;
+    int  graphBlocks = 8;
+
+    uint32_t allocRec();
+    void writeParam(Node& n, uint32_t dword, uint32_t value);
+    void writeParamF(Node& n, uint32_t dword, float value) { uint32_t u; memcpy(&u, &value, 4); writeParam(n, dword, u); }
+    void writeParamPtr(Node& n, uint32_t dword, const void* p);
+    int  allocRing(Node& n, size_t floats);
+    int  ensureResourceOnDevice(const ResourcePtr& r);
+    ResourcePtr tapResource(const std::string& name);
+    void rootUpdateStep(Node& n);
+    void flushPending();                   // fresh records + patches -> device (stream-ordered)
+    void freeDeferred();
+    int  ensureHbm(size_t buffers);
+    int  ensureOutRing(size_t floats);
+    int  swapInPending();
+    void enqueueBlock(const Plan& p);
+    void mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn);
+    int  setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime);
+    std::shared_ptr<Plan> buildPlan();
+};
+
+// plan.cpp
+struct Plan {
+    std::vector<Island> islands;
+    std::vector<uint32_t> levelIslands;
+    std::vector<uint32_t> levelOffsets;    // numLevels + 1
+    std::vector<uint32_t> levelLdsBytes;
+    std::vector<Task> tasks;
+    std::vector<Member> members;
+    std::vector<uint32_t> operands;
+    std::vector<ConstCell> constCells;
+    std::vector<RootEntry> roots;
+    std::vector<TapEntry> taps;
+    std::vector<int32_t> rootIds;          // same order as `roots`
+    std::set<int32_t> nodeIds;             // every node the render sequence references (gc)
+    uint32_t numHbmBuffers = kMaxHostIn;
+    uint32_t maxLdsBytes = 0;
+    // device copies
+    DevBuf dev;                            // one allocation holding all tables
+    PlanView view{};
+    // captured launch sequence for multi-block offline rendering
+    hipGraphExec_t graphExec = nullptr;
+    int graphBlocks = 0;
+    ~Plan();
+};
+
+} // namespace elemhip

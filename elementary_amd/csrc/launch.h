@@ -1,0 +1,14 @@
+// launch.h — host-callable launchers for the kernels in kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include "device.h"
+
+namespace elemhip {
+
+hipError_t configure_kernels(uint32_t maxLdsBytes);
+void launch_level(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, const uint32_t* lcg,
+                  uint32_t levelBegin, uint32_t numIslands, uint32_t ldsBytes);
+void launch_epilogue(hipStream_t s, const PlanView& pv, uint32_t* recs, const float* hbm, Globals* g, float* outRing);
+void launch_patches(hipStream_t s, const Patch* patches, uint32_t count, uint32_t* recs, uint32_t* globals);
+
+} // namespace elemhip

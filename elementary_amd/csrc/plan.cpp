@@ -1,0 +1,627 @@
+// plan.cpp — render-sequence build: node table -> islands -> device task tables.
+//
+// Step 1 restates Runtime::buildRenderSequence / traverse (runtime/elem/Runtime.h:502-577):
+// roots sorted active-first, DFS post-order per root, children in inlet order, `visited` shared
+// across roots.  Any topological order yields identical samples (buffers are never aliased,
+// GraphRenderSequence.h:121-124); the order still decides which root's sequence OWNS a shared
+// node, and therefore which nodes stop rendering when an inactive root finishes its fade
+// (GraphRenderSequence.h:212-219) and in which order tap buffers are promoted.
+//
+// Steps 2-5 are new: cluster each root sequence into islands (one workgroup, buffers in LDS),
+// schedule each island's nodes into barrier-separated stages of wave tasks, allocate LDS slots
+// by liveness, and order islands into launch levels.
+#include <algorithm>
+#include <cstdio>
+#include <functional>
+#include <numeric>
+#include <unordered_set>
+
+#include <hip/hip_runtime.h>
+
+#include "engine.h"
+
+namespace elemhip {
+
+namespace {
+
+enum Kind : uint8_t { K_CONST, K_PAR, K_SINGLE, K_CHAIN };
+
+Kind kindOf(uint16_t op) {
+    switch (op) {
+        case OP_CONST: case OP_SR: return K_CONST;
+        case OP_RAND: case OP_Z: case OP_SDELAY: case OP_DELAY: return K_SINGLE;
+        case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD:
+        case OP_ONCE: case OP_SEQ: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
+        case OP_SVFSHELF: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
+            return K_CHAIN;
+        default: return K_PAR;
+    }
+}
+
+uint32_t scratchSlots(uint16_t op) {
+    switch (op) {
+        case OP_SVF: case OP_SVFSHELF: return 6;   // a1,a2,a3 as double
+        case OP_MM1P: return 2;                     // G as double
+        case OP_DELAY: return 1;
+        default: return 0;
+    }
+}
+
+// inputs a leaf node of this type would read from the host channels (its reference arity)
+uint32_t leafArity(uint16_t op) {
+    switch (op) {
+        case OP_PHASOR: case OP_COUNTER: case OP_ONCE: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
+        case OP_Z: case OP_SDELAY: case OP_PREWARP: case OP_ROOT: case OP_TAPOUT: return 1;
+        case OP_SPHASOR: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_SEQ: case OP_POLE: case OP_MM1P: return 2;
+        case OP_ENV: case OP_SVF: case OP_DELAY: return 3;
+        case OP_SVFSHELF: return 4;
+        case OP_BIQUAD: return 6;
+        case OP_LE: case OP_LEQ: case OP_GE: case OP_GEQ: case OP_POW: case OP_EQ: case OP_AND: case OP_OR: return 2;
+        case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_MOD: case OP_MIN: case OP_MAX: case OP_IN: return kMaxHostIn;
+        case OP_CONST: case OP_SR: case OP_RAND: case OP_TIME: case OP_METRO: case OP_TAPIN: return 0;
+        default: return 1;   // unary math
+    }
+}
+
+struct NI {                      // per-node planning info
+    Node* n = nullptr;
+    int seq = 0;                 // owning root sequence
+    int pos = 0;                 // position in the global render order
+    Kind kind = K_PAR;
+    int island = -1;
+    int level = 0;               // stage inside the island
+    bool needLds = false;
+    bool exported = false;
+    uint32_t lds = kNone;        // LDS word offset of the output slot
+    uint32_t hbm = kNone;        // HBM arena index
+    uint32_t scratch = kNone;
+    int lastUse = 0;             // last in-island consumer stage
+};
+
+struct IslandBuild {
+    std::vector<int> nodes;      // NI indices in render order
+    int seq = 0;
+    int level = 0;               // launch level
+    std::vector<int> deps;       // islands it imports from
+};
+
+struct UF {
+    std::vector<int> p;
+    int find(int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
+    int add() { p.push_back((int)p.size()); return (int)p.size() - 1; }
+};
+
+} // namespace
+
+struct PlanBuilder {
+    Engine& e;
+    explicit PlanBuilder(Engine& eng) : e(eng) {}
+
+    std::vector<NI> ni;
+    std::unordered_map<int32_t, int> idx;   // node id -> NI index
+    std::vector<std::vector<int>> seqNodes; // per root sequence
+    std::vector<Node*> seqRoots;
+
+    void traverse(std::unordered_set<int32_t>& visited, std::vector<int32_t>& order, int32_t id) {
+        // iterative DFS post-order, children in inlet order (Runtime.h:502-518)
+        struct Frame { int32_t id; size_t next; };
+        if (visited.count(id)) return;
+        std::vector<Frame> st;
+        std::unordered_set<int32_t> onStack;
+        st.push_back({id, 0});
+        onStack.insert(id);
+        while (!st.empty()) {
+            Frame& f = st.back();
+            Node& n = e.nodes.at(f.id);
+            if (f.next < n.inlets.size()) {
+                const int32_t c = n.inlets[f.next++].source;
+                if (visited.count(c) || onStack.count(c) || !e.nodes.count(c)) continue;
+                st.push_back({c, 0});
+                onStack.insert(c);
+            } else {
+                order.push_back(f.id);
+                visited.insert(f.id);
+                onStack.erase(f.id);
+                st.pop_back();
+            }
+        }
+    }
+
+    std::shared_ptr<Plan> build(uint32_t maxIslandNodes);
+};
+
+std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
+    auto plan = std::make_shared<Plan>();
+    Plan& p = *plan;
+    const uint32_t bs = (uint32_t)e.blockSize;
+
+    // ---- 1. render order ---------------------------------------------------------------------
+    std::vector<Node*> sortedRoots;   // std::list push_front/push_back in Runtime.h:544-559
+    {
+        std::vector<Node*> front, back;
+        for (int32_t id : e.currentRoots) {
+            auto it = e.nodes.find(id);
+            if (it == e.nodes.end() || it->second.op != OP_ROOT) continue;
+            auto a = it->second.props.find("active");
+            const bool active = a != it->second.props.end() && a->second.isBool() && a->second.b;
+            if (active) front.push_back(&it->second); else back.push_back(&it->second);
+        }
+        std::reverse(front.begin(), front.end());
+        sortedRoots = front;
+        sortedRoots.insert(sortedRoots.end(), back.begin(), back.end());
+    }
+    std::unordered_set<int32_t> visited;
+    for (size_t s = 0; s < sortedRoots.size(); ++s) {
+        std::vector<int32_t> order;
+        traverse(visited, order, sortedRoots[s]->id);
+        seqRoots.push_back(sortedRoots[s]);
+        seqNodes.emplace_back();
+        for (int32_t id : order) {
+            NI x;
+            x.n = &e.nodes.at(id);
+            x.seq = (int)s;
+            x.pos = (int)ni.size();
+            x.kind = kindOf(x.n->op);
+            idx[id] = (int)ni.size();
+            seqNodes.back().push_back((int)ni.size());
+            ni.push_back(x);
+            p.nodeIds.insert(id);
+        }
+    }
+
+    // ---- 2. islands ---------------------------------------------------------------------------------
+    UF uf;
+    std::vector<uint32_t> weight;            // per island representative
+    std::vector<std::set<int>> succ;         // island DAG (by representative at insertion time)
+    auto rep = [&](int i) { return uf.find(i); };
+    auto newIsland = [&]() { int i = uf.add(); weight.push_back(0); succ.emplace_back(); return i; };
+
+    auto reaches = [&](const std::vector<int>& from, const std::set<int>& targets, const std::set<int>& skip) {
+        // is any island of `targets` reachable from `from` without starting inside `skip`?
+        std::vector<int> stack;
+        std::unordered_set<int> seen;
+        for (int f : from) for (int s : succ[f]) { int r = rep(s); if (!skip.count(r) && seen.insert(r).second) stack.push_back(r); }
+        size_t budget = 20000;
+        while (!stack.empty()) {
+            if (budget-- == 0) return true;   // give up: treat as unsafe
+            int x = stack.back(); stack.pop_back();
+            if (targets.count(x)) return true;
+            for (int s : succ[x]) { int r = rep(s); if (targets.count(r)) return true; if (seen.insert(r).second) stack.push_back(r); }
+        }
+        return false;
+    };
+
+    for (size_t k = 0; k < ni.size(); ++k) {
+        NI& x = ni[k];
+        if (x.kind == K_CONST) continue;
+        const uint32_t w = 1 + scratchSlots(x.n->op);
+        std::set<int> deps, foreign;
+        for (auto& in : x.n->inlets) {
+            auto it = idx.find(in.source);
+            if (it == idx.end()) continue;
+            NI& s = ni[it->second];
+            if (s.kind == K_CONST || in.channel != 0) continue;
+            if (s.seq != x.seq) { foreign.insert(rep(s.island)); continue; }
+            deps.insert(rep(s.island));
+        }
+        int target = -1;
+        if (!deps.empty()) {
+            uint32_t total = w;
+            for (int d : deps) total += weight[d];
+            std::vector<int> dv(deps.begin(), deps.end());
+            if (total <= maxIslandNodes && (deps.size() == 1 || !reaches(dv, deps, deps))) {
+                // a foreign (other-sequence) producer must not be downstream of the merged set
+                if (foreign.empty() || !reaches(dv, foreign, {})) {
+                    target = dv[0];
+                    for (size_t j = 1; j < dv.size(); ++j) {
+                        int a = rep(target), b = rep(dv[j]);
+                        if (a == b) continue;
+                        uf.p[b] = a;
+                        weight[a] += weight[b];
+                        succ[a].insert(succ[b].begin(), succ[b].end());
+                        target = a;
+                    }
+                    target = rep(target);
+                }
+            }
+            if (target < 0) {
+                // join the single producer island that none of the others is downstream of
+                int best = -1;
+                for (int d : dv) {
+                    if (weight[d] + w > maxIslandNodes) continue;
+                    std::set<int> others(deps); others.erase(d);
+                    for (int f : foreign) others.insert(f);
+                    if (!others.empty() && reaches({d}, others, {})) continue;
+                    if (best < 0 || weight[d] > weight[best]) best = d;
+                }
+                target = best;
+            }
+        }
+        if (target < 0) target = newIsland();
+        x.island = target;
+        weight[target] += w;
+        for (int d : deps) if (rep(d) != target) succ[rep(d)].insert(target);
+        for (int f : foreign) if (rep(f) != target) succ[rep(f)].insert(target);
+    }
+
+    // canonical island list
+    std::vector<IslandBuild> ib;
+    std::unordered_map<int, int> islandOf;   // uf representative -> dense index
+    for (size_t k = 0; k < ni.size(); ++k) {
+        NI& x = ni[k];
+        if (x.kind == K_CONST) continue;
+        const int r = rep(x.island);
+        auto it = islandOf.find(r);
+        if (it == islandOf.end()) { it = islandOf.emplace(r, (int)ib.size()).first; ib.emplace_back(); ib.back().seq = x.seq; }
+        x.island = it->second;
+        ib[x.island].nodes.push_back((int)k);
+    }
+
+    // exports, in-island consumers, island deps
+    for (size_t k = 0; k < ni.size(); ++k) {
+        NI& x = ni[k];
+        if (x.kind == K_CONST) continue;
+        if (x.n->op == OP_ROOT) x.exported = true;
+        if (x.kind == K_CHAIN) x.needLds = true;
+    }
+    for (size_t k = 0; k < ni.size(); ++k) {
+        NI& x = ni[k];
+        if (x.kind == K_CONST) continue;
+        for (auto& in : x.n->inlets) {
+            auto it = idx.find(in.source);
+            if (it == idx.end() || in.channel != 0) continue;
+            NI& s = ni[it->second];
+            if (s.kind == K_CONST) continue;
+            if (s.island == x.island) s.needLds = true;
+            else {
+                s.exported = true;
+                auto& d = ib[x.island].deps;
+                if (std::find(d.begin(), d.end(), s.island) == d.end()) d.push_back(s.island);
+            }
+        }
+    }
+
+    // launch levels (Kahn); a leftover island would mean a cycle slipped through clustering
+    {
+        std::vector<int> indeg(ib.size(), 0);
+        std::vector<std::vector<int>> out(ib.size());
+        for (size_t i = 0; i < ib.size(); ++i) for (int d : ib[i].deps) { out[d].push_back((int)i); indeg[i]++; }
+        std::vector<int> q;
+        for (size_t i = 0; i < ib.size(); ++i) if (!indeg[i]) q.push_back((int)i);
+        size_t seen = 0;
+        while (seen < q.size()) {
+            int i = q[seen++];
+            for (int o : out[i]) { ib[o].level = std::max(ib[o].level, ib[i].level + 1); if (--indeg[o] == 0) q.push_back(o); }
+        }
+        if (seen != ib.size()) { std::fprintf(stderr, "[elemhip] plan: island graph is cyclic\n"); return nullptr; }
+    }
+    int numLevels = 0;
+    for (auto& i : ib) numLevels = std::max(numLevels, i.level + 1);
+
+    // HBM arena indices: level-major so one level's exports are contiguous
+    {
+        std::vector<int> order(ib.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ib[a].level < ib[b].level; });
+        uint32_t next = kMaxHostIn;
+        for (int i : order) for (int k : ib[i].nodes) if (ni[k].exported) ni[k].hbm = next++;
+        p.numHbmBuffers = next;
+    }
+
+    // ---- 3/4. per-island schedule, LDS allocation, task emission -------------------------------------
+    p.islands.resize(ib.size());
+    for (size_t ii = 0; ii < ib.size(); ++ii) {
+        IslandBuild& B = ib[ii];
+        Island& I = p.islands[ii];
+        I.rootRec = seqRoots[B.seq]->rec;
+
+        // imports needed in LDS: external producers (or host inputs) feeding chain members
+        struct Import { uint32_t hbm; int lastUse; uint32_t lds; };
+        std::vector<Import> imports;
+        auto importFor = [&](uint32_t hbm) -> int {
+            for (size_t q = 0; q < imports.size(); ++q) if (imports[q].hbm == hbm) return (int)q;
+            imports.push_back(Import{hbm, 0, kNone});
+            return (int)imports.size() - 1;
+        };
+        // stages
+        bool anyImport = false;
+        for (int k : B.nodes) {
+            NI& x = ni[k];
+            if (x.kind != K_CHAIN) continue;
+            if (x.n->inlets.empty()) { if (leafArity(x.n->op) > 0) anyImport = true; continue; }
+            for (auto& in : x.n->inlets) {
+                auto it = idx.find(in.source);
+                if (it == idx.end() || in.channel != 0) continue;
+                NI& s = ni[it->second];
+                if (s.kind != K_CONST && s.island != x.island) anyImport = true;
+            }
+        }
+        const int base = anyImport ? 1 : 0;
+        int maxStage = 0;
+        for (int k : B.nodes) {
+            NI& x = ni[k];
+            int lv = base;
+            for (auto& in : x.n->inlets) {
+                auto it = idx.find(in.source);
+                if (it == idx.end() || in.channel != 0) continue;
+                NI& s = ni[it->second];
+                if (s.kind != K_CONST && s.island == x.island) lv = std::max(lv, s.level + 1);
+            }
+            x.level = lv;
+            x.lastUse = lv;
+            maxStage = std::max(maxStage, lv);
+        }
+        if (maxStage > 250) { std::fprintf(stderr, "[elemhip] plan: island too deep\n"); return nullptr; }
+        for (int k : B.nodes) {
+            NI& x = ni[k];
+            for (auto& in : x.n->inlets) {
+                auto it = idx.find(in.source);
+                if (it == idx.end() || in.channel != 0) continue;
+                NI& s = ni[it->second];
+                if (s.kind == K_CONST) continue;
+                if (s.island == x.island) s.lastUse = std::max(s.lastUse, x.level);
+                else if (x.kind == K_CHAIN) { Import& im = imports[importFor(s.hbm)]; im.lastUse = std::max(im.lastUse, x.level); }
+            }
+            if (x.kind == K_CHAIN && x.n->inlets.empty()) {
+                const uint32_t ar = std::min<uint32_t>(leafArity(x.n->op), kMaxHostIn);
+                for (uint32_t c = 0; c < ar; ++c) { Import& im = imports[importFor(c)]; im.lastUse = std::max(im.lastUse, x.level); }
+            }
+        }
+
+        // LDS slots by liveness. Word 0/1 = zero cell; slots start at word 2.
+        std::vector<int> slotFreeAt;   // stage from which the slot is free again
+        auto takeSlots = [&](int stage, uint32_t count, int lastUse) -> uint32_t {
+            // `count` consecutive slots free at `stage`
+            const size_t S = slotFreeAt.size();
+            for (size_t s0 = 0; s0 + count <= S; ++s0) {
+                bool ok = true;
+                for (uint32_t c = 0; c < count; ++c) if (slotFreeAt[s0 + c] > stage) { ok = false; break; }
+                if (ok) { for (uint32_t c = 0; c < count; ++c) slotFreeAt[s0 + c] = lastUse + 1; return 2u + (uint32_t)s0 * kSlotWords; }
+            }
+            // extend (reuse a free tail if there is one)
+            size_t s0 = S;
+            while (s0 > 0 && slotFreeAt[s0 - 1] <= stage && S - (s0 - 1) <= count) --s0;
+            slotFreeAt.resize(s0 + count, 0);
+            for (uint32_t c = 0; c < count; ++c) slotFreeAt[s0 + c] = lastUse + 1;
+            return 2u + (uint32_t)s0 * kSlotWords;
+        };
+        for (auto& im : imports) im.lds = takeSlots(0, 1, im.lastUse);
+        for (int stage = base; stage <= maxStage; ++stage) {
+            for (int k : B.nodes) {
+                NI& x = ni[k];
+                if (x.level != stage) continue;
+                if (x.needLds) x.lds = takeSlots(stage, 1, x.lastUse);
+                const uint32_t sc = scratchSlots(x.n->op);
+                if (sc) x.scratch = takeSlots(stage, sc, stage);
+            }
+        }
+        const uint32_t slotWords = 2u + (uint32_t)slotFreeAt.size() * kSlotWords;
+
+        // broadcast cells for const-like producers
+        I.constBegin = (uint32_t)p.constCells.size();
+        std::unordered_map<uint32_t, uint32_t> cellOf;   // rec -> lds word
+        auto cellFor = [&](Node* c) -> uint32_t {
+            auto it = cellOf.find(c->rec);
+            if (it != cellOf.end()) return it->second;
+            const uint32_t word = slotWords + (uint32_t)cellOf.size();
+            cellOf.emplace(c->rec, word);
+            p.constCells.push_back(ConstCell{word, c->rec});
+            return word;
+        };
+
+        auto makeMember = [&](NI& x) -> Member {
+            Member m{};
+            m.rec = x.n->rec;
+            m.opnd = (uint32_t)p.operands.size();
+            m.outLds = x.needLds ? x.lds : kNone;
+            m.outHbm = x.exported ? x.hbm : kNone;
+            m.scratch = x.scratch;
+            if (x.n->inlets.empty()) {
+                m.nin = kNone;
+                const uint32_t ar = std::min<uint32_t>(leafArity(x.n->op), kMaxHostIn);
+                for (uint32_t c = 0; c < ar; ++c) {
+                    if (x.kind == K_CHAIN) p.operands.push_back(kOpLds | imports[importFor(c)].lds);
+                    else p.operands.push_back(kOpHbm | c);
+                }
+                return m;
+            }
+            m.nin = (uint32_t)x.n->inlets.size();
+            for (auto& in : x.n->inlets) {
+                auto it = idx.find(in.source);
+                if (it == idx.end() || in.channel != 0) { p.operands.push_back(kOpZero); continue; }
+                NI& s = ni[it->second];
+                if (s.kind == K_CONST) p.operands.push_back(kOpConst | cellFor(s.n));
+                else if (s.island == x.island) p.operands.push_back(kOpLds | s.lds);
+                else if (x.kind == K_CHAIN) p.operands.push_back(kOpLds | imports[importFor(s.hbm)].lds);
+                else p.operands.push_back(kOpHbm | s.hbm);
+            }
+            return m;
+        };
+
+        // ---- tasks, stage by stage ----
+        I.taskBegin = (uint32_t)p.tasks.size();
+        auto emitRanges = [&](uint16_t op, int stage, uint32_t first, uint32_t count, const std::vector<int>& waves) {
+            const uint32_t f = (uint32_t)waves.size();
+            const uint32_t chunk = ((bs + f - 1) / f + 63) / 64 * 64;
+            for (uint32_t w = 0; w < f; ++w) {
+                const uint32_t s0 = std::min(bs, w * chunk), s1 = std::min(bs, (w + 1) * chunk);
+                if (s0 >= s1) continue;
+                p.tasks.push_back(Task{op, (uint8_t)stage, (uint8_t)waves[w], (uint16_t)s0, (uint16_t)s1, first, count});
+            }
+        };
+        if (!imports.empty()) {
+            const uint32_t first = (uint32_t)p.members.size();
+            for (auto& im : imports) {
+                Member m{};
+                m.rec = 0; m.opnd = (uint32_t)p.operands.size(); m.nin = 1; m.outLds = im.lds; m.outHbm = kNone; m.scratch = kNone;
+                p.operands.push_back(kOpHbm | im.hbm);
+                p.members.push_back(m);
+            }
+            emitRanges(OP_COPY, 0, first, (uint32_t)imports.size(), {0, 1, 2, 3});
+        }
+        for (int stage = base; stage <= maxStage; ++stage) {
+            std::map<uint16_t, std::vector<int>> chain, single, par;
+            for (int k : B.nodes) {
+                NI& x = ni[k];
+                if (x.level != stage) continue;
+                if (x.kind == K_CHAIN) chain[x.n->op].push_back(k);
+                else if (x.kind == K_SINGLE) single[x.n->op].push_back(k);
+                else par[x.n->op].push_back(k);
+            }
+            uint32_t load[kWaves] = {0, 0, 0, 0};
+            auto leastLoaded = [&]() { int b = 0; for (int w = 1; w < (int)kWaves; ++w) if (load[w] < load[b]) b = w; return b; };
+            for (auto& kv : chain) {
+                for (size_t off = 0; off < kv.second.size(); off += 64) {
+                    const uint32_t cnt = (uint32_t)std::min<size_t>(64, kv.second.size() - off);
+                    const uint32_t first = (uint32_t)p.members.size();
+                    for (uint32_t c = 0; c < cnt; ++c) p.members.push_back(makeMember(ni[kv.second[off + c]]));
+                    const int w = leastLoaded();
+                    load[w] += 1000;
+                    p.tasks.push_back(Task{kv.first, (uint8_t)stage, (uint8_t)w, 0, (uint16_t)bs, first, cnt});
+                }
+            }
+            for (auto& kv : single) {
+                for (int k : kv.second) {
+                    const uint32_t first = (uint32_t)p.members.size();
+                    p.members.push_back(makeMember(ni[k]));
+                    const int w = leastLoaded();
+                    load[w] += 100;
+                    p.tasks.push_back(Task{kv.first, (uint8_t)stage, (uint8_t)w, 0, (uint16_t)bs, first, 1});
+                }
+            }
+            std::vector<int> freeWaves;
+            for (int w = 0; w < (int)kWaves; ++w) if (load[w] == 0) freeWaves.push_back(w);
+            if (freeWaves.empty()) freeWaves.push_back(leastLoaded());
+            for (auto& kv : par) {
+                const uint32_t first = (uint32_t)p.members.size();
+                for (int k : kv.second) p.members.push_back(makeMember(ni[k]));
+                emitRanges(kv.first, stage, first, (uint32_t)kv.second.size(), freeWaves);
+            }
+        }
+        I.taskEnd = (uint32_t)p.tasks.size();
+        std::stable_sort(p.tasks.begin() + I.taskBegin, p.tasks.begin() + I.taskEnd,
+                         [](const Task& a, const Task& b) { return a.stage != b.stage ? a.stage < b.stage : a.wave < b.wave; });
+        I.constEnd = (uint32_t)p.constCells.size();
+        I.numStages = (uint32_t)maxStage + 1;
+        I.ldsWords = slotWords + (uint32_t)cellOf.size();
+        I.ldsWords = (I.ldsWords + 3u) & ~3u;
+        p.maxLdsBytes = std::max(p.maxLdsBytes, I.ldsWords * 4u);
+    }
+
+    // ---- 5. launch levels, roots, taps ------------------------------------------------------------------
+    p.levelOffsets.assign((size_t)numLevels + 1, 0);
+    p.levelLdsBytes.assign((size_t)numLevels, 0);
+    for (auto& i : ib) p.levelOffsets[(size_t)i.level + 1]++;
+    for (int l = 0; l < numLevels; ++l) p.levelOffsets[(size_t)l + 1] += p.levelOffsets[l];
+    p.levelIslands.resize(ib.size());
+    {
+        std::vector<uint32_t> cursor(p.levelOffsets.begin(), p.levelOffsets.end() - 1);
+        for (size_t i = 0; i < ib.size(); ++i) {
+            p.levelIslands[cursor[ib[i].level]++] = (uint32_t)i;
+            p.levelLdsBytes[ib[i].level] = std::max(p.levelLdsBytes[ib[i].level], p.islands[i].ldsWords * 4u);
+        }
+    }
+    for (size_t s = 0; s < seqRoots.size(); ++s) {
+        Node* r = seqRoots[s];
+        NI& x = ni[idx.at(r->id)];
+        p.roots.push_back(RootEntry{r->rec, x.hbm});
+        p.rootIds.push_back(r->id);
+        for (int k : seqNodes[s]) if (ni[k].n->op == OP_TAPOUT) p.taps.push_back(TapEntry{ni[k].n->rec, r->rec});
+    }
+    return plan;
+}
+
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+std::shared_ptr<Plan> Engine::buildPlan() {
+    std::shared_ptr<Plan> plan;
+    const uint32_t ldsLimit = 160u * 1024u - 1024u;
+    for (uint32_t limit = 56; limit >= 4; limit /= 2) {
+        PlanBuilder b(*this);
+        plan = b.build(limit);
+        if (!plan) return nullptr;
+        if (plan->maxLdsBytes <= ldsLimit) break;
+        plan.reset();
+    }
+    if (!plan) { std::fprintf(stderr, "[elemhip] plan: could not fit islands into LDS\n"); return nullptr; }
+    Plan& p = *plan;
+
+    // root records learn whether fade.process() runs on them (Core.h:74-77)
+    for (int32_t id : p.rootIds) {
+        Node& r = nodes.at(id);
+        const uint32_t has = r.inlets.empty() ? 0u : 1u;
+        if (shadow[r.rec * kRecDwords + rec::ROOT_HASIN] != has) writeParam(r, rec::ROOT_HASIN, has);
+    }
+
+    // pack + upload the tables
+    size_t off = 0;
+    auto place = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t oIslands = place(p.islands.size() * sizeof(Island));
+    const size_t oLevel = place(p.levelIslands.size() * 4);
+    const size_t oTasks = place(p.tasks.size() * sizeof(Task));
+    const size_t oMembers = place(p.members.size() * sizeof(Member));
+    const size_t oOperands = place(p.operands.size() * 4);
+    const size_t oCells = place(p.constCells.size() * sizeof(ConstCell));
+    const size_t oRoots = place(p.roots.size() * sizeof(RootEntry));
+    const size_t oTaps = place(p.taps.size() * sizeof(TapEntry));
+    std::vector<uint8_t> host(std::max<size_t>(off, 16), 0);
+    auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(host.data() + o, src, bytes); };
+    put(oIslands, p.islands.data(), p.islands.size() * sizeof(Island));
+    put(oLevel, p.levelIslands.data(), p.levelIslands.size() * 4);
+    put(oTasks, p.tasks.data(), p.tasks.size() * sizeof(Task));
+    put(oMembers, p.members.data(), p.members.size() * sizeof(Member));
+    put(oOperands, p.operands.data(), p.operands.size() * 4);
+    put(oCells, p.constCells.data(), p.constCells.size() * sizeof(ConstCell));
+    put(oRoots, p.roots.data(), p.roots.size() * sizeof(RootEntry));
+    put(oTaps, p.taps.data(), p.taps.size() * sizeof(TapEntry));
+    if (dry) return plan;
+    if (hipMalloc(&p.dev.ptr, host.size()) != hipSuccess) return nullptr;
+    p.dev.bytes = host.size();
+    if (hipMemcpy(p.dev.ptr, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    const uint8_t* d = static_cast<const uint8_t*>(p.dev.ptr);
+    p.view.islands = reinterpret_cast<const Island*>(d + oIslands);
+    p.view.levelIslands = reinterpret_cast<const uint32_t*>(d + oLevel);
+    p.view.tasks = reinterpret_cast<const Task*>(d + oTasks);
+    p.view.members = reinterpret_cast<const Member*>(d + oMembers);
+    p.view.operands = reinterpret_cast<const uint32_t*>(d + oOperands);
+    p.view.constCells = reinterpret_cast<const ConstCell*>(d + oCells);
+    p.view.roots = reinterpret_cast<const RootEntry*>(d + oRoots);
+    p.view.taps = reinterpret_cast<const TapEntry*>(d + oTaps);
+    p.view.numRoots = (uint32_t)p.roots.size();
+    p.view.numTaps = (uint32_t)p.taps.size();
+    return plan;
+}
+
+} // namespace elemhip
+
+namespace elemhip {
+
+// JSON description of the render plan (islands, levels, tasks) for host-logic tests and debugging.
+std::string Engine::describePlan() {
+    std::lock_guard<std::mutex> lock(mu);
+    if (pending) { current = pending; pending.reset(); }
+    if (!current) return "null";
+    const Plan& p = *current;
+    std::string s = "{";
+    auto kv = [&](const char* k, uint64_t v, bool comma = true) { s += "\"" + std::string(k) + "\":" + std::to_string(v) + (comma ? "," : ""); };
+    kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.tasks.size());
+    kv("num_members", p.members.size()); kv("num_operands", p.operands.size()); kv("num_nodes", p.nodeIds.size());
+    kv("num_hbm_buffers", p.numHbmBuffers); kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());
+    kv("num_taps", p.taps.size());
+    s += "\"level_sizes\":[";
+    for (size_t l = 0; l + 1 < p.levelOffsets.size(); ++l) { if (l) s += ","; s += std::to_string(p.levelOffsets[l + 1] - p.levelOffsets[l]); }
+    s += "],\"root_ids\":[";
+    for (size_t i = 0; i < p.rootIds.size(); ++i) { if (i) s += ","; s += std::to_string(p.rootIds[i]); }
+    s += "],\"islands\":[";
+    for (size_t i = 0; i < p.islands.size(); ++i) {
+        const Island& I = p.islands[i];
+        if (i) s += ",";
+        s += "{\"tasks\":" + std::to_string(I.taskEnd - I.taskBegin) + ",\"stages\":" + std::to_string(I.numStages) +
+             ",\"lds_bytes\":" + std::to_string(I.ldsWords * 4) + ",\"consts\":" + std::to_string(I.constEnd - I.constBegin) + "}";
+        if (i >= 63) break;
+    }
+    s += "]}";
+    return s;
+}
+
+} // namespace elemhip

@@ -1,0 +1,102 @@
+"""``Runtime`` — host-side mirror of ``elem::Runtime<float>`` backed by libelemhip.so (HIP, gfx950).
+
+There is no CPU fallback: constructing a ``Runtime`` without the compiled extension or without
+a usable GPU raises.  Method names/arguments follow the reference class
+(runtime/elem/Runtime.h:39-153); see ``_cabi.CRuntime`` for the shared surface.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Any, Dict, Optional
+
+from ._cabi import CRuntime, RETURN_CODES
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libelemhip.so")
+_lib: Optional[C.CDLL] = None
+
+
+class ElemHipError(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    """Load the in-tree HIP engine. Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ElemHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C elementary_amd/csrc`). The HIP engine has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        lib.elemhip_create.argtypes = [C.c_double, C.c_int, C.c_int]
+        lib.elemhip_create.restype = C.c_void_p
+        lib.elemhip_last_create_error.restype = C.c_int
+        lib.elemhip_describe.argtypes = [C.c_int]
+        lib.elemhip_describe.restype = C.c_char_p
+        lib.elemhip_process_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int64]
+        lib.elemhip_process_blocks.restype = C.c_int
+        lib.elemhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        lib.elemhip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        lib.elemhip_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+class _Stats(C.Structure):
+    _fields_ = [
+        ("blocks_rendered", C.c_uint64), ("plans_built", C.c_uint64), ("last_plan_build_ms", C.c_double),
+        ("num_islands", C.c_uint32), ("num_levels", C.c_uint32), ("num_tasks", C.c_uint32),
+        ("num_nodes_in_plan", C.c_uint32), ("max_lds_bytes", C.c_uint32), ("num_hbm_buffers", C.c_uint32),
+        ("graph_replays", C.c_uint64), ("graph_captures", C.c_uint64),
+    ]
+
+
+def describe(code: int) -> str:
+    try:
+        return load_library().elemhip_describe(int(code)).decode()
+    except ElemHipError:
+        return RETURN_CODES.get(code, "Return code not recognized")
+
+
+class Runtime(CRuntime):
+    """``elem::Runtime<float>`` on one MI355X (``device`` = HIP ordinal)."""
+
+    def __init__(self, sample_rate: float, block_size: int, device: int = 0):
+        lib = load_library()
+        h = lib.elemhip_create(float(sample_rate), int(block_size), int(device))
+        if not h:
+            code = lib.elemhip_last_create_error()
+            raise ElemHipError(f"elemhip_create failed: {describe(code)} (code {code})")
+        super().__init__(lib, "elemhip_", C.c_void_p(h), sample_rate, block_size)
+        self.device = int(device)
+
+    # -- offline / throughput path --------------------------------------------------------
+    def process_blocks(self, num_blocks: int, num_outputs: int, out_ptr: int = 0, in_ptr: int = 0, num_inputs: int = 0,
+                       sample_time: Optional[int] = None) -> None:
+        """Render ``num_blocks`` full blocks with device-resident I/O (raw device pointers).
+
+        ``out_ptr`` -> float32 [num_blocks][num_outputs][block_size] in HBM (0 = discard),
+        ``in_ptr``  -> float32 [num_blocks][num_inputs][block_size] in HBM (0 when no inputs).
+        """
+        st = self.sample_time if sample_time is None else int(sample_time)
+        rc = self._lib.elemhip_process_blocks(self._h, C.c_void_p(in_ptr or None), num_inputs,
+                                              C.c_void_p(out_ptr or None), num_outputs, int(num_blocks), st)
+        if rc != 0:
+            raise ElemHipError(f"elemhip_process_blocks failed: {describe(rc)} (code {rc})")
+        if sample_time is None:
+            self.sample_time += int(num_blocks) * self.block_size
+
+    def set_stream(self, hip_stream: int) -> None:
+        self._lib.elemhip_set_stream(self._h, C.c_void_p(hip_stream))
+
+    def set_option(self, key: str, value: float) -> None:
+        rc = self._lib.elemhip_set_option(self._h, key.encode(), float(value))
+        if rc != 0:
+            raise ElemHipError(f"unknown option {key!r}")
+
+    def stats(self) -> Dict[str, Any]:
+        s = _Stats()
+        self._lib.elemhip_get_stats(self._h, C.byref(s))
+        return {k: getattr(s, k) for k, _ in _Stats._fields_}
