@@ -126,6 +126,11 @@ int elemhip_get_stats(elemhip_t* h, elemhip_stats* out) {
     return elemhip::kOk;
 }
 
+int elemhip_time_launches(elemhip_t* h, size_t nOut, size_t numBlocks, float* msOut, size_t cap) {
+    if (!h || !msOut) return -elemhip::kInvalidInstructionFormat;
+    return h->engine.timeLaunches(nOut, numBlocks, msOut, cap);
+}
+
 // Debug/test hook: JSON description of the current render plan. Returns bytes needed.
 size_t elemhip_describe_plan(elemhip_t* h, char* buf, size_t cap) {
     if (!h) return 0;

@@ -787,6 +787,49 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     return kOk;
 }
 
+int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (dry) return -kNoDevice;
+    if (hipSetDevice(device) != hipSuccess) return -kHipError;
+    int rc = swapInPending();
+    if (rc != kOk) return -rc;
+    if (!current) return 0;
+    const Plan& p = *current;
+    const size_t L = p.levelOffsets.size() - 1;
+    if (cap < L + 1) return -kInvalidPropertyValue;
+    rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize);
+    if (rc != kOk) return -rc;
+    if (hGlobals.ringSlots != 1 || hGlobals.blockSlot != 0) {
+        hGlobals.ringSlots = 1; hGlobals.blockSlot = 0;
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, ringSlots) / 4), 1u, 0u});
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, blockSlot) / 4), 0u, 0u});
+    }
+    setGlobalsFor(0, nOut, (size_t)blockSize, hGlobals.sampleTime);
+    flushPending();
+    std::vector<hipEvent_t> ev(2 * (L + 1));
+    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -kHipError;
+    std::vector<double> acc(L + 1, 0.0);
+    for (size_t b = 0; b < numBlocks; ++b) {
+        for (size_t l = 0; l < L; ++l) {
+            const uint32_t lb = p.levelOffsets[l], le = p.levelOffsets[l + 1];
+            (void)hipEventRecord(ev[2 * l], stream);
+            if (le > lb) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l]);
+            (void)hipEventRecord(ev[2 * l + 1], stream);
+        }
+        (void)hipEventRecord(ev[2 * L], stream);
+        launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, dOutRing);
+        (void)hipEventRecord(ev[2 * L + 1], stream);
+        if (hipStreamSynchronize(stream) != hipSuccess) return -kHipError;
+        for (size_t l = 0; l <= L; ++l) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[2 * l], ev[2 * l + 1]); acc[l] += ms; }
+        mirrorRootFades(p, (uint32_t)blockSize, (uint32_t)nOut, 0);
+        hGlobals.sampleTime += blockSize;
+        st.blocksRendered++;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    for (size_t l = 0; l <= L; ++l) msOut[l] = (float)(acc[l] / (double)std::max<size_t>(numBlocks, 1));
+    return (int)(L + 1);
+}
+
 int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime) {
     std::lock_guard<std::mutex> lock(mu);
     if (dry) return kNoDevice;

@@ -95,6 +95,9 @@ public:
     // numBlocks consecutive full blocks, device-resident output `outDev[block][nOut][blockSize]`
     // (may be null: render only) and optional device-resident input `inDev[block][nIn][blockSize]`
     int processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime);
+    // render `numBlocks` blocks with a HIP event pair around every kernel launch; msOut[l] = mean
+    // duration of launch level l (l < numLevels), msOut[numLevels] = epilogue. Returns levels + 1.
+    int timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap);
 
     bool addSharedResource(const std::string& name, const float* const* ch, size_t nCh, size_t nSamples);
     void pruneSharedResources();

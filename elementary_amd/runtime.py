@@ -40,6 +40,10 @@ def load_library() -> C.CDLL:
         lib.elemhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         lib.elemhip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         lib.elemhip_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+        lib.elemhip_time_launches.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.c_size_t]
+        lib.elemhip_time_launches.restype = C.c_int
+        lib.elemhip_describe_plan.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        lib.elemhip_describe_plan.restype = C.c_size_t
         _lib = lib
     return _lib
 
@@ -61,7 +65,7 @@ def describe(code: int) -> str:
 
 
 class Runtime(CRuntime):
-    """``elem::Runtime<float>`` on one MI355X (``device`` = HIP ordinal)."""
+    """``elem::Runtime<float>`` on one MI355X (``device`` = HIP ordinal; -1 = dry host-logic handle)."""
 
     def __init__(self, sample_rate: float, block_size: int, device: int = 0):
         lib = load_library()
@@ -95,6 +99,21 @@ class Runtime(CRuntime):
         rc = self._lib.elemhip_set_option(self._h, key.encode(), float(value))
         if rc != 0:
             raise ElemHipError(f"unknown option {key!r}")
+
+    def time_launches(self, num_outputs: int, num_blocks: int):
+        """Mean HIP-event duration (ms) of each launch level and of the epilogue kernel."""
+        buf = (C.c_float * 64)()
+        k = self._lib.elemhip_time_launches(self._h, num_outputs, int(num_blocks), buf, 64)
+        if k < 0:
+            raise ElemHipError(f"elemhip_time_launches failed: {describe(-k)}")
+        self.sample_time += int(num_blocks) * self.block_size
+        return [float(buf[i]) for i in range(k)]
+
+    def describe_plan(self) -> Dict[str, Any]:
+        import json
+        buf = C.create_string_buffer(1 << 20)
+        self._lib.elemhip_describe_plan(self._h, buf, len(buf))
+        return json.loads(buf.value)
 
     def stats(self) -> Dict[str, Any]:
         s = _Stats()

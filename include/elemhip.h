@@ -79,6 +79,10 @@ void   elemhip_reset(elemhip_t*);
 /* ReturnCode::describe                                           Types.h:62-85 */
 const char* elemhip_describe(int code);
 int  elemhip_get_stats(elemhip_t*, elemhip_stats* out);
+/* Measurement hook: render `numBlocks` blocks (no host inputs) with a HIP event pair around every
+ * kernel launch on the engine's stream. msOut[l] = mean ms of launch level l, msOut[levels] = the
+ * epilogue kernel. Returns the number of entries written (levels + 1) or a negated error code. */
+int  elemhip_time_launches(elemhip_t*, size_t nOut, size_t numBlocks, float* msOut, size_t cap);
 /* Debug/test hook: JSON description of the current render plan (islands, launch levels, LDS).
  * deviceOrdinal == -1 at create time gives a "dry" handle that runs all host logic (instruction
  * decode, graph mutation, plan build, gc) without a GPU; it cannot render (process returns 101). */
