@@ -23,7 +23,9 @@ enum : uint32_t {
     kState0      = 8,      // first state dword
     kWaves       = 4,      // waves per island workgroup
     kThreads     = 256,
-    kSlotWords   = 514,    // LDS words per block-buffer slot (512 + pad, keeps 8-byte alignment)
+    kSlotWords   = 516,    // LDS words per block-buffer slot: 512 + 4 keeps slots 16-byte aligned and makes
+                           // lane-per-node ds_read_b128 (lane stride 516 words = 4 banks mod 64) conflict-free
+    kSlot0       = 4,      // first slot word; words 0..3 read as 0.0f
     kMaxBlock    = 512,    // max frames per block the LDS slots are sized for
     kMaxHostIn   = 32,     // host input channels addressable by leaf nodes (Types.h:142 uses 32 too)
     kNone        = 0xFFFFFFFFu,
@@ -54,34 +56,50 @@ enum Op : uint16_t {
     OP_TIME, OP_METRO, OP_CONVOLVE,
     // plan pseudo-ops
     OP_COPY,          // out = in0 (import HBM->LDS, export LDS->HBM)
+    OP_SVF_COEF,      // SVF coefficient pre-pass (a1,a2,a3 as double into the member's scratch), sample-parallel
+    OP_SHELF_COEF,    // shelf variant (a1,a2,a3,k,A)
     OP_COUNT_
 };
 
-// One node of a task.
+// One node of a task (8 dwords in the island program, 16-byte aligned).
 struct Member {
     uint32_t rec;        // node record index
-    uint32_t opnd;       // first operand (index into Plan::operands)
+    uint32_t opnd;       // first operand (index into the island's operand array)
     uint32_t nin;        // operand count; kNone => leaf: operands are host inputs 0..nIn-1
     uint32_t outLds;     // LDS word offset of the output slot, or kNone
     uint32_t outHbm;     // HBM arena buffer index to (also) write, or kNone
-    uint32_t scratch;    // LDS word offset of op scratch (svf coefficients, ...), or kNone
+    uint32_t scratch;    // LDS word offset of op scratch, or kNone
+    uint32_t pad0_, pad1_;
 };
 
+// 4 dwords in the island program.
 struct Task {
     uint16_t opcode;
     uint8_t  stage;      // barrier epoch inside the island
-    uint8_t  wave;       // executing wave (0..kWaves-1)
+    uint8_t  flags;      // chain tasks: bit k set = operand k of every member is a broadcast cell
     uint16_t s0, s1;     // sample range [s0, s1) for sample-parallel tasks
-    uint32_t first;      // first member (index into Plan::members)
+    uint32_t first;      // first member (index into the island's member array)
     uint32_t count;      // members in this task
 };
 
+// An island's program is one contiguous dword blob  [tasks | members | operands | const cells]
+// that the workgroup copies into LDS once, so the interpreter never waits on global memory
+// for metadata (a dependent scalar load per task cost ~0.7 us each).
 struct Island {
-    uint32_t taskBegin, taskEnd;   // into Plan::tasks, sorted by (stage, wave)
+    uint32_t progBegin;            // dword offset of the blob in PlanView::prog
+    uint32_t progDwords;
+    uint32_t numTasks;             // sorted by (wave, stage); wave w owns tasks [waveTask[w], waveTask[w+1])
+    uint32_t waveTask[kWaves + 1];
+    uint32_t split;                // > 1: the island is pure sample-parallel and runs as `split` workgroups,
+                                   // workgroup k rendering frames [k, k+1) * blockSize / split
+    uint32_t memOff;               // dword offsets inside the blob
+    uint32_t opndOff;
+    uint32_t cellOff;
+    uint32_t numCells;             // ConstCell pairs: LDS broadcast cells to fill at start
+    uint32_t ldsProg;              // LDS word where the blob is staged (after slots and cells)
+    uint32_t ldsWords;             // total dynamic LDS words
     uint32_t rootRec;              // record of the RootNode whose render sequence owns the island
-    uint32_t constBegin, constEnd; // into Plan::constCells: LDS broadcast cells to fill at start
     uint32_t numStages;
-    uint32_t ldsWords;
     uint32_t pad_;
 };
 
@@ -118,11 +136,8 @@ struct Globals {
 // Device view of a compiled plan (all pointers are device pointers).
 struct PlanView {
     const Island*    islands;
-    const uint32_t*  levelIslands;   // island indices grouped by launch level
-    const Task*      tasks;
-    const Member*    members;
-    const uint32_t*  operands;
-    const ConstCell* constCells;
+    const uint32_t*  levelIslands;   // per launch level: one entry per workgroup = island | (splitIndex << 24)
+    const uint32_t*  prog;           // island program blobs
     const RootEntry* roots;          // in render-sequence order
     const TapEntry*  taps;           // in render-sequence order
     uint32_t numRoots;

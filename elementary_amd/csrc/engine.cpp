@@ -173,8 +173,10 @@ int Engine::ensureHbm(size_t buffers) {
     if (buffers <= hbmBuffers) return kOk;
     size_t want = std::max(buffers, hbmBuffers * 2);
     float* nb = nullptr;
-    HIP_OK(hipMalloc(&nb, want * blockSize * sizeof(float)));
-    HIP_OK(hipMemset(nb, 0, want * blockSize * sizeof(float)));
+    // + slack: vector loads of a 64*V-frame task may read (never write) past a short block's buffer
+    const size_t floats = want * blockSize + 1024;
+    HIP_OK(hipMalloc(&nb, floats * sizeof(float)));
+    HIP_OK(hipMemset(nb, 0, floats * sizeof(float)));
     if (dHbm) deferredFree.push_back(dHbm);
     dHbm = nb; hbmBuffers = want;
     return kOk;
@@ -694,7 +696,7 @@ int Engine::swapInPending() {   // Runtime.h:277-285: newest sequence wins
         pending.reset();
         st.numIslands = (uint32_t)current->islands.size();
         st.numLevels = (uint32_t)current->levelOffsets.size() - 1;
-        st.numTasks = (uint32_t)current->tasks.size();
+        st.numTasks = current->numTasks;
         st.numNodesInPlan = (uint32_t)current->nodeIds.size();
         st.maxLdsBytes = current->maxLdsBytes;
         st.numHbmBuffers = current->numHbmBuffers;

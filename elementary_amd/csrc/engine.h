@@ -180,10 +180,8 @@ struct Plan {
     std::vector<uint32_t> levelIslands;
     std::vector<uint32_t> levelOffsets;    // numLevels + 1
     std::vector<uint32_t> levelLdsBytes;
-    std::vector<Task> tasks;
-    std::vector<Member> members;
-    std::vector<uint32_t> operands;
-    std::vector<ConstCell> constCells;
+    std::vector<uint32_t> prog;            // per-island program blobs (device.h: Island)
+    uint32_t numTasks = 0, numMembers = 0, numOperands = 0;
     std::vector<RootEntry> roots;
     std::vector<TapEntry> taps;
     std::vector<int32_t> rootIds;          // same order as `roots`

@@ -1,12 +1,13 @@
 // kernels.hip — the block-render path as hand-written HIP for gfx950 (CDNA4).
 //
-// One launch renders one *island level*: every workgroup (4 wavefronts) interprets the task
-// list of one island with that island's block buffers resident in LDS.  Stateless node loops
-// (runtime/elem/builtins/Math.h etc.) run sample-parallel, 64 lanes x (samples/64); stateful
-// recurrences (phasor, polyBLEP phase, one-pole, biquad, SVF, ...) run one node per lane with
-// only the loop-carried state update on the serial chain and everything else hoisted into
-// sample-parallel pre/post passes.  An epilogue workgroup then sums root buffers into the
-// output bus, advances root fades and promotes feedback taps (GraphRenderSequence.h:268-309).
+// One launch renders one *island level*: every workgroup (4 wavefronts) interprets the program
+// of one island with that island's block buffers AND its program resident in LDS.  Stateless node
+// loops (runtime/elem/builtins/Math.h etc.) run sample-parallel, 64 lanes x (samples/64);
+// stateful recurrences (phasor, polyBLEP phase, one-pole, biquad, SVF, ...) run one node per lane
+// with only the loop-carried state update on the serial chain, everything else hoisted into
+// sample-parallel pre/post passes, and the chain's operands streamed from LDS with 16-byte reads
+// one chunk ahead of the dependent arithmetic.  An epilogue workgroup then sums root buffers into
+// the output bus, advances root fades and promotes feedback taps (GraphRenderSequence.h:268-309).
 //
 // PARITY RULES: compiled with -ffp-contract=off; float-state recurrences are
 // op-for-op the reference's expressions, in the reference's order; nodes that compute in double
@@ -23,32 +24,45 @@ extern __shared__ __attribute__((aligned(16))) float lds[];
 
 namespace {
 
+// Global-memory pointers carry an explicit address space. With plain (generic) pointers the
+// optimiser merges `cond ? hbm[i] : lds[j]` into one FLAT load of a selected generic pointer,
+// and a flat access to LDS costs ~700 cycles instead of ~100.
+typedef float __attribute__((address_space(1)))*          gfp;
+typedef const float __attribute__((address_space(1)))*    gcfp;
+typedef uint32_t __attribute__((address_space(1)))*       gup;
+typedef const uint32_t __attribute__((address_space(1)))* gcup;
+
 struct Ctx {
-    uint32_t*       recs;
-    float*          hbm;
+    gup             recs;
+    gfp             hbm;
     const Globals*  g;
-    const uint32_t* operands;
-    const uint32_t* lcg;      // [2*(kMaxBlock+1)] jump-ahead table for `rand`
+    gcup            lcg;      // [2*(kMaxBlock+1)] jump-ahead table for `rand`
+    uint32_t        members;  // LDS word offsets of the staged program tables
+    uint32_t        operands;
     uint32_t        n;        // frames this block
     uint32_t        stride;   // floats per arena buffer
     uint32_t        numIn;    // host input channels
     uint32_t        lane;
+    float           srF;
+    double          sr;
 };
 
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
 __device__ __forceinline__ float    u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t f2u(float f)    { return __float_as_uint(f); }
+__device__ __forceinline__ uint32_t ldsu(uint32_t w) { return __float_as_uint(lds[w]); }
 
-__device__ __forceinline__ double rec_ld_f64(const uint32_t* r, uint32_t d) {
+__device__ __forceinline__ double rec_ld_f64(gcup r, uint32_t d) {
     return __hiloint2double((int)r[d + 1], (int)r[d]);
 }
-__device__ __forceinline__ void rec_st_f64(uint32_t* r, uint32_t d, double v) {
+__device__ __forceinline__ void rec_st_f64(gup r, uint32_t d, double v) {
     r[d] = (uint32_t)__double2loint(v); r[d + 1] = (uint32_t)__double2hiint(v);
 }
-__device__ __forceinline__ float* rec_ptr(const uint32_t* r, uint32_t d) {
+__device__ __forceinline__ gfp rec_ptr(gcup r, uint32_t d) {
     uint64_t p = (uint64_t)r[d] | ((uint64_t)r[d + 1] << 32);
-    return reinterpret_cast<float*>(p);
+    return (gfp)reinterpret_cast<float*>(p);
 }
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) {   // std::clamp
@@ -58,15 +72,59 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) {
     return (v < lo) ? lo : ((hi < v) ? hi : v);
 }
 
-// ---- operand access ---------------------------------------------------------------------
+// ---- program access (staged in LDS) ------------------------------------------------------------
+typedef float    v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef double   v2d __attribute__((ext_vector_type(2)));
+
+// 16-byte LDS accesses: the compiler only emits ds_read_b128 / ds_write_b128 when told the
+// address is aligned (every slot, scratch array and program table is laid out on 16 bytes)
+__device__ __forceinline__ v4u lds4u(uint32_t w) { return *reinterpret_cast<const v4u*>(__builtin_assume_aligned(&lds[w], 16)); }
+__device__ __forceinline__ v4f ld4(uint32_t w) { return *reinterpret_cast<const v4f*>(__builtin_assume_aligned(&lds[w], 16)); }
+__device__ __forceinline__ void st4(uint32_t w, v4f v) { *reinterpret_cast<v4f*>(__builtin_assume_aligned(&lds[w], 16)) = v; }
+__device__ __forceinline__ v2d ld2d(const double* p) { return *reinterpret_cast<const v2d*>(__builtin_assume_aligned(p, 16)); }
+
+__device__ __forceinline__ Member member_uniform(const Ctx& c, uint32_t k) {   // same k on every lane
+    const uint32_t w = c.members + k * 8u;
+    const v4u a = lds4u(w);
+    Member m;
+    m.rec = UNI(a.x); m.opnd = UNI(a.y); m.nin = UNI(a.z); m.outLds = UNI(a.w);
+    m.outHbm = UNI(ldsu(w + 4)); m.scratch = UNI(ldsu(w + 5));
+    return m;
+}
+__device__ __forceinline__ Member member_lane(const Ctx& c, uint32_t k) {      // per-lane k
+    const uint32_t w = c.members + k * 8u;
+    const v4u a = lds4u(w);
+    Member m;
+    m.rec = a.x; m.opnd = a.y; m.nin = a.z; m.outLds = a.w;
+    m.outHbm = ldsu(w + 4); m.scratch = ldsu(w + 5);
+    return m;
+}
 __device__ __forceinline__ uint32_t member_nin(const Ctx& c, const Member& m) {
     return m.nin == kNone ? c.numIn : m.nin;
 }
-__device__ __forceinline__ uint32_t member_opnd(const Ctx& c, const Member& m, uint32_t k) {
-    return c.operands[m.opnd + k];
+__device__ __forceinline__ uint32_t opnd_uniform(const Ctx& c, const Member& m, uint32_t k) {
+    return UNI(ldsu(c.operands + m.opnd + k));
+}
+__device__ __forceinline__ uint32_t opnd_lane(const Ctx& c, const Member& m, uint32_t k) {
+    return ldsu(c.operands + m.opnd + k);
 }
 
-// sample-parallel fetch: `o` is wave-uniform, so the kind switch is a scalar branch
+// Sample-parallel operand: LDS buffer (step 1) / broadcast cell (step 0) share one addressing
+// form, HBM buffers are the other; both are wave-uniform so the choice is a scalar branch made
+// once per operand, outside the sample loop.
+struct PIn { uint32_t base, step; gcfp g; };
+__device__ __forceinline__ PIn pin_of(const Ctx& c, uint32_t o) {
+    const uint32_t kind = o & kOpKindMask, v = o & kOpValMask;
+    PIn p;
+    p.g = nullptr;
+    if (kind == kOpLds)        { p.base = v; p.step = 1u; }
+    else if (kind == kOpConst) { p.base = v; p.step = 0u; }
+    else if (kind == kOpHbm)   { p.base = 0u; p.step = 0u; p.g = (gcfp)(c.hbm + (size_t)v * c.stride); }
+    else                       { p.base = 0u; p.step = 0u; }   // LDS word 0 reads 0.0f
+    return p;
+}
+__device__ __forceinline__ float pget(const PIn& p, uint32_t i) { return p.g ? p.g[i] : lds[p.base + i * p.step]; }
 __device__ __forceinline__ float fetch(const Ctx& c, uint32_t o, uint32_t i) {
     const uint32_t kind = o & kOpKindMask, v = o & kOpValMask;
     if (kind == kOpLds)   return lds[v + i];
@@ -74,26 +132,84 @@ __device__ __forceinline__ float fetch(const Ctx& c, uint32_t o, uint32_t i) {
     if (kind == kOpHbm)   return c.hbm[(size_t)v * c.stride + i];
     return 0.0f;
 }
-
 __device__ __forceinline__ void put(const Ctx& c, const Member& m, uint32_t i, float y) {
     if (m.outLds != kNone) lds[m.outLds + i] = y;
     if (m.outHbm != kNone) c.hbm[(size_t)m.outHbm * c.stride + i] = y;
 }
-
 __device__ __forceinline__ void zero_fill(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
     for (uint32_t i = s0 + c.lane; i < s1; i += 64) put(c, m, i, 0.0f);
 }
 
-// lane-per-node access: every operand of a serial op lives in LDS (the planner imports HBM
-// operands first); value(t) = lds[base + t * step]
-struct SIn { uint32_t base, step; };
-__device__ __forceinline__ SIn sin_of(uint32_t o) {
-    const uint32_t kind = o & kOpKindMask, v = o & kOpValMask;
-    if (kind == kOpLds)   return SIn{v, 1u};
-    if (kind == kOpConst) return SIn{v, 0u};
-    return SIn{0u, 0u};   // LDS word 0 is kept at 0.0f
+// Canonical frame mapping of sample-parallel tasks: a task covers 64*V frames, V in {1,2,4,8}
+// (the planner only emits such ranges), and lane l owns the V CONSECUTIVE frames i .. i+V-1 with
+// i = s0 + l*V: one vector LDS/global access per operand, no per-frame control flow. Every
+// sample-parallel op uses this mapping, which is what lets dependent ops of one stage run back
+// to back on a wave without a barrier (each lane only re-reads what it wrote itself).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const v2f __attribute__((address_space(1)))* gcv2;
+typedef const v4f __attribute__((address_space(1)))* gcv4;
+typedef v2f __attribute__((address_space(1)))* gv2;
+typedef v4f __attribute__((address_space(1)))* gv4;
+
+template <int V>
+__device__ __forceinline__ void vload(const PIn& p, uint32_t i, float (&x)[V]) {
+    if (p.g) {
+        if constexpr (V == 1) x[0] = p.g[i];
+        else if constexpr (V == 2) { const v2f a = *(gcv2)(p.g + i); x[0] = a.x; x[1] = a.y; }
+        else {
+#pragma unroll
+            for (int q = 0; q < V; q += 4) { const v4f a = *(gcv4)(p.g + i + q); x[q] = a.x; x[q + 1] = a.y; x[q + 2] = a.z; x[q + 3] = a.w; }
+        }
+    } else if (p.step) {
+        const uint32_t w = p.base + i;
+        if constexpr (V == 1) x[0] = lds[w];
+        else if constexpr (V == 2) { const v2f a = *reinterpret_cast<const v2f*>(__builtin_assume_aligned(&lds[w], 8)); x[0] = a.x; x[1] = a.y; }
+        else {
+#pragma unroll
+            for (int q = 0; q < V; q += 4) { const v4f a = ld4(w + q); x[q] = a.x; x[q + 1] = a.y; x[q + 2] = a.z; x[q + 3] = a.w; }
+        }
+    } else {
+        const float v = lds[p.base];
+#pragma unroll
+        for (int q = 0; q < V; ++q) x[q] = v;
+    }
 }
-__device__ __forceinline__ float sget(SIn s, uint32_t t) { return lds[s.base + t * s.step]; }
+
+// nlim = first frame that must NOT be written (block shorter than the task range => per-frame tail)
+template <int V>
+__device__ __forceinline__ void vstore(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim, const float (&y)[V]) {
+    if (i + V <= nlim) {
+        if (m.outLds != kNone) {
+            const uint32_t w = m.outLds + i;
+            if constexpr (V == 1) lds[w] = y[0];
+            else if constexpr (V == 2) { v2f a; a.x = y[0]; a.y = y[1]; *reinterpret_cast<v2f*>(__builtin_assume_aligned(&lds[w], 8)) = a; }
+            else {
+#pragma unroll
+                for (int q = 0; q < V; q += 4) { v4f a; a.x = y[q]; a.y = y[q + 1]; a.z = y[q + 2]; a.w = y[q + 3]; st4(w + q, a); }
+            }
+        }
+        if (m.outHbm != kNone) {
+            gfp g = c.hbm + (size_t)m.outHbm * c.stride + i;
+            if constexpr (V == 1) g[0] = y[0];
+            else if constexpr (V == 2) { v2f a; a.x = y[0]; a.y = y[1]; *(gv2)g = a; }
+            else {
+#pragma unroll
+                for (int q = 0; q < V; q += 4) { v4f a; a.x = y[q]; a.y = y[q + 1]; a.z = y[q + 2]; a.w = y[q + 3]; *(gv4)(g + q) = a; }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < V; ++q) if (i + q < nlim) put(c, m, i + q, y[q]);
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void vzero(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    float z[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) z[q] = 0.0f;
+    vstore<V>(c, m, i, nlim, z);
+}
 
 // ---- stateless math (Math.h) -------------------------------------------------------------
 __device__ __forceinline__ float unary_eval(uint16_t op, float x) {
@@ -142,113 +258,177 @@ __device__ __forceinline__ float reduce_eval(uint16_t op, float a, float b) {
     }
 }
 
-// One switch per task, not per sample: the per-sample loops below are specialised by template.
-template <uint16_t OPC>
-__device__ void run_unary(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    if (member_nin(c, m) < 1) return zero_fill(c, m, s0, s1);
-    const uint32_t o = member_opnd(c, m, 0);
-    for (uint32_t i = s0 + c.lane; i < s1; i += 64) put(c, m, i, unary_eval(OPC, fetch(c, o, i)));
+template <uint16_t OPC, int V>
+__device__ __forceinline__ void run_unary(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    if (member_nin(c, m) < 1) return vzero<V>(c, m, i, nlim);
+    float x[V];
+    vload<V>(pin_of(c, opnd_uniform(c, m, 0)), i, x);
+#pragma unroll
+    for (int q = 0; q < V; ++q) x[q] = unary_eval(OPC, x[q]);
+    vstore<V>(c, m, i, nlim, x);
 }
 
-template <uint16_t OPC>
-__device__ void run_binary(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    if (member_nin(c, m) < 2) return zero_fill(c, m, s0, s1);
-    const uint32_t o0 = member_opnd(c, m, 0), o1 = member_opnd(c, m, 1);
-    for (uint32_t i = s0 + c.lane; i < s1; i += 64)
-        put(c, m, i, binary_eval(OPC, fetch(c, o0, i), fetch(c, o1, i)));
+template <uint16_t OPC, int V>
+__device__ __forceinline__ void run_binary(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    if (member_nin(c, m) < 2) return vzero<V>(c, m, i, nlim);
+    float x[V], y[V];
+    vload<V>(pin_of(c, opnd_uniform(c, m, 0)), i, x);
+    vload<V>(pin_of(c, opnd_uniform(c, m, 1)), i, y);
+#pragma unroll
+    for (int q = 0; q < V; ++q) x[q] = binary_eval(OPC, x[q], y[q]);
+    vstore<V>(c, m, i, nlim, x);
 }
 
-// BinaryReducingNode (Math.h:59-89): strict left fold over the children, any fan-in.
-template <uint16_t OPC>
-__device__ void run_reduce(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
+// BinaryReducingNode (Math.h:59-89): strict left fold over the children, any fan-in. Operand
+// codes are fetched 64 at a time (lane b reads code k+b with one LDS access, v_readlane
+// broadcasts them) and the loads of a batch of children are all in flight before the ordered fold.
+template <uint16_t OPC, int V>
+__device__ __forceinline__ void run_reduce(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
     uint32_t nin = member_nin(c, m);
-    if (nin < 1) return zero_fill(c, m, s0, s1);
+    if (nin < 1) return vzero<V>(c, m, i, nlim);
     if (m.nin == kNone && nin > kMaxHostIn) nin = kMaxHostIn;
-    float acc[8];
-    const uint32_t o0 = member_opnd(c, m, 0);
+    float acc[V];
+    vload<V>(pin_of(c, opnd_uniform(c, m, 0)), i, acc);
+    if (nin == 2) {
+        float y[V];
+        vload<V>(pin_of(c, opnd_uniform(c, m, 1)), i, y);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t i = s0 + c.lane + 64u * j;
-        acc[j] = (i < s1) ? fetch(c, o0, i) : 0.0f;
+        for (int q = 0; q < V; ++q) acc[q] = reduce_eval(OPC, acc[q], y[q]);
+        return vstore<V>(c, m, i, nlim, acc);
     }
-    for (uint32_t k = 1; k < nin; ++k) {
-        const uint32_t o = member_opnd(c, m, k);
+    constexpr int KB = (V <= 2) ? 16 : (V == 4 ? 8 : 4);   // children in flight (KB * V registers)
+    uint32_t k = 1;
+    while (k < nin) {
+        const uint32_t left = min(nin - k, 64u);
+        const uint32_t mine = (c.lane < left) ? ldsu(c.operands + m.opnd + k + c.lane) : (uint32_t)kOpZero;
+        for (uint32_t b0 = 0; b0 < left; b0 += KB) {
+            float v[KB][V];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t i = s0 + c.lane + 64u * j;
-            if (i < s1) acc[j] = reduce_eval(OPC, acc[j], fetch(c, o, i));
+            for (int b = 0; b < KB; ++b)
+                if (b0 + b < left) vload<V>(pin_of(c, (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)(b0 + b))), i, v[b]);
+#pragma unroll
+            for (int b = 0; b < KB; ++b)
+                if (b0 + b < left) {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) acc[q] = reduce_eval(OPC, acc[q], v[b][q]);
+                }
         }
+        k += left;
     }
+    vstore<V>(c, m, i, nlim, acc);
+}
+
+// Per-frame form for the less common sample-parallel nodes: f(frame) -> value, same mapping.
+template <int V, typename F>
+__device__ __forceinline__ void vmap(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim, F&& f) {
+    float y[V];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t i = s0 + c.lane + 64u * j;
-        if (i < s1) put(c, m, i, acc[j]);
-    }
+    for (int q = 0; q < V; ++q) y[q] = f(i + q);
+    vstore<V>(c, m, i, nlim, y);
 }
 
 // IdentityNode `in` (Math.h:92-126): out = inputData[channel]; leaf => host input channel.
-__device__ void run_in(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    const uint32_t ch = c.recs[m.rec * kRecDwords + rec::P0];   // static_cast<size_t>(int): negatives wrap large
+template <int V>
+__device__ __forceinline__ void run_in(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    const uint32_t ch = UNI(c.recs[m.rec * kRecDwords + rec::P0]);
     const uint32_t nin = member_nin(c, m);
-    const bool neg = (int32_t)ch < 0;
-    if (neg || ch >= nin || (m.nin == kNone && ch >= kMaxHostIn)) return zero_fill(c, m, s0, s1);
-    const uint32_t o = member_opnd(c, m, ch);
-    for (uint32_t i = s0 + c.lane; i < s1; i += 64) put(c, m, i, fetch(c, o, i));
+    const bool neg = (int32_t)ch < 0;   // static_cast<size_t>(negative int) is huge: zero-fill
+    if (neg || ch >= nin || (m.nin == kNone && ch >= kMaxHostIn)) return vzero<V>(c, m, i, nlim);
+    float x[V];
+    vload<V>(pin_of(c, opnd_uniform(c, m, ch)), i, x);
+    vstore<V>(c, m, i, nlim, x);
 }
 
-__device__ void run_copy(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    const uint32_t o = member_opnd(c, m, 0);
-    for (uint32_t i = s0 + c.lane; i < s1; i += 64) put(c, m, i, fetch(c, o, i));
+template <int V>
+__device__ __forceinline__ void run_copy(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    float x[V];
+    vload<V>(pin_of(c, opnd_uniform(c, m, 0)), i, x);
+    vstore<V>(c, m, i, nlim, x);
 }
 
 // RootNode (Core.h:66-78) + GainFade::process (helpers/GainFade.h:56-72). The gain itself is
 // advanced once per block by the epilogue, after every island has read it.
-__device__ void run_root(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    if (member_nin(c, m) < 1) return zero_fill(c, m, s0, s1);
-    const uint32_t* r = c.recs + m.rec * kRecDwords;
-    const float g = u2f(r[rec::ROOT_GAIN]), tg = u2f(r[rec::ROOT_TARGET]), step = u2f(r[rec::ROOT_STEP]);
-    const uint32_t o = member_opnd(c, m, 0);
+template <int V>
+__device__ __forceinline__ void run_root(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    if (member_nin(c, m) < 1) return vzero<V>(c, m, i, nlim);
+    gcup r = c.recs + m.rec * kRecDwords;
+    const float g = u2f(UNI(r[rec::ROOT_GAIN])), tg = u2f(UNI(r[rec::ROOT_TARGET])), step = u2f(UNI(r[rec::ROOT_STEP]));
+    float x[V];
+    vload<V>(pin_of(c, opnd_uniform(c, m, 0)), i, x);
     if (g == tg) {
-        for (uint32_t i = s0 + c.lane; i < s1; i += 64) put(c, m, i, fetch(c, o, i) * tg);
+#pragma unroll
+        for (int q = 0; q < V; ++q) x[q] = x[q] * tg;
     } else {
-        for (uint32_t i = s0 + c.lane; i < s1; i += 64)
-            put(c, m, i, fetch(c, o, i) * clampf(g + step * (float)(int)i, 0.0f, 1.0f));
+#pragma unroll
+        for (int q = 0; q < V; ++q) x[q] = x[q] * clampf(g + step * (float)(int)(i + q), 0.0f, 1.0f);
     }
+    vstore<V>(c, m, i, nlim, x);
 }
 
 // CutoffPrewarpNode (filters/MultiMode1p.h:9-36): double internals.
-__device__ void run_prewarp(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    if (member_nin(c, m) < 1) return zero_fill(c, m, s0, s1);
-    const double T = 1.0 / c.g->sampleRate;
-    const uint32_t o = member_opnd(c, m, 0);
-    for (uint32_t i = s0 + c.lane; i < s1; i += 64) {
+template <int V>
+__device__ __forceinline__ void run_prewarp(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    if (member_nin(c, m) < 1) return vzero<V>(c, m, i, nlim);
+    const double T = 1.0 / c.sr;
+    float x[V];
+    vload<V>(pin_of(c, opnd_uniform(c, m, 0)), i, x);
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
         const double twoPi = 2.0 * 3.141592653589793238;
-        const double wd = twoPi * (double)fetch(c, o, i);
-        put(c, m, i, (float)tan(wd * T / 2.0));
+        const double wd = twoPi * (double)x[q];
+        x[q] = (float)tan(wd * T / 2.0);
     }
+    vstore<V>(c, m, i, nlim, x);
 }
 
 // SampleTimeNode (wasm/SampleTime.h:11-24), MetronomeNode (wasm/Metro.h:40-55)
-__device__ void run_time(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
+template <int V>
+__device__ __forceinline__ void run_time(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
     const int64_t st = c.g->sampleTime;
-    for (uint32_t i = s0 + c.lane; i < s1; i += 64)
-        put(c, m, i, (float)(double)((uint64_t)st + (uint64_t)i));
+    vmap<V>(c, m, i, nlim, [&](uint32_t t) { return (float)(double)((uint64_t)st + (uint64_t)t); });
 }
-__device__ void run_metro(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    const uint32_t* r = c.recs + m.rec * kRecDwords;
+template <int V>
+__device__ __forceinline__ void run_metro(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    gcup r = c.recs + m.rec * kRecDwords;
     const int64_t is64 = (int64_t)((uint64_t)r[rec::P0] | ((uint64_t)r[rec::P1] << 32));
     const double is = (double)is64;
     const int64_t st = c.g->sampleTime;
-    for (uint32_t i = s0 + c.lane; i < s1; i += 64) {
-        const double t = (double)((uint64_t)st + (uint64_t)i) / is;
-        put(c, m, i, ((t - floor(t)) < 0.5) ? 1.0f : 0.0f);
-    }
+    vmap<V>(c, m, i, nlim, [&](uint32_t t) {
+        const double tt = (double)((uint64_t)st + (uint64_t)t) / is;
+        return ((tt - floor(tt)) < 0.5) ? 1.0f : 0.0f;
+    });
+}
+
+// TapInNode / TapOutNode (Feedback.h:40-53, 111-126); buffers are always float.
+template <int V>
+__device__ __forceinline__ void run_tapin(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    gcup r = c.recs + m.rec * kRecDwords;
+    gcfp shared = rec_ptr(r, rec::TAP_SHARED);
+    if (!shared) return vzero<V>(c, m, i, nlim);
+    vmap<V>(c, m, i, nlim, [&](uint32_t t) { return shared[t]; });
+}
+template <int V>
+__device__ __forceinline__ void run_tapout(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    gcup r = c.recs + m.rec * kRecDwords;
+    if (member_nin(c, m) < 1) return vzero<V>(c, m, i, nlim);
+    gfp priv = rec_ptr(r, rec::TAP_PRIVATE);
+    float x[V];
+    vload<V>(pin_of(c, opnd_uniform(c, m, 0)), i, x);
+#pragma unroll
+    for (int q = 0; q < V; ++q) if (i + q < nlim) priv[i + q] = x[q];
+    vstore<V>(c, m, i, nlim, x);
+}
+
+template <int V>
+__device__ __forceinline__ void run_fill(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    const float v = u2f(UNI(c.recs[m.rec * kRecDwords + rec::P0]));
+    vmap<V>(c, m, i, nlim, [&](uint32_t) { return v; });
 }
 
 // UniformRandomNoiseNode (Noise.h:9-43): the LCG is affine mod 2^32, so sample i is an exact
 // jump-ahead  s_{i+1} = A[i+1]*s_0 + C[i+1]  from a precomputed table — bit-identical, no chain.
-__device__ void run_rand(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
+__device__ __forceinline__ void run_rand(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
+    gup r = c.recs + m.rec * kRecDwords;
     const uint32_t seed = r[rec::S0];
     for (uint32_t i = s0 + c.lane; i < s1; i += 64) {
         const uint32_t s = c.lcg[2 * (i + 1)] * seed + c.lcg[2 * (i + 1) + 1];
@@ -259,10 +439,10 @@ __device__ void run_rand(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1
 }
 
 // SingleSampleDelayNode (Delays.h:15-39): out[i] = (i ? in[i-1] : z); z = in[n-1]
-__device__ void run_z(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
+__device__ __forceinline__ void run_z(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
     if (member_nin(c, m) < 1) return zero_fill(c, m, s0, s1);
-    uint32_t* r = c.recs + m.rec * kRecDwords;
-    const uint32_t o = member_opnd(c, m, 0);
+    gup r = c.recs + m.rec * kRecDwords;
+    const uint32_t o = opnd_uniform(c, m, 0);
     const float z = u2f(r[rec::S0]);
     const float last = (c.n > 0) ? fetch(c, o, c.n - 1) : z;
     for (uint32_t i = s0 + c.lane; i < s1; i += 64) put(c, m, i, i ? fetch(c, o, i - 1) : z);
@@ -270,31 +450,12 @@ __device__ void run_z(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
     if (c.lane == 0) r[rec::S0] = f2u(last);
 }
 
-// TapInNode / TapOutNode (Feedback.h:40-53, 111-126); buffers are always float.
-__device__ void run_tapin(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    const uint32_t* r = c.recs + m.rec * kRecDwords;
-    const float* shared = rec_ptr(r, rec::TAP_SHARED);
-    if (!shared) return zero_fill(c, m, s0, s1);
-    for (uint32_t i = s0 + c.lane; i < s1; i += 64) put(c, m, i, shared[i]);
-}
-__device__ void run_tapout(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    const uint32_t* r = c.recs + m.rec * kRecDwords;
-    if (member_nin(c, m) < 1) return zero_fill(c, m, s0, s1);
-    float* priv = rec_ptr(r, rec::TAP_PRIVATE);
-    const uint32_t o = member_opnd(c, m, 0);
-    for (uint32_t i = s0 + c.lane; i < s1; i += 64) {
-        const float x = fetch(c, o, i);
-        priv[i] = x;
-        put(c, m, i, x);
-    }
-}
-
 // SampleDelayNode (Delays.h:177-272). The reference writes the block into the ring and then
 // reads ring[(size + w0 - len + i) & mask]; for i >= len that is this block's in[i-len], for
 // i < len it is older ring data the block's own writes cannot touch (size >= len + blockSize).
-__device__ void run_sdelay(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
-    float* ring = rec_ptr(r, rec::RING_PTR);
+__device__ __forceinline__ void run_sdelay(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
+    gup r = c.recs + m.rec * kRecDwords;
+    gfp ring = rec_ptr(r, rec::RING_PTR);
     const int size = (int)r[rec::RING_SIZE];
     const int len  = (int)r[rec::RING_LEN];
     int w0 = (int)r[rec::RING_WRITE];
@@ -305,7 +466,7 @@ __device__ void run_sdelay(const Ctx& c, const Member& m, uint32_t s0, uint32_t 
         return zero_fill(c, m, s0, s1);
     }
     const int mask = size - 1;
-    const uint32_t o = member_opnd(c, m, 0);
+    const uint32_t o = opnd_uniform(c, m, 0);
     const int readStart = w0 - len;
     for (uint32_t i = s0 + c.lane; i < s1; i += 64) {
         float y;
@@ -319,12 +480,12 @@ __device__ void run_sdelay(const Ctx& c, const Member& m, uint32_t s0, uint32_t 
     if (c.lane == 0) { r[rec::RING_RESET] = 0; r[rec::RING_WRITE] = (uint32_t)((w0 + (int)c.n) & mask); }
 }
 
-// VariableDelayNode (Delays.h:51-169). Every lane replays the write-index walk; when the
-// smallest read offset in the block exceeds the block length no read can observe a write of
-// this block, so reads/writes are sample-parallel; otherwise lane 0 walks the block serially.
-__device__ void run_delay(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
-    float* ring = rec_ptr(r, rec::RING_PTR);
+// VariableDelayNode (Delays.h:51-169). When the smallest read offset in the block exceeds the
+// block length no read can observe a write of this block, so reads then writes are
+// sample-parallel; otherwise lane 0 walks the block serially.
+__device__ __forceinline__ void run_delay(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
+    gup r = c.recs + m.rec * kRecDwords;
+    gfp ring = rec_ptr(r, rec::RING_PTR);
     const int size = (int)r[rec::RING_SIZE];
     int w0 = (int)r[rec::RING_WRITE];
     if (r[rec::RING_RESET]) w0 = 0;
@@ -334,7 +495,7 @@ __device__ void run_delay(const Ctx& c, const Member& m, uint32_t s0, uint32_t s
         if (c.lane == 0) { r[rec::RING_RESET] = 0; r[rec::RING_WRITE] = (uint32_t)w0; }
         return zero_fill(c, m, s0, s1);
     }
-    const uint32_t oLen = member_opnd(c, m, 0), oFb = member_opnd(c, m, 1), oX = member_opnd(c, m, 2);
+    const uint32_t oLen = opnd_uniform(c, m, 0), oFb = opnd_uniform(c, m, 1), oX = opnd_uniform(c, m, 2);
     if (size == 0 || ring == nullptr) {   // Delays.h:106-107 copies input 0
         for (uint32_t i = s0 + c.lane; i < s1; i += 64) put(c, m, i, fetch(c, oLen, i));
         WAVE_SYNC();
@@ -342,7 +503,6 @@ __device__ void run_delay(const Ctx& c, const Member& m, uint32_t s0, uint32_t s
         return;
     }
     const float fsize = (float)size;
-    // smallest clamped offset over the block
     float mn = FLT_MAX;
     for (uint32_t i = s0 + c.lane; i < s1; i += 64) mn = fminf(mn, clampf(fetch(c, oLen, i), 0.0f, fsize));
     for (int d = 32; d >= 1; d >>= 1) mn = fminf(mn, __shfl_xor(mn, d));
@@ -361,8 +521,7 @@ __device__ void run_delay(const Ctx& c, const Member& m, uint32_t s0, uint32_t s
             const float fb = clampf(fetch(c, oFb, i), -1.0f, 1.0f);
             const float in = fetch(c, oX, i) + fb * out;
             put(c, m, i, out);
-            // all reads of the block are ordered before any write by the WAVE_SYNC below
-            lds[m.scratch + i] = in;
+            lds[m.scratch + i] = in;   // every read of the block precedes every write
         }
         WAVE_SYNC();
         for (uint32_t i = s0 + c.lane; i < s1; i += 64) {
@@ -406,139 +565,82 @@ __device__ void run_delay(const Ctx& c, const Member& m, uint32_t s0, uint32_t s
 }
 
 // ---- lane-per-node recurrences ---------------------------------------------------------------
-// Each helper below is entered by lanes [0, count) of the task's wave; `m` is that lane's node.
-// Loads of a chunk are issued before the dependent chain so LDS latency is paid once per chunk.
+// Entered by lanes [0, count) of the task's wave; `m` is that lane's node. Every operand of a
+// chain lives in LDS (the planner imports HBM operands first): a block buffer (16-byte aligned,
+// streamed 8 samples at a time with two ds_read_b128) or a broadcast cell (read once). Which
+// operands are cells is a property of the TASK (the planner groups chain members by that mask),
+// so the choice is a scalar branch.
 constexpr int CH = 8;
+
+struct SIn { uint32_t base; float cval; };
+
+__device__ __forceinline__ SIn sin_of(uint32_t o) {
+    const uint32_t kind = o & kOpKindMask, v = o & kOpValMask;
+    SIn s;
+    if (kind == kOpLds)        { s.base = v; s.cval = 0.0f; }
+    else if (kind == kOpConst) { s.base = v; s.cval = lds[v]; }
+    else                       { s.base = 0u; s.cval = 0.0f; }   // zero operand (mask bit set by the planner)
+    return s;
+}
+
+template <int NIN>
+__device__ __forceinline__ void load_chunk(const SIn (&in)[NIN], uint32_t cmask, uint32_t t0, float (&x)[NIN][CH]) {
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        if (cmask & (1u << k)) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) x[k][j] = in[k].cval;
+        } else {
+            const v4f a = ld4(in[k].base + t0);
+            const v4f b = ld4(in[k].base + t0 + 4);
+            x[k][0] = a.x; x[k][1] = a.y; x[k][2] = a.z; x[k][3] = a.w;
+            x[k][4] = b.x; x[k][5] = b.y; x[k][6] = b.z; x[k][7] = b.w;
+        }
+    }
+}
+
+// Generic chunked chain: `step(x[NIN]) -> y` carries the node state by reference. Two chunks per
+// trip (ping-pong registers): the next chunk's operands are in flight while the current chunk's
+// dependent arithmetic runs.
+template <int NIN, typename Step>
+__device__ __forceinline__ void chain_loop(const SIn (&in)[NIN], uint32_t cmask, uint32_t outBase, uint32_t n, Step&& step) {
+    const uint32_t nFull = n & ~(uint32_t)(CH - 1);
+    auto run8 = [&](const float (&x)[NIN][CH], uint32_t t0) {
+        float y[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            float xs[NIN];
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) xs[k] = x[k][j];
+            y[j] = step(xs);
+        }
+        v4f a, b;
+        a.x = y[0]; a.y = y[1]; a.z = y[2]; a.w = y[3]; b.x = y[4]; b.y = y[5]; b.z = y[6]; b.w = y[7];
+        st4(outBase + t0, a);
+        st4(outBase + t0 + 4, b);
+    };
+    float A[NIN][CH], B[NIN][CH];
+    uint32_t t0 = 0;
+    if (nFull) load_chunk<NIN>(in, cmask, 0, A);
+    while (t0 + 2 * CH <= nFull) {
+        load_chunk<NIN>(in, cmask, t0 + CH, B);
+        run8(A, t0);
+        const uint32_t tn = (t0 + 2 * CH < nFull) ? t0 + 2 * CH : t0;   // nothing left: harmless re-read
+        load_chunk<NIN>(in, cmask, tn, A);
+        run8(B, t0 + CH);
+        t0 += 2 * CH;
+    }
+    if (t0 < nFull) { run8(A, t0); t0 += CH; }
+    for (uint32_t t = nFull; t < n; ++t) {
+        float xs[NIN];
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) xs[k] = (cmask & (1u << k)) ? in[k].cval : lds[in[k].base + t];
+        lds[outBase + t] = step(xs);
+    }
+}
 
 __device__ __forceinline__ void szero(const Member& m, uint32_t n) {
     for (uint32_t t = 0; t < n; ++t) lds[m.outLds + t] = 0.0f;
-}
-
-// PhasorNode (Core.h:85-136): step = f * (1/sr) in float; phase = next - floor(next)
-template <bool WithReset>
-__device__ void ser_phasor(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
-    const uint32_t nin = member_nin(c, m);
-    if (nin < (WithReset ? 2u : 1u)) return szero(m, c.n);
-    const SIn f = sin_of(member_opnd(c, m, 0));
-    const SIn rs = WithReset ? sin_of(member_opnd(c, m, 1)) : SIn{0, 0};
-    float phase = u2f(r[rec::S0]);
-    float lastIn = u2f(r[rec::S1]);
-    const float rsr = 1.0f / c.g->sampleRateF;
-    for (uint32_t t0 = 0; t0 < c.n; t0 += CH) {
-        float fq[CH], rv[CH], y[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const uint32_t t = min(t0 + j, c.n - 1);
-            fq[j] = sget(f, t) * rsr;
-            if (WithReset) rv[j] = sget(rs, t);
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            if (WithReset && t0 + j < c.n) {
-                const float dt = rv[j] - lastIn;     // Change::tick (helpers/Change.h:20-31)
-                lastIn = rv[j];
-                if (dt > 0.0f) phase = 0.0f;          // change(...) > 0.5  <=>  dt > 0
-            }
-            y[j] = phase;
-            const float next = phase + fq[j];
-            const float np = next - floorf(next);
-            if (t0 + j < c.n) phase = np;
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) if (t0 + j < c.n) lds[m.outLds + t0 + j] = y[j];
-    }
-    r[rec::S0] = f2u(phase);
-    if (WithReset) r[rec::S1] = f2u(lastIn);
-}
-
-// OnePoleNode (Filters.h:13-39): z = x + p*z
-__device__ void ser_pole(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
-    if (member_nin(c, m) < 2) return szero(m, c.n);
-    const SIn ps = sin_of(member_opnd(c, m, 0)), xs = sin_of(member_opnd(c, m, 1));
-    float z = u2f(r[rec::S0]);
-    for (uint32_t t0 = 0; t0 < c.n; t0 += CH) {
-        float p[CH], x[CH], y[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) { const uint32_t t = min(t0 + j, c.n - 1); p[j] = sget(ps, t); x[j] = sget(xs, t); }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) { const float nz = x[j] + p[j] * z; if (t0 + j < c.n) z = nz; y[j] = z; }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) if (t0 + j < c.n) lds[m.outLds + t0 + j] = y[j];
-    }
-    r[rec::S0] = f2u(z);
-}
-
-// EnvelopeNode (Filters.h:46-79)
-__device__ void ser_env(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
-    if (member_nin(c, m) < 3) return szero(m, c.n);
-    const SIn as = sin_of(member_opnd(c, m, 0)), rs = sin_of(member_opnd(c, m, 1)), xs = sin_of(member_opnd(c, m, 2));
-    float z = u2f(r[rec::S0]);
-    for (uint32_t t0 = 0; t0 < c.n; t0 += CH) {
-        float ap[CH], rp[CH], vn[CH], y[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const uint32_t t = min(t0 + j, c.n - 1);
-            ap[j] = sget(as, t); rp[j] = sget(rs, t); vn[j] = fabsf(sget(xs, t));
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const float k = (fabsf(vn[j]) > z) ? ap[j] : rp[j];
-            const float nz = k * (z - vn[j]) + vn[j];
-            if (t0 + j < c.n) z = nz;
-            y[j] = z;
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) if (t0 + j < c.n) lds[m.outLds + t0 + j] = y[j];
-    }
-    r[rec::S0] = f2u(z);
-}
-
-// BiquadFilterNode (Filters.h:87-120), TDF-II with coefficient signals
-__device__ void ser_biquad(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
-    if (member_nin(c, m) < 6) return szero(m, c.n);
-    SIn s[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s[k] = sin_of(member_opnd(c, m, k));
-    float z1 = u2f(r[rec::S0]), z2 = u2f(r[rec::S1]);
-    for (uint32_t t0 = 0; t0 < c.n; t0 += CH) {
-        float b0x[CH], b1x[CH], b2x[CH], a1[CH], a2[CH], y[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const uint32_t t = min(t0 + j, c.n - 1);
-            const float x = sget(s[5], t);
-            b0x[j] = sget(s[0], t) * x; b1x[j] = sget(s[1], t) * x; b2x[j] = sget(s[2], t) * x;
-            a1[j] = sget(s[3], t); a2[j] = sget(s[4], t);
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const float yy = b0x[j] + z1;
-            const float nz1 = b1x[j] - a1[j] * yy + z2;
-            const float nz2 = b2x[j] - a2[j] * yy;
-            if (t0 + j < c.n) { z1 = nz1; z2 = nz2; }
-            y[j] = yy;
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) if (t0 + j < c.n) lds[m.outLds + t0 + j] = y[j];
-    }
-    r[rec::S0] = f2u(z1); r[rec::S1] = f2u(z2);
-}
-
-// CounterNode / AccumNode / LatchNode / MaxHold / OnceNode (Core.h:183-404)
-__device__ void ser_counter(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
-    if (member_nin(c, m) < 1) return szero(m, c.n);
-    const SIn gs = sin_of(member_opnd(c, m, 0));
-    float count = u2f(r[rec::S0]);
-    for (uint32_t t = 0; t < c.n; ++t) {
-        const float in = sget(gs, t);
-        if ((1.0f - in) <= FLT_EPSILON) { lds[m.outLds + t] = count; count = count + 1.0f; }
-        else { count = 0.0f; lds[m.outLds + t] = 0.0f; }
-    }
-    r[rec::S0] = f2u(count);
 }
 
 __device__ __forceinline__ float change_tick(float& lastIn, float xn) {   // helpers/Change.h:20-31
@@ -547,70 +649,158 @@ __device__ __forceinline__ float change_tick(float& lastIn, float xn) {   // hel
     return (dt > 0.0f) ? 1.0f : ((dt < 0.0f) ? -1.0f : 0.0f);
 }
 
-__device__ void ser_accum(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
+// PhasorNode (Core.h:85-136): step = f * (1/sr) in float; phase = next - floor(next)
+__device__ __forceinline__ void ser_phasor(const Ctx& c, const Member& m, uint32_t cm) {
+    gup r = c.recs + m.rec * kRecDwords;
+    if (member_nin(c, m) < 1) return szero(m, c.n);
+    const SIn in[1] = {sin_of(opnd_lane(c, m, 0))};
+    float phase = u2f(r[rec::S0]);
+    const float rsr = 1.0f / c.srF;
+    chain_loop<1>(in, cm, m.outLds, c.n, [&](const float (&x)[1]) {
+        const float stepv = x[0] * rsr;
+        const float y = phase;
+        const float next = phase + stepv;
+        phase = next - floorf(next);
+        return y;
+    });
+    r[rec::S0] = f2u(phase);
+}
+
+__device__ __forceinline__ void ser_sphasor(const Ctx& c, const Member& m, uint32_t cm) {
+    gup r = c.recs + m.rec * kRecDwords;
     if (member_nin(c, m) < 2) return szero(m, c.n);
-    const SIn xs = sin_of(member_opnd(c, m, 0)), rs = sin_of(member_opnd(c, m, 1));
+    const SIn in[2] = {sin_of(opnd_lane(c, m, 0)), sin_of(opnd_lane(c, m, 1))};
+    float phase = u2f(r[rec::S0]), lastIn = u2f(r[rec::S1]);
+    const float rsr = 1.0f / c.srF;
+    chain_loop<2>(in, cm, m.outLds, c.n, [&](const float (&x)[2]) {
+        if (change_tick(lastIn, x[1]) > 0.5f) phase = 0.0f;
+        const float stepv = x[0] * rsr;
+        const float y = phase;
+        const float next = phase + stepv;
+        phase = next - floorf(next);
+        return y;
+    });
+    r[rec::S0] = f2u(phase); r[rec::S1] = f2u(lastIn);
+}
+
+// OnePoleNode (Filters.h:13-39): z = x + p*z
+__device__ __forceinline__ void ser_pole(const Ctx& c, const Member& m, uint32_t cm) {
+    gup r = c.recs + m.rec * kRecDwords;
+    if (member_nin(c, m) < 2) return szero(m, c.n);
+    const SIn in[2] = {sin_of(opnd_lane(c, m, 0)), sin_of(opnd_lane(c, m, 1))};
+    float z = u2f(r[rec::S0]);
+    chain_loop<2>(in, cm, m.outLds, c.n, [&](const float (&x)[2]) { z = x[1] + x[0] * z; return z; });
+    r[rec::S0] = f2u(z);
+}
+
+// EnvelopeNode (Filters.h:46-79)
+__device__ __forceinline__ void ser_env(const Ctx& c, const Member& m, uint32_t cm) {
+    gup r = c.recs + m.rec * kRecDwords;
+    if (member_nin(c, m) < 3) return szero(m, c.n);
+    const SIn in[3] = {sin_of(opnd_lane(c, m, 0)), sin_of(opnd_lane(c, m, 1)), sin_of(opnd_lane(c, m, 2))};
+    float z = u2f(r[rec::S0]);
+    chain_loop<3>(in, cm, m.outLds, c.n, [&](const float (&x)[3]) {
+        const float vn = fabsf(x[2]);
+        if (fabsf(vn) > z) z = x[0] * (z - vn) + vn;
+        else               z = x[1] * (z - vn) + vn;
+        return z;
+    });
+    r[rec::S0] = f2u(z);
+}
+
+// BiquadFilterNode (Filters.h:87-120), TDF-II with coefficient signals
+__device__ __forceinline__ void ser_biquad(const Ctx& c, const Member& m, uint32_t cm) {
+    gup r = c.recs + m.rec * kRecDwords;
+    if (member_nin(c, m) < 6) return szero(m, c.n);
+    SIn in[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) in[k] = sin_of(opnd_lane(c, m, k));
+    float z1 = u2f(r[rec::S0]), z2 = u2f(r[rec::S1]);
+    chain_loop<6>(in, cm, m.outLds, c.n, [&](const float (&x)[6]) {
+        const float xx = x[5];
+        const float y = x[0] * xx + z1;
+        z1 = x[1] * xx - x[3] * y + z2;
+        z2 = x[2] * xx - x[4] * y;
+        return y;
+    });
+    r[rec::S0] = f2u(z1); r[rec::S1] = f2u(z2);
+}
+
+// CounterNode / AccumNode / LatchNode / MaxHold / OnceNode (Core.h:183-404)
+__device__ __forceinline__ void ser_counter(const Ctx& c, const Member& m, uint32_t cm) {
+    gup r = c.recs + m.rec * kRecDwords;
+    if (member_nin(c, m) < 1) return szero(m, c.n);
+    const SIn in[1] = {sin_of(opnd_lane(c, m, 0))};
+    float count = u2f(r[rec::S0]);
+    chain_loop<1>(in, cm, m.outLds, c.n, [&](const float (&x)[1]) {
+        if ((1.0f - x[0]) <= FLT_EPSILON) { const float y = count; count = count + 1.0f; return y; }
+        count = 0.0f;
+        return 0.0f;
+    });
+    r[rec::S0] = f2u(count);
+}
+
+__device__ __forceinline__ void ser_accum(const Ctx& c, const Member& m, uint32_t cm) {
+    gup r = c.recs + m.rec * kRecDwords;
+    if (member_nin(c, m) < 2) return szero(m, c.n);
+    const SIn in[2] = {sin_of(opnd_lane(c, m, 0)), sin_of(opnd_lane(c, m, 1))};
     float total = u2f(r[rec::S0]), lastIn = u2f(r[rec::S1]);
-    for (uint32_t t = 0; t < c.n; ++t) {
-        if (change_tick(lastIn, sget(rs, t)) > 0.5f) total = 0.0f;
-        total += sget(xs, t);
-        lds[m.outLds + t] = total;
-    }
+    chain_loop<2>(in, cm, m.outLds, c.n, [&](const float (&x)[2]) {
+        if (change_tick(lastIn, x[1]) > 0.5f) total = 0.0f;
+        total += x[0];
+        return total;
+    });
     r[rec::S0] = f2u(total); r[rec::S1] = f2u(lastIn);
 }
 
-__device__ void ser_latch(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
+__device__ __forceinline__ void ser_latch(const Ctx& c, const Member& m, uint32_t cm) {
+    gup r = c.recs + m.rec * kRecDwords;
     if (member_nin(c, m) < 2) return szero(m, c.n);
-    const SIn ls = sin_of(member_opnd(c, m, 0)), xs = sin_of(member_opnd(c, m, 1));
+    const SIn in[2] = {sin_of(opnd_lane(c, m, 0)), sin_of(opnd_lane(c, m, 1))};
     float z = u2f(r[rec::S0]), hold = u2f(r[rec::S1]);
-    for (uint32_t t = 0; t < c.n; ++t) {
-        const float l = sget(ls, t), x = sget(xs, t);
-        if (fabsf(z) <= FLT_EPSILON && l > FLT_EPSILON) hold = x;
-        z = l;
-        lds[m.outLds + t] = hold;
-    }
+    chain_loop<2>(in, cm, m.outLds, c.n, [&](const float (&x)[2]) {
+        if (fabsf(z) <= FLT_EPSILON && x[0] > FLT_EPSILON) hold = x[1];
+        z = x[0];
+        return hold;
+    });
     r[rec::S0] = f2u(z); r[rec::S1] = f2u(hold);
 }
 
-__device__ void ser_maxhold(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
+__device__ __forceinline__ void ser_maxhold(const Ctx& c, const Member& m, uint32_t cm) {
+    gup r = c.recs + m.rec * kRecDwords;
     if (member_nin(c, m) < 2) return szero(m, c.n);
-    const SIn xs = sin_of(member_opnd(c, m, 0)), rs = sin_of(member_opnd(c, m, 1));
+    const SIn in[2] = {sin_of(opnd_lane(c, m, 0)), sin_of(opnd_lane(c, m, 1))};
     const uint32_t hts = r[rec::P0];
     float lastIn = u2f(r[rec::S0]); uint32_t at = r[rec::S1]; float mx = u2f(r[rec::S2]);
-    for (uint32_t t = 0; t < c.n; ++t) {
-        const float in = sget(xs, t), reset = sget(rs, t);
-        if (change_tick(lastIn, reset) > 0.5f || ++at >= hts) { mx = in; at = 0; }
-        else if (in > mx) { at = 0; mx = in; }
-        lds[m.outLds + t] = mx;
-    }
+    chain_loop<2>(in, cm, m.outLds, c.n, [&](const float (&x)[2]) {
+        if (change_tick(lastIn, x[1]) > 0.5f || ++at >= hts) { mx = x[0]; at = 0; }
+        else if (x[0] > mx) { at = 0; mx = x[0]; }
+        return mx;
+    });
     r[rec::S0] = f2u(lastIn); r[rec::S1] = at; r[rec::S2] = f2u(mx);
 }
 
-__device__ void ser_once(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
+__device__ __forceinline__ void ser_once(const Ctx& c, const Member& m, uint32_t cm) {
+    gup r = c.recs + m.rec * kRecDwords;
     if (member_nin(c, m) < 1) return szero(m, c.n);
-    const SIn xs = sin_of(member_opnd(c, m, 0));
+    const SIn in[1] = {sin_of(opnd_lane(c, m, 0))};
     const bool isArmed = u2f(r[rec::S2]) != 0.0f;    // atomic<FloatType> armed, loaded once per block
     float gain = u2f(r[rec::S0]), lastIn = u2f(r[rec::S1]);
     bool disarm = false;
-    for (uint32_t t = 0; t < c.n; ++t) {
-        const float x = sget(xs, t);
-        const float delta = change_tick(lastIn, x);
+    chain_loop<1>(in, cm, m.outLds, c.n, [&](const float (&x)[1]) {
+        const float delta = change_tick(lastIn, x[0]);
         if (isArmed && delta > 0.5f) { gain = 1.0f; disarm = true; }
         if (delta < -0.5f) gain = 0.0f;
-        lds[m.outLds + t] = x * gain;
-    }
+        return x[0] * gain;
+    });
     r[rec::S0] = f2u(gain); r[rec::S1] = f2u(lastIn);
     if (disarm) r[rec::S2] = f2u(0.0f);
 }
 
 // SequenceNode (Core.h:407-573)
-__device__ void ser_seq(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
-    const float* seq = rec_ptr(r, rec::SEQ_PTR);
+__device__ __forceinline__ void ser_seq(const Ctx& c, const Member& m, uint32_t cm) {
+    gup r = c.recs + m.rec * kRecDwords;
+    gcfp seq = rec_ptr(r, rec::SEQ_PTR);
     const uint32_t len = r[rec::SEQ_LEN];
     uint32_t idx = r[rec::SEQ_INDEX];
     float holdValue = u2f(r[rec::SEQ_HOLDVAL]);
@@ -631,73 +821,22 @@ __device__ void ser_seq(const Ctx& c, const Member& m) {
     const bool hasReset = nin > 1;
     const bool hold = r[rec::SEQ_HOLD] != 0, loop = r[rec::SEQ_LOOP] != 0;
     const uint32_t offset = r[rec::SEQ_OFFSET];
-    const SIn ts = sin_of(member_opnd(c, m, 0));
-    const SIn rs = hasReset ? sin_of(member_opnd(c, m, 1)) : SIn{0, 0};
+    const SIn in[2] = {sin_of(opnd_lane(c, m, 0)), hasReset ? sin_of(opnd_lane(c, m, 1)) : SIn{0u, 0.0f}};
+    const uint32_t cm2 = hasReset ? cm : (cm | 2u);
     float chg = u2f(r[rec::SEQ_CHANGE]), rchg = u2f(r[rec::SEQ_RCHANGE]);
-    for (uint32_t t = 0; t < c.n; ++t) {
-        const float in = sget(ts, t);
-        const float reset = hasReset ? sget(rs, t) : 0.0f;
-        if (change_tick(rchg, reset) > 0.5f) idx = offset;
-        if (change_tick(chg, in) > 0.5f) {
+    chain_loop<2>(in, cm2, m.outLds, c.n, [&](const float (&x)[2]) {
+        if (change_tick(rchg, x[1]) > 0.5f) idx = offset;
+        if (change_tick(chg, x[0]) > 0.5f) {
             // std::min(seqIndex, size - 1): size_t arithmetic, an empty sequence reads nothing here
             if (len) holdValue = seq[min(idx, len - 1)];
             first = true;
             if ((++idx >= len) && loop) idx = 0;
         }
-        float y;
-        if (idx < len) y = hold ? holdValue : holdValue * in;
-        else           y = hold ? holdValue : 0.0f;
-        lds[m.outLds + t] = y;
-    }
+        if (idx < len) return hold ? holdValue : holdValue * x[0];
+        return hold ? holdValue : 0.0f;
+    });
     r[rec::SEQ_INDEX] = idx; r[rec::SEQ_HOLDVAL] = f2u(holdValue); r[rec::SEQ_FIRST] = first;
     r[rec::SEQ_CHANGE] = f2u(chg); r[rec::SEQ_RCHANGE] = f2u(rchg); r[rec::SEQ_HAVE] = 1;
-}
-
-// MultiMode1p (filters/MultiMode1p.h:38-113): double state; G = g/(1+g) hoisted into `pre`.
-__device__ void ser_mm1p(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
-    const SIn xs = sin_of(member_opnd(c, m, 1));
-    const uint32_t mode = r[rec::P0];
-    const double* G = reinterpret_cast<const double*>(lds + m.scratch);
-    double z = rec_ld_f64(r, rec::S0);
-    for (uint32_t t = 0; t < c.n; ++t) {
-        const float xn = sget(xs, t);
-        const double v = ((double)xn - z) * G[t];
-        const double lp = v + z;
-        z = lp + v;
-        float y;
-        if (mode == 0)      y = (float)lp;
-        else if (mode == 2) y = xn - (float)lp;
-        else                y = (float)(lp + lp - (double)xn);
-        lds[m.outLds + t] = y;
-    }
-    rec_st_f64(r, rec::S0, z);
-}
-
-// StateVariableFilterNode::tick (filters/SVF.h:48-70) / shelf (filters/SVFShelf.h:44-64).
-// Scratch holds a1,a2,a3 (double) per sample from the coefficient pre-pass; for modes whose
-// output needs k (and A) the chain stores v1,v2 back over a1,a2 and a parallel post-pass
-// forms the output.
-template <bool Direct>
-__device__ void ser_svf_chain(const Ctx& c, const Member& m, uint32_t inIdx, uint32_t mode) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
-    const SIn xs = sin_of(member_opnd(c, m, inIdx));
-    double* A1 = reinterpret_cast<double*>(lds + m.scratch);
-    double* A2 = A1 + kSlotWords;       // each double array spans two float slots
-    double* A3 = A2 + kSlotWords;
-    double ic1 = rec_ld_f64(r, rec::S0), ic2 = rec_ld_f64(r, rec::S2);
-    for (uint32_t t = 0; t < c.n; ++t) {
-        const double a1 = A1[t], a2 = A2[t], a3 = A3[t];
-        const double v0 = (double)sget(xs, t);
-        const double v3 = v0 - ic2;
-        const double v1 = ic1 * a1 + v3 * a2;
-        const double v2 = ic2 + ic1 * a2 + v3 * a3;
-        ic1 = v1 * 2.0 - ic1;
-        ic2 = v2 * 2.0 - ic2;
-        if (Direct) lds[m.outLds + t] = (float)(mode == 0 ? v2 : v1);
-        else { A1[t] = v1; A2[t] = v2; }
-    }
-    rec_st_f64(r, rec::S0, ic1); rec_st_f64(r, rec::S2, ic2);
 }
 
 // PolyBlepOscillatorNode (Oscillators.h:19-94)
@@ -709,240 +848,370 @@ __device__ __forceinline__ float blep(float phase, float inc) {
 
 // serial part: only `phase += inc; if (phase >= 1) phase -= 1`. The out slot carries inc[t] in
 // (from the pre-pass) and the pre-tick phase[t] out (for the post-pass).
-__device__ void ser_blep_phase(const Ctx& c, const Member& m) {
-    uint32_t* r = c.recs + m.rec * kRecDwords;
+__device__ __forceinline__ void ser_blep_phase(const Ctx& c, const Member& m) {
+    gup r = c.recs + m.rec * kRecDwords;
     float phase = u2f(r[rec::S0]);
-    for (uint32_t t0 = 0; t0 < c.n; t0 += CH) {
-        float inc[CH], y[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) inc[j] = lds[m.outLds + min(t0 + j, c.n - 1)];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            y[j] = phase;
-            float np = phase + inc[j];
-            if (np >= 1.0f) np -= 1.0f;
-            if (t0 + j < c.n) phase = np;
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) if (t0 + j < c.n) lds[m.outLds + t0 + j] = y[j];
-    }
+    const SIn in[1] = {SIn{m.outLds, 0.0f}};
+    chain_loop<1>(in, 0u, m.outLds, c.n, [&](const float (&x)[1]) {
+        const float y = phase;
+        phase += x[0];
+        if (phase >= 1.0f) phase -= 1.0f;
+        return y;
+    });
     r[rec::S0] = f2u(phase);
 }
 
-__device__ void ser_blep_acc(const Ctx& c, const Member& m) {   // triangle integrator (:58-59)
-    uint32_t* r = c.recs + m.rec * kRecDwords;
+__device__ __forceinline__ void ser_blep_acc(const Ctx& c, const Member& m) {   // triangle integrator (:58-59)
+    gup r = c.recs + m.rec * kRecDwords;
     float acc = u2f(r[rec::S1]);
-    for (uint32_t t0 = 0; t0 < c.n; t0 += CH) {
-        float d[CH], y[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) d[j] = lds[m.outLds + min(t0 + j, c.n - 1)];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) { const float na = acc + d[j]; if (t0 + j < c.n) acc = na; y[j] = acc; }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) if (t0 + j < c.n) lds[m.outLds + t0 + j] = y[j];
-    }
+    const SIn in[1] = {SIn{m.outLds, 0.0f}};
+    chain_loop<1>(in, 0u, m.outLds, c.n, [&](const float (&x)[1]) { acc += x[0]; return acc; });
     r[rec::S1] = f2u(acc);
 }
 
-// ---- task dispatch ------------------------------------------------------------------------------
-template <typename F>
-__device__ __forceinline__ void for_members(const Ctx& c, const Member* members, const Task& t, F&& f) {
-    for (uint32_t k = 0; k < t.count; ++k) { const Member m = members[t.first + k]; f(m); }
+// ---- double-state filters as wave scans -----------------------------------------------------------
+// SVF / shelf / mm1p keep their state in double in the reference (filters/SVF.h:112-120,
+// MultiMode1p.h:110); their per-sample update is an affine map of the state whose coefficients
+// depend only on the inputs, so one wave evaluates a whole block as a scan of affine maps:
+// lane l owns samples [8l, 8l+8), composes them locally, a 6-step Kogge-Stone scan over the 64
+// lane aggregates yields each lane's incoming state, and the lane then replays its 8 samples to
+// form the outputs. Re-association moves results by O(1e-16) relative — far inside the 1e-6 bar
+// for these (stable, contractive) recurrences — and removes the 512-step f64 dependency chain.
+struct Aff2 { double m11, m12, m21, m22, q1, q2; };   // s' = M s + q
+
+__device__ __forceinline__ Aff2 aff2_after(const Aff2& f, const Aff2& g) {   // apply f, then g
+    Aff2 r;
+    r.m11 = g.m11 * f.m11 + g.m12 * f.m21; r.m12 = g.m11 * f.m12 + g.m12 * f.m22;
+    r.m21 = g.m21 * f.m11 + g.m22 * f.m21; r.m22 = g.m21 * f.m12 + g.m22 * f.m22;
+    r.q1 = g.m11 * f.q1 + g.m12 * f.q2 + g.q1;
+    r.q2 = g.m21 * f.q1 + g.m22 * f.q2 + g.q2;
+    return r;
+}
+__device__ __forceinline__ double shfl_up_f64(double v, int d) {
+    const int lo = __shfl_up(__double2loint(v), d), hi = __shfl_up(__double2hiint(v), d);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_f64(double v, int l) {
+    const int lo = __shfl(__double2loint(v), l), hi = __shfl(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
 
-// Stateful task: parallel pre-pass over all members, lane-per-member chain, parallel post-pass.
-__device__ void run_stateful(const Ctx& c, const Member* members, const Task& t) {
-    const uint32_t n = c.n;
-    const uint16_t op = t.opcode;
-    // ---- pre-pass (sample-parallel) ----
-    if (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_BLEPTRIANGLE) {
-        const float sr = c.g->sampleRateF;
-        for_members(c, members, t, [&](const Member& m) {
-            if (member_nin(c, m) < 1) return;
-            const uint32_t o = member_opnd(c, m, 0);
-            for (uint32_t i = c.lane; i < n; i += 64) lds[m.outLds + i] = fetch(c, o, i) / sr;
-        });
-    } else if (op == OP_SVF) {
-        const double sr = c.g->sampleRate;
-        for_members(c, members, t, [&](const Member& m) {
-            if (member_nin(c, m) < 3) return;
-            const uint32_t oF = member_opnd(c, m, 0), oQ = member_opnd(c, m, 1);
-            double* A1 = reinterpret_cast<double*>(lds + m.scratch);
-            double* A2 = A1 + kSlotWords; double* A3 = A2 + kSlotWords;
-            for (uint32_t i = c.lane; i < n; i += 64) {   // updateCoeffs, SVF.h:72-80
-                const double fc = (double)fetch(c, oF, i), q = (double)fetch(c, oQ, i);
-                const double g = tan(3.14159265359 * clampd(fc, 20.0, sr / 2.0001) / sr);
-                const double k = 1.0 / clampd(q, 0.25, 20.0);
-                const double a1 = 1.0 / (1.0 + g * (g + k));
-                const double a2 = g * a1;
-                A1[i] = a1; A2[i] = a2; A3[i] = g * a2;
-            }
-        });
-    } else if (op == OP_SVFSHELF) {
-        const double sr = c.g->sampleRate;
-        for_members(c, members, t, [&](const Member& m) {
-            if (member_nin(c, m) < 4) return;
-            const uint32_t mode = c.recs[m.rec * kRecDwords + rec::P0];
-            const uint32_t oF = member_opnd(c, m, 0), oQ = member_opnd(c, m, 1), oG = member_opnd(c, m, 2);
-            double* A1 = reinterpret_cast<double*>(lds + m.scratch);
-            double* A2 = A1 + kSlotWords; double* A3 = A2 + kSlotWords;
-            for (uint32_t i = c.lane; i < n; i += 64) {   // updateCoeffs, SVFShelf.h:66-83
-                const double fc = (double)fetch(c, oF, i), q = (double)fetch(c, oQ, i), dB = (double)fetch(c, oG, i);
-                const double A = pow(10.0, dB / 40.0);
-                double g = tan(3.14159265359 * clampd(fc, 20.0, sr / 2.0001) / sr);
-                double k = 1.0 / clampd(q, 0.25, 20.0);
-                if (mode == 0) g /= A;
-                if (mode == 1) g *= A;
-                if (mode == 2) k /= A;
-                const double a1 = 1.0 / (1.0 + g * (g + k));
-                const double a2 = g * a1;
-                A1[i] = a1; A2[i] = a2; A3[i] = g * a2;
-            }
-        });
-    } else if (op == OP_MM1P) {
-        for_members(c, members, t, [&](const Member& m) {
-            if (member_nin(c, m) < 2) return;
-            const uint32_t oG = member_opnd(c, m, 0);
-            double* G = reinterpret_cast<double*>(lds + m.scratch);
-            for (uint32_t i = c.lane; i < n; i += 64) {
-                const double g = clampd((double)fetch(c, oG, i), 0.0, 0.9999);
-                G[i] = g / (1.0 + g);
-            }
-        });
+// Exclusive scan over lanes of per-lane aggregates; returns the composition of lanes [0, lane).
+__device__ __forceinline__ Aff2 aff2_exclusive_scan(Aff2 a, uint32_t lane, Aff2& total) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Aff2 p;
+        p.m11 = shfl_up_f64(a.m11, d); p.m12 = shfl_up_f64(a.m12, d); p.m21 = shfl_up_f64(a.m21, d);
+        p.m22 = shfl_up_f64(a.m22, d); p.q1 = shfl_up_f64(a.q1, d); p.q2 = shfl_up_f64(a.q2, d);
+        if (lane >= (uint32_t)d) a = aff2_after(p, a);
     }
-    WAVE_SYNC();
+    total.m11 = shfl_f64(a.m11, 63); total.m12 = shfl_f64(a.m12, 63); total.m21 = shfl_f64(a.m21, 63);
+    total.m22 = shfl_f64(a.m22, 63); total.q1 = shfl_f64(a.q1, 63); total.q2 = shfl_f64(a.q2, 63);
+    Aff2 e;
+    e.m11 = shfl_up_f64(a.m11, 1); e.m12 = shfl_up_f64(a.m12, 1); e.m21 = shfl_up_f64(a.m21, 1);
+    e.m22 = shfl_up_f64(a.m22, 1); e.q1 = shfl_up_f64(a.q1, 1); e.q2 = shfl_up_f64(a.q2, 1);
+    if (lane == 0) { e.m11 = 1.0; e.m12 = 0.0; e.m21 = 0.0; e.m22 = 1.0; e.q1 = 0.0; e.q2 = 0.0; }
+    return e;
+}
 
-    // ---- chain (lane-per-member) ----
-    if (c.lane < t.count && n > 0) {
-        const Member m = members[t.first + c.lane];
-        switch (op) {
-            case OP_PHASOR:   ser_phasor<false>(c, m); break;
-            case OP_SPHASOR:  ser_phasor<true>(c, m); break;
-            case OP_POLE:     ser_pole(c, m); break;
-            case OP_ENV:      ser_env(c, m); break;
-            case OP_BIQUAD:   ser_biquad(c, m); break;
-            case OP_COUNTER:  ser_counter(c, m); break;
-            case OP_ACCUM:    ser_accum(c, m); break;
-            case OP_LATCH:    ser_latch(c, m); break;
-            case OP_MAXHOLD:  ser_maxhold(c, m); break;
-            case OP_ONCE:     ser_once(c, m); break;
-            case OP_SEQ:      ser_seq(c, m); break;
-            case OP_MM1P:
-                if (member_nin(c, m) < 2) szero(m, n); else ser_mm1p(c, m);
-                break;
-            case OP_SVF: {
-                if (member_nin(c, m) < 3) { szero(m, n); break; }
-                const uint32_t mode = c.recs[m.rec * kRecDwords + rec::P0];
-                if (mode <= 1) ser_svf_chain<true>(c, m, 2, mode); else ser_svf_chain<false>(c, m, 2, mode);
-                break;
-            }
-            case OP_SVFSHELF:
-                if (member_nin(c, m) < 4) szero(m, n); else ser_svf_chain<false>(c, m, 3, 0);
-                break;
-            case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
-                if (member_nin(c, m) < 1) szero(m, n); else ser_blep_phase(c, m);
-                break;
-            default: break;
+// SVF / shelf coefficient pre-pass (updateCoeffs, filters/SVF.h:72-80, SVFShelf.h:66-83): the
+// double tan / pow / divisions are the expensive, state-free part, so they run sample-parallel on
+// every free wave one stage before the scan and land in the member's scratch as doubles:
+// a1,a2,a3 (svf) or a1,a2,a3,k,A (shelf), each array spanning two float slots.
+template <bool Shelf, int V>
+__device__ __forceinline__ void run_svf_coef(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
+    if (member_nin(c, m) < (Shelf ? 4u : 3u)) return;
+    const uint32_t mode = Shelf ? UNI(c.recs[m.rec * kRecDwords + rec::P0]) : 0u;
+    double* A1 = reinterpret_cast<double*>(lds + m.scratch);
+    double* A2 = A1 + kSlotWords; double* A3 = A2 + kSlotWords;
+    double* KK = A3 + kSlotWords; double* AA = KK + kSlotWords;
+    const double sr = c.sr;
+    float fcv[V], qv[V], gv[V];
+    vload<V>(pin_of(c, opnd_uniform(c, m, 0)), i, fcv);
+    vload<V>(pin_of(c, opnd_uniform(c, m, 1)), i, qv);
+    if (Shelf) vload<V>(pin_of(c, opnd_uniform(c, m, 2)), i, gv);
+#pragma unroll
+    for (int q_ = 0; q_ < V; ++q_) {
+        const uint32_t t = i + q_;
+        const double fc = (double)fcv[q_], q = (double)qv[q_];
+        double g = tan(3.14159265359 * clampd(fc, 20.0, sr / 2.0001) / sr);
+        double k = 1.0 / clampd(q, 0.25, 20.0);
+        if (Shelf) {
+            const double A = pow(10.0, (double)gv[q_] / 40.0);
+            if (mode == 0) g /= A;
+            if (mode == 1) g *= A;
+            if (mode == 2) k /= A;
+            if (t < nlim) { KK[t] = k; AA[t] = A; }
+        }
+        const double a1 = 1.0 / (1.0 + g * (g + k));
+        const double a2 = g * a1;
+        if (t < nlim) { A1[t] = a1; A2[t] = a2; A3[t] = g * a2; }
+    }
+}
+
+// StateVariableFilterNode (filters/SVF.h:48-105) and StateVariableShelfFilterNode
+// (filters/SVFShelf.h:44-124), whole wave on one node.
+//   tick:  v3 = v0 - ic2; v1 = ic1*a1 + v3*a2; v2 = ic2 + ic1*a2 + v3*a3; ic1 = 2 v1 - ic1; ic2 = 2 v2 - ic2
+//   =>     ic1' = (2a1-1) ic1 - 2a2 ic2 + 2a2 v0 ;  ic2' = 2a2 ic1 + (1-2a3) ic2 + 2a3 v0
+template <bool Shelf>
+__device__ __forceinline__ void scan_svf(const Ctx& c, const Member& m) {
+    gup r = c.recs + m.rec * kRecDwords;
+    const uint32_t n = c.n, need = Shelf ? 4u : 3u;
+    if (member_nin(c, m) < need) { for (uint32_t i = c.lane; i < n; i += 64) lds[m.outLds + i] = 0.0f; return; }
+    const uint32_t mode = UNI(r[rec::P0]);
+    const PIn pQ = pin_of(c, opnd_uniform(c, m, 1));
+    const PIn pX = pin_of(c, opnd_uniform(c, m, Shelf ? 3 : 2));
+    const double* A1 = reinterpret_cast<const double*>(lds + m.scratch);
+    const double* A2 = A1 + kSlotWords; const double* A3 = A2 + kSlotWords;
+    const double* KK = A3 + kSlotWords; const double* AA = KK + kSlotWords;
+    const uint32_t t0 = c.lane * 8u;
+    double a1[8], a2[8], a3[8], v0[8];
+    {   // lane-owned 8 samples: 16-byte LDS reads
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const v2d p1 = ld2d(&A1[t0 + j]);
+            const v2d p2 = ld2d(&A2[t0 + j]);
+            const v2d p3 = ld2d(&A3[t0 + j]);
+            a1[j] = p1.x; a1[j + 1] = p1.y; a2[j] = p2.x; a2[j + 1] = p2.y; a3[j] = p3.x; a3[j + 1] = p3.y;
+        }
+        if (pX.g) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v0[j] = (double)pX.g[t0 + j];
+        } else if (pX.step) {
+            const v4f xa = ld4(pX.base + t0);
+            const v4f xb = ld4(pX.base + t0 + 4);
+            v0[0] = xa.x; v0[1] = xa.y; v0[2] = xa.z; v0[3] = xa.w; v0[4] = xb.x; v0[5] = xb.y; v0[6] = xb.z; v0[7] = xb.w;
+        } else {
+            const double x = (double)lds[pX.base];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v0[j] = x;
         }
     }
-    WAVE_SYNC();
+    Aff2 agg; agg.m11 = 1.0; agg.m12 = 0.0; agg.m21 = 0.0; agg.m22 = 1.0; agg.q1 = 0.0; agg.q2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (t0 + j < n) {
+            Aff2 s;
+            s.m11 = 2.0 * a1[j] - 1.0; s.m12 = -2.0 * a2[j];
+            s.m21 = 2.0 * a2[j];       s.m22 = 1.0 - 2.0 * a3[j];
+            s.q1 = 2.0 * a2[j] * v0[j]; s.q2 = 2.0 * a3[j] * v0[j];
+            agg = aff2_after(agg, s);
+        }
+    }
+    Aff2 total;
+    const Aff2 pre = aff2_exclusive_scan(agg, c.lane, total);
+    const double s1 = rec_ld_f64(r, rec::S0), s2 = rec_ld_f64(r, rec::S2);
+    double ic1 = pre.m11 * s1 + pre.m12 * s2 + pre.q1;
+    double ic2 = pre.m21 * s1 + pre.m22 * s2 + pre.q2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t t = t0 + j;
+        if (t < n) {
+            const double v3 = v0[j] - ic2;
+            const double v1 = ic1 * a1[j] + v3 * a2[j];
+            const double v2 = ic2 + ic1 * a2[j] + v3 * a3[j];
+            ic1 = v1 * 2.0 - ic1;
+            ic2 = v2 * 2.0 - ic2;
+            float y;
+            if (!Shelf) {   // SVF.h:57-69
+                if (mode == 0)      y = (float)v2;
+                else if (mode == 1) y = (float)v1;
+                else {
+                    const float qf = pQ.g ? pQ.g[t] : lds[pQ.base + t * pQ.step];
+                    const double k = 1.0 / clampd((double)qf, 0.25, 20.0);
+                    if (mode == 2)      y = (float)(v0[j] - k * v1 - v2);
+                    else if (mode == 3) y = (float)(v0[j] - k * v1);
+                    else                y = (float)(v0[j] - 2.0 * k * v1);
+                }
+            } else {        // SVFShelf.h:54-63
+                const double A = AA[t], k = KK[t];
+                if (mode == 2)      y = (float)(v0[j] + k * (A * A - 1.0) * v1);
+                else if (mode == 0) y = (float)(v0[j] + k * (A - 1.0) * v1 + (A * A - 1.0) * v2);
+                else                y = (float)(A * A * v0[j] + k * (1.0 - A) * A * v1 + (1.0 - A * A) * v2);
+            }
+            lds[m.outLds + t] = y;
+        }
+    }
+    if (c.lane == 0) {
+        rec_st_f64(r, rec::S0, total.m11 * s1 + total.m12 * s2 + total.q1);
+        rec_st_f64(r, rec::S2, total.m21 * s1 + total.m22 * s2 + total.q2);
+    }
+}
 
-    // ---- post-pass (sample-parallel) ----
-    if (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_BLEPTRIANGLE) {
-        const float sr = c.g->sampleRateF;
-        for_members(c, members, t, [&](const Member& m) {
-            if (member_nin(c, m) < 1) return;
-            const uint32_t o = member_opnd(c, m, 0);
-            for (uint32_t i = c.lane; i < n; i += 64) {
-                const float inc = fetch(c, o, i) / sr;
-                const float phase = lds[m.outLds + i];
-                float y;
-                if (op == OP_BLEPSAW) {
-                    y = 2.0f * phase - 1.0f - blep(phase, inc);
+// MultiMode1p (filters/MultiMode1p.h:79-107): v = (x - z) G; lp = v + z; z' = lp + v
+//   =>  z' = (1 - 2G) z + 2G x  (1-D affine scan); lp is formed from the pre-sample state.
+__device__ __forceinline__ void scan_mm1p(const Ctx& c, const Member& m) {
+    gup r = c.recs + m.rec * kRecDwords;
+    const uint32_t n = c.n;
+    if (member_nin(c, m) < 2) { for (uint32_t i = c.lane; i < n; i += 64) lds[m.outLds + i] = 0.0f; return; }
+    const uint32_t mode = UNI(r[rec::P0]);
+    const PIn pGn = pin_of(c, opnd_uniform(c, m, 0)), pX = pin_of(c, opnd_uniform(c, m, 1));
+    const uint32_t t0 = c.lane * 8u;
+    double G[8]; float xs[8];
+    double am = 1.0, aq = 0.0;   // z' = am z + aq over this lane's samples
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t t = t0 + j;
+        const bool live = t < n;
+        const uint32_t tc = live ? t : 0u;
+        auto rd = [&](const PIn& p) { return p.g ? p.g[tc] : lds[p.base + tc * p.step]; };
+        const double g = clampd((double)rd(pGn), 0.0, 0.9999);
+        G[j] = g / (1.0 + g);
+        xs[j] = rd(pX);
+        if (live) {
+            const double mm = 1.0 - 2.0 * G[j], qq = 2.0 * G[j] * (double)xs[j];
+            am = mm * am; aq = mm * aq + qq;
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double pm = shfl_up_f64(am, d), pq = shfl_up_f64(aq, d);
+        if (c.lane >= (uint32_t)d) { aq = am * pq + aq; am = am * pm; }
+    }
+    const double tm = shfl_f64(am, 63), tq = shfl_f64(aq, 63);
+    double em = shfl_up_f64(am, 1), eq = shfl_up_f64(aq, 1);
+    if (c.lane == 0) { em = 1.0; eq = 0.0; }
+    const double z0 = rec_ld_f64(r, rec::S0);
+    double z = em * z0 + eq;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t t = t0 + j;
+        if (t < n) {
+            const float xn = xs[j];
+            const double v = ((double)xn - z) * G[j];
+            const double lp = v + z;
+            z = lp + v;
+            float y;
+            if (mode == 0)      y = (float)lp;
+            else if (mode == 2) y = xn - (float)lp;
+            else                y = (float)(lp + lp - (double)xn);
+            lds[m.outLds + t] = y;
+        }
+    }
+    if (c.lane == 0) rec_st_f64(r, rec::S0, tm * z0 + tq);
+}
+
+// ---- task dispatch ------------------------------------------------------------------------------
+struct TaskU { uint32_t opcode, stage, flags, s0, s1, first, count; };
+
+template <typename F>
+__device__ __forceinline__ void for_members(const Ctx& c, const TaskU& t, F&& f) {
+    for (uint32_t k = 0; k < t.count; ++k) { const Member m = member_uniform(c, t.first + k); f(m); }
+}
+
+// Stateful task: whole-wave scans for the double-state filters; otherwise a sample-parallel
+// pre-pass over all members, the lane-per-member chain, and a sample-parallel post-pass.
+__device__ __forceinline__ void run_stateful(const Ctx& c, const TaskU& t) {
+    const uint32_t n = c.n;
+    const uint32_t op = t.opcode;
+    const uint32_t cm = t.flags;
+    if (op == OP_SVF || op == OP_SVFSHELF || op == OP_MM1P) {
+        for_members(c, t, [&](const Member& m) {
+            if (op == OP_SVF) scan_svf<false>(c, m);
+            else if (op == OP_SVFSHELF) scan_svf<true>(c, m);
+            else scan_mm1p(c, m);
+        });
+    } else {
+        const bool isBlep = (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_BLEPTRIANGLE);
+        if (isBlep) {   // pre-pass: inc[t] = f/sr into the out slot
+            const float sr = c.srF;
+            for_members(c, t, [&](const Member& m) {
+                if (member_nin(c, m) < 1) return;
+                const PIn p = pin_of(c, opnd_uniform(c, m, 0));
+                if (n == 512) {   // full block: 8 consecutive frames per lane, vector LDS traffic
+                    float x[8];
+                    vload<8>(p, c.lane * 8u, x);
+                    v4f a, b;
+                    a.x = x[0] / sr; a.y = x[1] / sr; a.z = x[2] / sr; a.w = x[3] / sr;
+                    b.x = x[4] / sr; b.y = x[5] / sr; b.z = x[6] / sr; b.w = x[7] / sr;
+                    st4(m.outLds + c.lane * 8u, a); st4(m.outLds + c.lane * 8u + 4u, b);
                 } else {
+                    for (uint32_t i = c.lane; i < n; i += 64) lds[m.outLds + i] = pget(p, i) / sr;
+                }
+            });
+            WAVE_SYNC();
+        }
+        if (c.lane < t.count && n > 0) {
+            const Member m = member_lane(c, t.first + c.lane);
+            switch (op) {
+                case OP_PHASOR:   ser_phasor(c, m, cm); break;
+                case OP_SPHASOR:  ser_sphasor(c, m, cm); break;
+                case OP_POLE:     ser_pole(c, m, cm); break;
+                case OP_ENV:      ser_env(c, m, cm); break;
+                case OP_BIQUAD:   ser_biquad(c, m, cm); break;
+                case OP_COUNTER:  ser_counter(c, m, cm); break;
+                case OP_ACCUM:    ser_accum(c, m, cm); break;
+                case OP_LATCH:    ser_latch(c, m, cm); break;
+                case OP_MAXHOLD:  ser_maxhold(c, m, cm); break;
+                case OP_ONCE:     ser_once(c, m, cm); break;
+                case OP_SEQ:      ser_seq(c, m, cm); break;
+                case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
+                    if (member_nin(c, m) < 1) szero(m, n); else ser_blep_phase(c, m);
+                    break;
+                default: break;
+            }
+        }
+        WAVE_SYNC();
+        if (isBlep) {   // post-pass: waveform from (phase, inc)
+            const float sr = c.srF;
+            for_members(c, t, [&](const Member& m) {
+                if (member_nin(c, m) < 1) return;
+                const PIn p = pin_of(c, opnd_uniform(c, m, 0));
+                auto wave = [&](float f, float phase) {
+                    const float inc = f / sr;
+                    if (op == OP_BLEPSAW) return 2.0f * phase - 1.0f - blep(phase, inc);
                     const float naive = phase < 0.5f ? 1.0f : -1.0f;
                     const float halfPhase = fmodf(phase + 0.5f, 1.0f);
                     const float square = naive + blep(phase, inc) - blep(halfPhase, inc);
-                    y = (op == OP_BLEPSQUARE) ? square : (4.0f * inc * square);
+                    return (op == OP_BLEPSQUARE) ? square : (4.0f * inc * square);
+                };
+                if (n == 512) {
+                    float f[8], ph[8];
+                    vload<8>(p, c.lane * 8u, f);
+                    vload<8>(PIn{m.outLds, 1u, (gcfp)nullptr}, c.lane * 8u, ph);
+                    v4f a, b;
+                    a.x = wave(f[0], ph[0]); a.y = wave(f[1], ph[1]); a.z = wave(f[2], ph[2]); a.w = wave(f[3], ph[3]);
+                    b.x = wave(f[4], ph[4]); b.y = wave(f[5], ph[5]); b.z = wave(f[6], ph[6]); b.w = wave(f[7], ph[7]);
+                    st4(m.outLds + c.lane * 8u, a); st4(m.outLds + c.lane * 8u + 4u, b);
+                } else {
+                    for (uint32_t i = c.lane; i < n; i += 64) lds[m.outLds + i] = wave(pget(p, i), lds[m.outLds + i]);
                 }
-                lds[m.outLds + i] = y;
-            }
-        });
-        if (op == OP_BLEPTRIANGLE) {
-            WAVE_SYNC();
-            if (c.lane < t.count && n > 0) {
-                const Member m = members[t.first + c.lane];
-                if (member_nin(c, m) >= 1) ser_blep_acc(c, m);
+            });
+            if (op == OP_BLEPTRIANGLE) {
+                WAVE_SYNC();
+                if (c.lane < t.count && n > 0) {
+                    const Member m = member_lane(c, t.first + c.lane);
+                    if (member_nin(c, m) >= 1) ser_blep_acc(c, m);
+                }
             }
         }
-    } else if (op == OP_SVF) {
-        for_members(c, members, t, [&](const Member& m) {
-            if (member_nin(c, m) < 3) return;
-            const uint32_t mode = c.recs[m.rec * kRecDwords + rec::P0];
-            if (mode <= 1) return;
-            const uint32_t oQ = member_opnd(c, m, 1), oX = member_opnd(c, m, 2);
-            const double* V1 = reinterpret_cast<const double*>(lds + m.scratch);
-            const double* V2 = V1 + kSlotWords;
-            for (uint32_t i = c.lane; i < n; i += 64) {   // SVF.h:57-69
-                const double k = 1.0 / clampd((double)fetch(c, oQ, i), 0.25, 20.0);
-                const double v0 = (double)fetch(c, oX, i), v1 = V1[i], v2 = V2[i];
-                float y;
-                if (mode == 2)      y = (float)(v0 - k * v1 - v2);
-                else if (mode == 3) y = (float)(v0 - k * v1);
-                else                y = (float)(v0 - 2.0 * k * v1);
-                lds[m.outLds + i] = y;
-            }
-        });
-    } else if (op == OP_SVFSHELF) {
-        for_members(c, members, t, [&](const Member& m) {
-            if (member_nin(c, m) < 4) return;
-            const uint32_t mode = c.recs[m.rec * kRecDwords + rec::P0];
-            const uint32_t oQ = member_opnd(c, m, 1), oG = member_opnd(c, m, 2), oX = member_opnd(c, m, 3);
-            const double* V1 = reinterpret_cast<const double*>(lds + m.scratch);
-            const double* V2 = V1 + kSlotWords;
-            for (uint32_t i = c.lane; i < n; i += 64) {   // SVFShelf.h:54-63
-                const double A = pow(10.0, (double)fetch(c, oG, i) / 40.0);
-                double k = 1.0 / clampd((double)fetch(c, oQ, i), 0.25, 20.0);
-                if (mode == 2) k /= A;
-                const double v0 = (double)fetch(c, oX, i), v1 = V1[i], v2 = V2[i];
-                float y;
-                if (mode == 2)      y = (float)(v0 + k * (A * A - 1.0) * v1);
-                else if (mode == 0) y = (float)(v0 + k * (A - 1.0) * v1 + (A * A - 1.0) * v2);
-                else                y = (float)(A * A * v0 + k * (1.0 - A) * A * v1 + (1.0 - A * A) * v2);
-                lds[m.outLds + i] = y;
-            }
-        });
     }
     WAVE_SYNC();
-    // stateful outputs are produced in LDS; the planner schedules an OP_COPY export if another
-    // island consumes them, except for direct HBM outputs requested here
-    for_members(c, members, t, [&](const Member& m) {
+    // chain outputs are produced in LDS; copy out the ones another island (or the epilogue) reads
+    for_members(c, t, [&](const Member& m) {
         if (m.outHbm == kNone) return;
         for (uint32_t i = c.lane; i < n; i += 64) c.hbm[(size_t)m.outHbm * c.stride + i] = lds[m.outLds + i];
     });
 }
 
-__device__ void run_task(const Ctx& c, const Member* members, const Task& t) {
-    const uint32_t s0 = min((uint32_t)t.s0, c.n), s1 = min((uint32_t)t.s1, c.n);
-#define PAR(OPC, FN) case OPC: for_members(c, members, t, [&](const Member& m) { FN(c, m, s0, s1); }); break;
-#define UN(OPC)  case OPC: for_members(c, members, t, [&](const Member& m) { run_unary<OPC>(c, m, s0, s1); }); break;
-#define BI(OPC)  case OPC: for_members(c, members, t, [&](const Member& m) { run_binary<OPC>(c, m, s0, s1); }); break;
-#define RE(OPC)  case OPC: for_members(c, members, t, [&](const Member& m) { run_reduce<OPC>(c, m, s0, s1); }); break;
+// sample-parallel opcodes on the canonical mapping, V consecutive frames per lane
+template <int V>
+__device__ __forceinline__ void run_par(const Ctx& c, const TaskU& t, uint32_t i, uint32_t nlim) {
+#define PAR(OPC, FN) case OPC: for_members(c, t, [&](const Member& m) { FN<V>(c, m, i, nlim); }); break;
+#define UN(OPC)  case OPC: for_members(c, t, [&](const Member& m) { run_unary<OPC, V>(c, m, i, nlim); }); break;
+#define BI(OPC)  case OPC: for_members(c, t, [&](const Member& m) { run_binary<OPC, V>(c, m, i, nlim); }); break;
+#define RE(OPC)  case OPC: for_members(c, t, [&](const Member& m) { run_reduce<OPC, V>(c, m, i, nlim); }); break;
     switch (t.opcode) {
         UN(OP_SIN) UN(OP_COS) UN(OP_TAN) UN(OP_TANH) UN(OP_ASINH) UN(OP_LN) UN(OP_LOG) UN(OP_LOG2)
         UN(OP_CEIL) UN(OP_FLOOR) UN(OP_ROUND) UN(OP_SQRT) UN(OP_EXP) UN(OP_ABS)
         BI(OP_LE) BI(OP_LEQ) BI(OP_GE) BI(OP_GEQ) BI(OP_POW) BI(OP_EQ) BI(OP_AND) BI(OP_OR)
         RE(OP_ADD) RE(OP_SUB) RE(OP_MUL) RE(OP_DIV) RE(OP_MOD) RE(OP_MIN) RE(OP_MAX)
         PAR(OP_IN, run_in) PAR(OP_COPY, run_copy) PAR(OP_ROOT, run_root) PAR(OP_PREWARP, run_prewarp)
-        PAR(OP_TIME, run_time) PAR(OP_METRO, run_metro) PAR(OP_RAND, run_rand) PAR(OP_Z, run_z)
-        PAR(OP_TAPIN, run_tapin) PAR(OP_TAPOUT, run_tapout) PAR(OP_SDELAY, run_sdelay) PAR(OP_DELAY, run_delay)
-        case OP_CONST: case OP_SR:   // materialised only when a consumer needs a real buffer
-            for_members(c, members, t, [&](const Member& m) {
-                const float v = u2f(c.recs[m.rec * kRecDwords + rec::P0]);
-                for (uint32_t i = s0 + c.lane; i < s1; i += 64) put(c, m, i, v);
-            });
-            break;
-        default: run_stateful(c, members, t); break;
+        PAR(OP_TIME, run_time) PAR(OP_METRO, run_metro) PAR(OP_TAPIN, run_tapin) PAR(OP_TAPOUT, run_tapout)
+        PAR(OP_CONST, run_fill) PAR(OP_SR, run_fill)
+        case OP_SVF_COEF:   for_members(c, t, [&](const Member& m) { run_svf_coef<false, V>(c, m, i, nlim); }); break;
+        case OP_SHELF_COEF: for_members(c, t, [&](const Member& m) { run_svf_coef<true, V>(c, m, i, nlim); }); break;
+        default: break;
     }
 #undef PAR
 #undef UN
@@ -950,10 +1219,39 @@ __device__ void run_task(const Ctx& c, const Member* members, const Task& t) {
 #undef RE
 }
 
+__device__ __forceinline__ void run_task(const Ctx& c, const TaskU& t, uint32_t lo, uint32_t hi) {
+    switch (t.opcode) {
+        // whole-block, single-wave ops with their own state handling
+        case OP_RAND:   for_members(c, t, [&](const Member& m) { run_rand(c, m, 0, c.n); }); return;
+        case OP_Z:      for_members(c, t, [&](const Member& m) { run_z(c, m, 0, c.n); }); return;
+        case OP_SDELAY: for_members(c, t, [&](const Member& m) { run_sdelay(c, m, 0, c.n); }); return;
+        case OP_DELAY:  for_members(c, t, [&](const Member& m) { run_delay(c, m, 0, c.n); }); return;
+        case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_ONCE:
+        case OP_SEQ: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF: case OP_SVFSHELF:
+        case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
+            run_stateful(c, t);
+            return;
+        default: break;
+    }
+    // sample-parallel: frames [s0, s1) of this workgroup's slice, 64*V of them
+    const uint32_t s0 = max(t.s0, lo), s1 = min(t.s1, hi);
+    if (s0 >= s1 || s0 >= c.n) return;
+    const uint32_t V = (s1 - s0) >> 6;
+    const uint32_t nlim = min(s1, c.n);
+    const uint32_t i = s0 + c.lane * V;
+    switch (V) {
+        case 1: run_par<1>(c, t, i, nlim); break;
+        case 2: run_par<2>(c, t, i, nlim); break;
+        case 4: run_par<4>(c, t, i, nlim); break;
+        case 8: run_par<8>(c, t, i, nlim); break;
+        default: break;   // the planner only emits 64, 128, 256 or 512-frame ranges
+    }
+}
+
 // RootNode::stillRunning (Core.h:28-31) and the channel test of RootRenderSequence::process
 // (GraphRenderSequence.h:214-219)
-__device__ __forceinline__ bool root_running(const uint32_t* recs, uint32_t rootRec, uint32_t numOut) {
-    const uint32_t* r = recs + rootRec * kRecDwords;
+__device__ __forceinline__ bool root_running(gcup recs, uint32_t rootRec, uint32_t numOut) {
+    gcup r = recs + rootRec * kRecDwords;
     const float tg = u2f(r[rec::ROOT_TARGET]), g = u2f(r[rec::ROOT_GAIN]);
     const bool on = tg > 0.5f;
     const bool settled = fabsf(tg - g) <= 1e-6f;
@@ -967,64 +1265,93 @@ __device__ __forceinline__ bool root_running(const uint32_t* recs, uint32_t root
 __global__ __launch_bounds__(kThreads)
 void elemhip_island_kernel(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, const uint32_t* lcg,
                            uint32_t levelBegin) {
-    const Island isl = pv.islands[pv.levelIslands[levelBegin + blockIdx.x]];
-    if (!root_running(recs, isl.rootRec, g->numOut)) return;
+    const uint32_t entry = pv.levelIslands[levelBegin + blockIdx.x];
+    const Island isl = pv.islands[entry & 0xFFFFFFu];
+    const uint32_t splitIdx = entry >> 24;
+    const uint32_t numOut = g->numOut;
+    if (!root_running((gcup)recs, isl.rootRec, numOut)) return;
 
-    Ctx c;
-    c.recs = recs; c.hbm = hbm; c.g = g; c.operands = pv.operands; c.lcg = lcg;
-    c.n = g->numSamples; c.stride = g->blockStride; c.numIn = g->numIn;
-    c.lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-
-    // LDS word 0 (and 1) read as 0.0f; broadcast cells take their node's current value
-    if (threadIdx.x < 2) lds[threadIdx.x] = 0.0f;
-    for (uint32_t k = isl.constBegin + threadIdx.x; k < isl.constEnd; k += kThreads) {
-        const ConstCell cc = pv.constCells[k];
-        lds[cc.ldsWord] = u2f(recs[cc.rec * kRecDwords + rec::P0]);
+    // stage the island program in LDS (one coalesced copy), then fill the broadcast cells
+    uint32_t* progLds = reinterpret_cast<uint32_t*>(lds + isl.ldsProg);
+    gcup prog = (gcup)(pv.prog + isl.progBegin);
+    for (uint32_t k = threadIdx.x; k < isl.progDwords; k += kThreads) progLds[k] = prog[k];
+    if (threadIdx.x < kSlot0) lds[threadIdx.x] = 0.0f;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < isl.numCells; k += kThreads) {
+        const uint32_t word = progLds[isl.cellOff + 2 * k], rec_ = progLds[isl.cellOff + 2 * k + 1];
+        lds[word] = u2f(((gcup)recs)[rec_ * kRecDwords + rec::P0]);
     }
     __syncthreads();
 
+    Ctx c;
+    c.recs = (gup)recs; c.hbm = (gfp)hbm; c.g = g; c.lcg = (gcup)lcg;
+    c.members = isl.ldsProg + isl.memOff; c.operands = isl.ldsProg + isl.opndOff;
+    c.n = g->numSamples; c.stride = g->blockStride; c.numIn = g->numIn;
+    c.lane = threadIdx.x & 63u;
+    c.srF = g->sampleRateF; c.sr = g->sampleRate;
+    const uint32_t wave = UNI(threadIdx.x >> 6);
+    // frames this workgroup renders (whole block unless the island is split)
+    const uint32_t lo = isl.split > 1 ? (splitIdx * c.stride) / isl.split : 0u;
+    const uint32_t hi = isl.split > 1 ? ((splitIdx + 1) * c.stride) / isl.split : 0xFFFFu;
+
     uint32_t stage = 0;
-    for (uint32_t ti = isl.taskBegin; ti < isl.taskEnd; ++ti) {
-        const Task t = pv.tasks[ti];
+    const uint32_t tb = wave == 0 ? isl.waveTask[0] : wave == 1 ? isl.waveTask[1] : wave == 2 ? isl.waveTask[2] : isl.waveTask[3];
+    const uint32_t te = wave == 0 ? isl.waveTask[1] : wave == 1 ? isl.waveTask[2] : wave == 2 ? isl.waveTask[3] : isl.waveTask[4];
+    for (uint32_t ti = tb; ti < te; ++ti) {
+        const v4u h = lds4u(isl.ldsProg + ti * 4u);
+        const uint32_t d0 = UNI(h.x), d1 = UNI(h.y);
+        TaskU t;
+        t.opcode = d0 & 0xFFFFu; t.stage = (d0 >> 16) & 0xFFu; t.flags = d0 >> 24;
+        t.s0 = d1 & 0xFFFFu; t.s1 = d1 >> 16;
+        t.first = UNI(h.z); t.count = UNI(h.w);
         while (stage < t.stage) { __syncthreads(); ++stage; }
-        if (t.wave == wave) run_task(c, pv.members, t);
+        run_task(c, t, lo, hi);
     }
+    while (stage + 1 < isl.numStages) { __syncthreads(); ++stage; }
 }
 
 // Epilogue: one workgroup. (1) zero + sum running roots into the output bus in render-sequence
 // order (GraphRenderSequence.h:286-295, 227-231); (2) promote tap buffers of active roots
 // (:306-308, Feedback.h:90-109); (3) advance root fades (GainFade.h:70-71); (4) advance the block.
 __global__ __launch_bounds__(1024)
-void elemhip_epilogue_kernel(PlanView pv, uint32_t* recs, const float* hbm, Globals* g, float* outRing) {
+void elemhip_epilogue_kernel(PlanView pv, uint32_t* recs_, const float* hbm_, Globals* g, float* outRing) {
+    gup recs = (gup)recs_; gcfp hbm = (gcfp)hbm_;
+    __shared__ int rootChan[1024];   // channel of root r if it ran this block, else -1
     const uint32_t n = g->numSamples, numOut = g->numOut, stride = g->blockStride;
-    float* out = outRing + (size_t)g->blockSlot * numOut * stride;
+    gfp out = (gfp)(outRing + (size_t)g->blockSlot * numOut * stride);
+    const uint32_t nr = min(pv.numRoots, 1024u);
+    for (uint32_t r = threadIdx.x; r < nr; r += blockDim.x) {
+        const uint32_t rr = pv.roots[r].rec;
+        rootChan[r] = root_running(recs, rr, numOut) ? (int)recs[rr * kRecDwords + rec::ROOT_CHANNEL] : -1;
+    }
+    __syncthreads();
     for (uint32_t idx = threadIdx.x; idx < numOut * n; idx += blockDim.x) {
         const uint32_t ch = idx / n, i = idx - ch * n;
         float acc = 0.0f;
-        for (uint32_t r = 0; r < pv.numRoots; ++r) {
+        for (uint32_t r = 0; r < nr; ++r)
+            if (rootChan[r] == (int)ch) acc += hbm[(size_t)pv.roots[r].hbm * stride + i];
+        for (uint32_t r = nr; r < pv.numRoots; ++r) {   // > 1024 roots: slow path
             const RootEntry re = pv.roots[r];
-            if (!root_running(recs, re.rec, numOut)) continue;
-            if (recs[re.rec * kRecDwords + rec::ROOT_CHANNEL] != ch) continue;
-            acc += hbm[(size_t)re.hbm * stride + i];
+            if (root_running(recs, re.rec, numOut) && recs[re.rec * kRecDwords + rec::ROOT_CHANNEL] == ch)
+                acc += hbm[(size_t)re.hbm * stride + i];
         }
         out[(size_t)ch * stride + i] = acc;
     }
     for (uint32_t k = 0; k < pv.numTaps; ++k) {
         const TapEntry te = pv.taps[k];
-        const uint32_t* rr = recs + te.rootRec * kRecDwords;
-        // only sequences that ran this block hold fresh tap data; promotion needs root.active()
+        gcup rr = recs + te.rootRec * kRecDwords;
+        // promotion needs root.active() (GraphRenderSequence.h:200-210)
         if (!(u2f(rr[rec::ROOT_TARGET]) > 0.5f)) continue;
-        const uint32_t* tr = recs + te.rec * kRecDwords;
-        float* shared = rec_ptr(tr, rec::TAP_SHARED);
-        const float* priv = rec_ptr(tr, rec::TAP_PRIVATE);
+        gcup tr = recs + te.rec * kRecDwords;
+        gfp shared = rec_ptr(tr, rec::TAP_SHARED);
+        gcfp priv = rec_ptr(tr, rec::TAP_PRIVATE);
         if (!shared || !priv) continue;
         __syncthreads();   // earlier promotions into the same name complete first (last writer wins)
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) shared[i] = priv[i];
     }
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < pv.numRoots; r += blockDim.x) {
-        uint32_t* rr = recs + pv.roots[r].rec * kRecDwords;
+        gup rr = recs + pv.roots[r].rec * kRecDwords;
         if (!root_running(recs, pv.roots[r].rec, numOut)) continue;
         const float gcur = u2f(rr[rec::ROOT_GAIN]), tg = u2f(rr[rec::ROOT_TARGET]), step = u2f(rr[rec::ROOT_STEP]);
         if (gcur != tg && (rr[rec::ROOT_HASIN] || g->numIn > 0) /* fade.process ran (Core.h:74-77) */)

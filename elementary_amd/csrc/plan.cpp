@@ -40,8 +40,8 @@ Kind kindOf(uint16_t op) {
 
 uint32_t scratchSlots(uint16_t op) {
     switch (op) {
-        case OP_SVF: case OP_SVFSHELF: return 6;   // a1,a2,a3 as double
-        case OP_MM1P: return 2;                     // G as double
+        case OP_SVF: return 6;        // a1,a2,a3 as double (coefficient pre-pass -> scan)
+        case OP_SVFSHELF: return 10;  // a1,a2,a3,k,A
         case OP_DELAY: return 1;
         default: return 0;
     }
@@ -70,6 +70,7 @@ struct NI {                      // per-node planning info
     Kind kind = K_PAR;
     int island = -1;
     int level = 0;               // stage inside the island
+    int sub = 0;                 // depth inside a fused run of sample-parallel ops of one stage
     bool needLds = false;
     bool exported = false;
     uint32_t lds = kNone;        // LDS word offset of the output slot
@@ -173,8 +174,9 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
     UF uf;
     std::vector<uint32_t> weight;            // per island representative
     std::vector<std::set<int>> succ;         // island DAG (by representative at insertion time)
+    std::vector<int> ilevel;                 // running estimate of each island's launch level
     auto rep = [&](int i) { return uf.find(i); };
-    auto newIsland = [&]() { int i = uf.add(); weight.push_back(0); succ.emplace_back(); return i; };
+    auto newIsland = [&]() { int i = uf.add(); weight.push_back(0); succ.emplace_back(); ilevel.push_back(0); return i; };
 
     auto reaches = [&](const std::vector<int>& from, const std::set<int>& targets, const std::set<int>& skip) {
         // is any island of `targets` reachable from `from` without starting inside `skip`?
@@ -217,6 +219,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
                         int a = rep(target), b = rep(dv[j]);
                         if (a == b) continue;
                         uf.p[b] = a;
+                        ilevel[a] = std::max(ilevel[a], ilevel[b]);
                         weight[a] += weight[b];
                         succ[a].insert(succ[b].begin(), succ[b].end());
                         target = a;
@@ -226,18 +229,29 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
             }
             if (target < 0) {
                 // join the single producer island that none of the others is downstream of
+                // (and only if that does not push the island to a later launch level: a mixer fed
+                // by many peer islands gets its own island instead of stalling one of its peers)
                 int best = -1;
                 for (int d : dv) {
                     if (weight[d] + w > maxIslandNodes) continue;
                     std::set<int> others(deps); others.erase(d);
                     for (int f : foreign) others.insert(f);
+                    bool raises = false;
+                    for (int o : others) if (ilevel[o] >= ilevel[d]) { raises = true; break; }
+                    if (raises) continue;
                     if (!others.empty() && reaches({d}, others, {})) continue;
                     if (best < 0 || weight[d] > weight[best]) best = d;
                 }
                 target = best;
             }
         }
-        if (target < 0) target = newIsland();
+        if (target < 0) {
+            target = newIsland();
+            for (int d : deps) ilevel[target] = std::max(ilevel[target], ilevel[rep(d)] + 1);
+            for (int f : foreign) ilevel[target] = std::max(ilevel[target], ilevel[rep(f)] + 1);
+        } else {
+            for (int f : foreign) ilevel[target] = std::max(ilevel[target], ilevel[rep(f)] + 1);
+        }
         x.island = target;
         weight[target] += w;
         for (int d : deps) if (rep(d) != target) succ[rep(d)].insert(target);
@@ -340,13 +354,24 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
         int maxStage = 0;
         for (int k : B.nodes) {
             NI& x = ni[k];
-            int lv = base;
+            int lv = base, sub = 0;
             for (auto& in : x.n->inlets) {
                 auto it = idx.find(in.source);
                 if (it == idx.end() || in.channel != 0) continue;
                 NI& s = ni[it->second];
-                if (s.kind != K_CONST && s.island == x.island) lv = std::max(lv, s.level + 1);
+                if (s.kind == K_CONST || s.island != x.island) continue;
+                // Sample-parallel ops are lane-local (lane l reads and writes only samples l + 64j of
+                // its slice), so a sample-parallel consumer of a sample-parallel producer can run in
+                // the SAME stage on the same wave, right after it, with no barrier in between.
+                const bool xsvf = x.n->op == OP_SVF || x.n->op == OP_SVFSHELF;   // its coefficient pre-pass is such an op too
+                const bool fuse = (x.kind == K_PAR || xsvf) && s.kind == K_PAR;
+                const int need = fuse ? s.level : s.level + 1;
+                if (need > lv) { lv = need; sub = 0; }
+                if (fuse && s.level == lv) sub = std::max(sub, s.sub + 1);
             }
+            x.sub = sub;
+            // svf / shelf take two stages: sample-parallel coefficient pre-pass, then the scan
+            if (x.n->op == OP_SVF || x.n->op == OP_SVFSHELF) lv += 1;
             x.level = lv;
             x.lastUse = lv;
             maxStage = std::max(maxStage, lv);
@@ -368,7 +393,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
             }
         }
 
-        // LDS slots by liveness. Word 0/1 = zero cell; slots start at word 2.
+        // LDS slots by liveness. Words 0..3 = zero cell; slots start at word kSlot0.
         std::vector<int> slotFreeAt;   // stage from which the slot is free again
         auto takeSlots = [&](int stage, uint32_t count, int lastUse) -> uint32_t {
             // `count` consecutive slots free at `stage`
@@ -376,43 +401,53 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
             for (size_t s0 = 0; s0 + count <= S; ++s0) {
                 bool ok = true;
                 for (uint32_t c = 0; c < count; ++c) if (slotFreeAt[s0 + c] > stage) { ok = false; break; }
-                if (ok) { for (uint32_t c = 0; c < count; ++c) slotFreeAt[s0 + c] = lastUse + 1; return 2u + (uint32_t)s0 * kSlotWords; }
+                if (ok) { for (uint32_t c = 0; c < count; ++c) slotFreeAt[s0 + c] = lastUse + 1; return kSlot0 + (uint32_t)s0 * kSlotWords; }
             }
             // extend (reuse a free tail if there is one)
             size_t s0 = S;
             while (s0 > 0 && slotFreeAt[s0 - 1] <= stage && S - (s0 - 1) <= count) --s0;
             slotFreeAt.resize(s0 + count, 0);
             for (uint32_t c = 0; c < count; ++c) slotFreeAt[s0 + c] = lastUse + 1;
-            return 2u + (uint32_t)s0 * kSlotWords;
+            return kSlot0 + (uint32_t)s0 * kSlotWords;
         };
         for (auto& im : imports) im.lds = takeSlots(0, 1, im.lastUse);
         for (int stage = base; stage <= maxStage; ++stage) {
+            for (int k : B.nodes) {   // coefficient scratch of the svf's that scan in the NEXT stage
+                NI& x = ni[k];
+                if (x.level != stage + 1 || (x.n->op != OP_SVF && x.n->op != OP_SVFSHELF)) continue;
+                x.scratch = takeSlots(stage, scratchSlots(x.n->op), stage + 1);
+            }
             for (int k : B.nodes) {
                 NI& x = ni[k];
                 if (x.level != stage) continue;
                 if (x.needLds) x.lds = takeSlots(stage, 1, x.lastUse);
                 const uint32_t sc = scratchSlots(x.n->op);
-                if (sc) x.scratch = takeSlots(stage, sc, stage);
+                if (sc && x.n->op != OP_SVF && x.n->op != OP_SVFSHELF) x.scratch = takeSlots(stage, sc, stage);
             }
         }
-        const uint32_t slotWords = 2u + (uint32_t)slotFreeAt.size() * kSlotWords;
+        const uint32_t slotWords = kSlot0 + (uint32_t)slotFreeAt.size() * kSlotWords;
 
+        // island-local program tables
+        std::vector<Task> tasks;
+        std::vector<int> taskWave;               // executing wave of tasks[i]
+        std::vector<Member> members;
+        std::vector<uint32_t> operands;
+        std::vector<ConstCell> cells;
         // broadcast cells for const-like producers
-        I.constBegin = (uint32_t)p.constCells.size();
         std::unordered_map<uint32_t, uint32_t> cellOf;   // rec -> lds word
         auto cellFor = [&](Node* c) -> uint32_t {
             auto it = cellOf.find(c->rec);
             if (it != cellOf.end()) return it->second;
             const uint32_t word = slotWords + (uint32_t)cellOf.size();
             cellOf.emplace(c->rec, word);
-            p.constCells.push_back(ConstCell{word, c->rec});
+            cells.push_back(ConstCell{word, c->rec});
             return word;
         };
 
         auto makeMember = [&](NI& x) -> Member {
             Member m{};
             m.rec = x.n->rec;
-            m.opnd = (uint32_t)p.operands.size();
+            m.opnd = (uint32_t)operands.size();
             m.outLds = x.needLds ? x.lds : kNone;
             m.outHbm = x.exported ? x.hbm : kNone;
             m.scratch = x.scratch;
@@ -420,104 +455,166 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
                 m.nin = kNone;
                 const uint32_t ar = std::min<uint32_t>(leafArity(x.n->op), kMaxHostIn);
                 for (uint32_t c = 0; c < ar; ++c) {
-                    if (x.kind == K_CHAIN) p.operands.push_back(kOpLds | imports[importFor(c)].lds);
-                    else p.operands.push_back(kOpHbm | c);
+                    if (x.kind == K_CHAIN) operands.push_back(kOpLds | imports[importFor(c)].lds);
+                    else operands.push_back(kOpHbm | c);
                 }
                 return m;
             }
             m.nin = (uint32_t)x.n->inlets.size();
             for (auto& in : x.n->inlets) {
                 auto it = idx.find(in.source);
-                if (it == idx.end() || in.channel != 0) { p.operands.push_back(kOpZero); continue; }
+                if (it == idx.end() || in.channel != 0) { operands.push_back(kOpZero); continue; }
                 NI& s = ni[it->second];
-                if (s.kind == K_CONST) p.operands.push_back(kOpConst | cellFor(s.n));
-                else if (s.island == x.island) p.operands.push_back(kOpLds | s.lds);
-                else if (x.kind == K_CHAIN) p.operands.push_back(kOpLds | imports[importFor(s.hbm)].lds);
-                else p.operands.push_back(kOpHbm | s.hbm);
+                if (s.kind == K_CONST) operands.push_back(kOpConst | cellFor(s.n));
+                else if (s.island == x.island) operands.push_back(kOpLds | s.lds);
+                else if (x.kind == K_CHAIN) operands.push_back(kOpLds | imports[importFor(s.hbm)].lds);
+                else operands.push_back(kOpHbm | s.hbm);
             }
             return m;
         };
 
         // ---- tasks, stage by stage ----
-        I.taskBegin = (uint32_t)p.tasks.size();
+        // A sample-parallel task covers 64*V frames with V in {1,2,4,8} (lane l owns V consecutive
+        // frames). The block is cut into 64-frame units handed out as power-of-two runs.
         auto emitRanges = [&](uint16_t op, int stage, uint32_t first, uint32_t count, const std::vector<int>& waves) {
-            const uint32_t f = (uint32_t)waves.size();
-            const uint32_t chunk = ((bs + f - 1) / f + 63) / 64 * 64;
-            for (uint32_t w = 0; w < f; ++w) {
-                const uint32_t s0 = std::min(bs, w * chunk), s1 = std::min(bs, (w + 1) * chunk);
-                if (s0 >= s1) continue;
-                p.tasks.push_back(Task{op, (uint8_t)stage, (uint8_t)waves[w], (uint16_t)s0, (uint16_t)s1, first, count});
+            const uint32_t units = (bs + 63) / 64;                      // 64-frame units (8 for a 512 block)
+            std::vector<std::pair<uint32_t, uint32_t>> runs;            // (first unit, units)
+            if (units == 8 && waves.size() == 3) runs = {{0, 4}, {4, 2}, {6, 2}};
+            else {
+                uint32_t f = 1;
+                while (f * 2 <= waves.size() && f * 2 <= units) f *= 2; // power-of-two wave count
+                uint32_t per = (units + f - 1) / f, p2 = 1;
+                while (p2 < per) p2 *= 2;                               // units per wave, power of two
+                for (uint32_t u = 0; u < units; u += p2) runs.push_back({u, std::min(p2, units - u)});
+            }
+            for (size_t w = 0; w < runs.size(); ++w) {
+                uint32_t u0 = runs[w].first, un = runs[w].second;
+                // a non power-of-two tail (block sizes that are not 64 * 2^k) is cut further
+                while (un) {
+                    uint32_t take = 1; while (take * 2 <= un && take * 2 <= 8) take *= 2;
+                    tasks.push_back(Task{op, (uint8_t)stage, 0, (uint16_t)(u0 * 64), (uint16_t)((u0 + take) * 64), first, count});
+                    taskWave.push_back(waves[w % waves.size()]);
+                    u0 += take; un -= take;
+                }
             }
         };
         if (!imports.empty()) {
-            const uint32_t first = (uint32_t)p.members.size();
+            const uint32_t first = (uint32_t)members.size();
             for (auto& im : imports) {
                 Member m{};
-                m.rec = 0; m.opnd = (uint32_t)p.operands.size(); m.nin = 1; m.outLds = im.lds; m.outHbm = kNone; m.scratch = kNone;
-                p.operands.push_back(kOpHbm | im.hbm);
-                p.members.push_back(m);
+                m.rec = 0; m.opnd = (uint32_t)operands.size(); m.nin = 1; m.outLds = im.lds; m.outHbm = kNone; m.scratch = kNone;
+                operands.push_back(kOpHbm | im.hbm);
+                members.push_back(m);
             }
             emitRanges(OP_COPY, 0, first, (uint32_t)imports.size(), {0, 1, 2, 3});
         }
         for (int stage = base; stage <= maxStage; ++stage) {
-            std::map<uint16_t, std::vector<int>> chain, single, par;
+            std::map<uint32_t, std::vector<int>> chain;   // key: opcode | constMask << 16
+            std::map<uint16_t, std::vector<int>> single;
+            std::map<std::pair<int, uint16_t>, std::vector<int>> par;   // (fusion depth, opcode): emitted in dependency order
+            auto constMaskOf = [&](NI& x) -> uint32_t {
+                uint32_t mask = 0;
+                for (size_t q = 0; q < x.n->inlets.size() && q < 8; ++q) {
+                    auto it = idx.find(x.n->inlets[q].source);
+                    if (it == idx.end() || x.n->inlets[q].channel != 0) { mask |= 1u << q; continue; }   // zero operand
+                    if (ni[it->second].kind == K_CONST) mask |= 1u << q;
+                }
+                return mask;
+            };
             for (int k : B.nodes) {
                 NI& x = ni[k];
+                if (x.level == stage + 1 && x.n->op == OP_SVF) par[{1 << 20, OP_SVF_COEF}].push_back(k);
+                if (x.level == stage + 1 && x.n->op == OP_SVFSHELF) par[{1 << 20, OP_SHELF_COEF}].push_back(k);
                 if (x.level != stage) continue;
-                if (x.kind == K_CHAIN) chain[x.n->op].push_back(k);
+                if (x.kind == K_CHAIN) chain[(uint32_t)x.n->op | (constMaskOf(x) << 16)].push_back(k);
                 else if (x.kind == K_SINGLE) single[x.n->op].push_back(k);
-                else par[x.n->op].push_back(k);
+                else par[{x.sub, x.n->op}].push_back(k);
             }
             uint32_t load[kWaves] = {0, 0, 0, 0};
             auto leastLoaded = [&]() { int b = 0; for (int w = 1; w < (int)kWaves; ++w) if (load[w] < load[b]) b = w; return b; };
             for (auto& kv : chain) {
                 for (size_t off = 0; off < kv.second.size(); off += 64) {
                     const uint32_t cnt = (uint32_t)std::min<size_t>(64, kv.second.size() - off);
-                    const uint32_t first = (uint32_t)p.members.size();
-                    for (uint32_t c = 0; c < cnt; ++c) p.members.push_back(makeMember(ni[kv.second[off + c]]));
+                    const uint32_t first = (uint32_t)members.size();
+                    for (uint32_t c = 0; c < cnt; ++c) members.push_back(makeMember(ni[kv.second[off + c]]));
                     const int w = leastLoaded();
                     load[w] += 1000;
-                    p.tasks.push_back(Task{kv.first, (uint8_t)stage, (uint8_t)w, 0, (uint16_t)bs, first, cnt});
+                    tasks.push_back(Task{(uint16_t)(kv.first & 0xFFFFu), (uint8_t)stage, (uint8_t)(kv.first >> 16), 0, (uint16_t)bs, first, cnt});
+                    taskWave.push_back(w);
                 }
             }
             for (auto& kv : single) {
                 for (int k : kv.second) {
-                    const uint32_t first = (uint32_t)p.members.size();
-                    p.members.push_back(makeMember(ni[k]));
+                    const uint32_t first = (uint32_t)members.size();
+                    members.push_back(makeMember(ni[k]));
                     const int w = leastLoaded();
                     load[w] += 100;
-                    p.tasks.push_back(Task{kv.first, (uint8_t)stage, (uint8_t)w, 0, (uint16_t)bs, first, 1});
+                    tasks.push_back(Task{kv.first, (uint8_t)stage, 0, 0, (uint16_t)bs, first, 1});
+                    taskWave.push_back(w);
                 }
             }
             std::vector<int> freeWaves;
             for (int w = 0; w < (int)kWaves; ++w) if (load[w] == 0) freeWaves.push_back(w);
             if (freeWaves.empty()) freeWaves.push_back(leastLoaded());
             for (auto& kv : par) {
-                const uint32_t first = (uint32_t)p.members.size();
-                for (int k : kv.second) p.members.push_back(makeMember(ni[k]));
-                emitRanges(kv.first, stage, first, (uint32_t)kv.second.size(), freeWaves);
+                const uint32_t first = (uint32_t)members.size();
+                for (int k : kv.second) members.push_back(makeMember(ni[k]));
+                emitRanges(kv.first.second, stage, first, (uint32_t)kv.second.size(), freeWaves);
             }
         }
-        I.taskEnd = (uint32_t)p.tasks.size();
-        std::stable_sort(p.tasks.begin() + I.taskBegin, p.tasks.begin() + I.taskEnd,
-                         [](const Task& a, const Task& b) { return a.stage != b.stage ? a.stage < b.stage : a.wave < b.wave; });
-        I.constEnd = (uint32_t)p.constCells.size();
+        {   // per-wave task lists: sort by (wave, stage), keep emission order inside a (wave, stage)
+            std::vector<size_t> order(tasks.size());
+            std::iota(order.begin(), order.end(), (size_t)0);
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+                return taskWave[a] != taskWave[b] ? taskWave[a] < taskWave[b] : tasks[a].stage < tasks[b].stage; });
+            std::vector<Task> sorted; sorted.reserve(tasks.size());
+            for (uint32_t w = 0; w <= kWaves; ++w) I.waveTask[w] = 0;
+            for (size_t q : order) { sorted.push_back(tasks[q]); I.waveTask[taskWave[q] + 1]++; }
+            for (uint32_t w = 0; w < kWaves; ++w) I.waveTask[w + 1] += I.waveTask[w];
+            tasks.swap(sorted);
+        }
+        // a pure sample-parallel island that streams many HBM buffers (a mixer) runs as several
+        // workgroups, each rendering a slice of the block
+        {
+            bool pure = true;
+            size_t hbmReads = 0;
+            for (int k : B.nodes) if (ni[k].kind != K_PAR) pure = false;
+            for (uint32_t o : operands) if ((o & kOpKindMask) == kOpHbm) hbmReads++;
+            I.split = (pure && imports.empty() && hbmReads >= 8 && bs >= 128) ? std::min<uint32_t>(8, bs / 64) : 1;
+        }
+        // pack the blob: [tasks | members | operands | cells]
+        static_assert(sizeof(Task) == 16 && sizeof(Member) == 32 && sizeof(ConstCell) == 8, "program layout");
+        I.progBegin = (uint32_t)p.prog.size();
+        I.numTasks = (uint32_t)tasks.size();
+        I.memOff = I.numTasks * 4u;
+        I.opndOff = I.memOff + (uint32_t)members.size() * 8u;
+        I.cellOff = I.opndOff + (uint32_t)operands.size();
+        I.numCells = (uint32_t)cells.size();
+        I.progDwords = I.cellOff + I.numCells * 2u;
+        p.prog.resize((size_t)I.progBegin + I.progDwords);
+        uint32_t* blob = p.prog.data() + I.progBegin;
+        if (!tasks.empty()) std::memcpy(blob, tasks.data(), tasks.size() * sizeof(Task));
+        if (!members.empty()) std::memcpy(blob + I.memOff, members.data(), members.size() * sizeof(Member));
+        if (!operands.empty()) std::memcpy(blob + I.opndOff, operands.data(), operands.size() * 4);
+        if (!cells.empty()) std::memcpy(blob + I.cellOff, cells.data(), cells.size() * sizeof(ConstCell));
+        while (p.prog.size() % 4) p.prog.push_back(0);   // keep every blob 16-byte aligned
         I.numStages = (uint32_t)maxStage + 1;
-        I.ldsWords = slotWords + (uint32_t)cellOf.size();
-        I.ldsWords = (I.ldsWords + 3u) & ~3u;
+        I.ldsProg = (slotWords + (uint32_t)cellOf.size() + 3u) & ~3u;
+        I.ldsWords = (I.ldsProg + I.progDwords + 3u) & ~3u;
         p.maxLdsBytes = std::max(p.maxLdsBytes, I.ldsWords * 4u);
+        p.numTasks += I.numTasks; p.numMembers += (uint32_t)members.size(); p.numOperands += (uint32_t)operands.size();
     }
 
     // ---- 5. launch levels, roots, taps ------------------------------------------------------------------
     p.levelOffsets.assign((size_t)numLevels + 1, 0);
     p.levelLdsBytes.assign((size_t)numLevels, 0);
-    for (auto& i : ib) p.levelOffsets[(size_t)i.level + 1]++;
+    for (size_t i = 0; i < ib.size(); ++i) p.levelOffsets[(size_t)ib[i].level + 1] += p.islands[i].split;
     for (int l = 0; l < numLevels; ++l) p.levelOffsets[(size_t)l + 1] += p.levelOffsets[l];
-    p.levelIslands.resize(ib.size());
+    p.levelIslands.resize(p.levelOffsets.back());
     {
         std::vector<uint32_t> cursor(p.levelOffsets.begin(), p.levelOffsets.end() - 1);
         for (size_t i = 0; i < ib.size(); ++i) {
-            p.levelIslands[cursor[ib[i].level]++] = (uint32_t)i;
+            for (uint32_t k = 0; k < p.islands[i].split; ++k) p.levelIslands[cursor[ib[i].level]++] = (uint32_t)i | (k << 24);
             p.levelLdsBytes[ib[i].level] = std::max(p.levelLdsBytes[ib[i].level], p.islands[i].ldsWords * 4u);
         }
     }
@@ -558,20 +655,14 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     auto place = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
     const size_t oIslands = place(p.islands.size() * sizeof(Island));
     const size_t oLevel = place(p.levelIslands.size() * 4);
-    const size_t oTasks = place(p.tasks.size() * sizeof(Task));
-    const size_t oMembers = place(p.members.size() * sizeof(Member));
-    const size_t oOperands = place(p.operands.size() * 4);
-    const size_t oCells = place(p.constCells.size() * sizeof(ConstCell));
+    const size_t oProg = place(p.prog.size() * 4);
     const size_t oRoots = place(p.roots.size() * sizeof(RootEntry));
     const size_t oTaps = place(p.taps.size() * sizeof(TapEntry));
     std::vector<uint8_t> host(std::max<size_t>(off, 16), 0);
     auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(host.data() + o, src, bytes); };
     put(oIslands, p.islands.data(), p.islands.size() * sizeof(Island));
     put(oLevel, p.levelIslands.data(), p.levelIslands.size() * 4);
-    put(oTasks, p.tasks.data(), p.tasks.size() * sizeof(Task));
-    put(oMembers, p.members.data(), p.members.size() * sizeof(Member));
-    put(oOperands, p.operands.data(), p.operands.size() * 4);
-    put(oCells, p.constCells.data(), p.constCells.size() * sizeof(ConstCell));
+    put(oProg, p.prog.data(), p.prog.size() * 4);
     put(oRoots, p.roots.data(), p.roots.size() * sizeof(RootEntry));
     put(oTaps, p.taps.data(), p.taps.size() * sizeof(TapEntry));
     if (dry) return plan;
@@ -581,10 +672,7 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     const uint8_t* d = static_cast<const uint8_t*>(p.dev.ptr);
     p.view.islands = reinterpret_cast<const Island*>(d + oIslands);
     p.view.levelIslands = reinterpret_cast<const uint32_t*>(d + oLevel);
-    p.view.tasks = reinterpret_cast<const Task*>(d + oTasks);
-    p.view.members = reinterpret_cast<const Member*>(d + oMembers);
-    p.view.operands = reinterpret_cast<const uint32_t*>(d + oOperands);
-    p.view.constCells = reinterpret_cast<const ConstCell*>(d + oCells);
+    p.view.prog = reinterpret_cast<const uint32_t*>(d + oProg);
     p.view.roots = reinterpret_cast<const RootEntry*>(d + oRoots);
     p.view.taps = reinterpret_cast<const TapEntry*>(d + oTaps);
     p.view.numRoots = (uint32_t)p.roots.size();
@@ -604,8 +692,8 @@ std::string Engine::describePlan() {
     const Plan& p = *current;
     std::string s = "{";
     auto kv = [&](const char* k, uint64_t v, bool comma = true) { s += "\"" + std::string(k) + "\":" + std::to_string(v) + (comma ? "," : ""); };
-    kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.tasks.size());
-    kv("num_members", p.members.size()); kv("num_operands", p.operands.size()); kv("num_nodes", p.nodeIds.size());
+    kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.numTasks);
+    kv("num_members", p.numMembers); kv("num_operands", p.numOperands); kv("num_nodes", p.nodeIds.size());
     kv("num_hbm_buffers", p.numHbmBuffers); kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());
     kv("num_taps", p.taps.size());
     s += "\"level_sizes\":[";
@@ -616,8 +704,9 @@ std::string Engine::describePlan() {
     for (size_t i = 0; i < p.islands.size(); ++i) {
         const Island& I = p.islands[i];
         if (i) s += ",";
-        s += "{\"tasks\":" + std::to_string(I.taskEnd - I.taskBegin) + ",\"stages\":" + std::to_string(I.numStages) +
-             ",\"lds_bytes\":" + std::to_string(I.ldsWords * 4) + ",\"consts\":" + std::to_string(I.constEnd - I.constBegin) + "}";
+        s += "{\"tasks\":" + std::to_string(I.numTasks) + ",\"stages\":" + std::to_string(I.numStages) +
+             ",\"lds_bytes\":" + std::to_string(I.ldsWords * 4) + ",\"consts\":" + std::to_string(I.numCells) +
+             ",\"prog_dwords\":" + std::to_string(I.progDwords) + "}";
         if (i >= 63) break;
     }
     s += "]}";

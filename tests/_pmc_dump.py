@@ -1,0 +1,4 @@
+import sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+q = "select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like '%island%' group by kernel_name, counter_name"
+for r in db.execute(q): print(r[1], round(r[2],1), r[3])
