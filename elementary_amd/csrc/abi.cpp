@@ -131,6 +131,11 @@ int elemhip_time_launches(elemhip_t* h, size_t nOut, size_t numBlocks, float* ms
     return h->engine.timeLaunches(nOut, numBlocks, msOut, cap);
 }
 
+int elemhip_trace_level(elemhip_t* h, size_t nOut, uint32_t level, unsigned long long* out, size_t cap) {
+    if (!h || !out) return elemhip::kInvalidInstructionFormat;
+    return h->engine.traceLevel(nOut, level, out, cap);
+}
+
 // Debug/test hook: JSON description of the current render plan. Returns bytes needed.
 size_t elemhip_describe_plan(elemhip_t* h, char* buf, size_t cap) {
     if (!h) return 0;

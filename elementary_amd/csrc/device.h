@@ -72,7 +72,9 @@ struct Member {
     uint32_t pad0_, pad1_;
 };
 
-// 4 dwords in the island program.
+// 8 dwords in the island program (two 16-byte LDS reads). The second half repeats what the
+// common single-member task needs from its member and operand tables, so decoding such a task
+// costs one LDS round trip instead of three.
 struct Task {
     uint16_t opcode;
     uint8_t  stage;      // barrier epoch inside the island
@@ -80,6 +82,10 @@ struct Task {
     uint16_t s0, s1;     // sample range [s0, s1) for sample-parallel tasks
     uint32_t first;      // first member (index into the island's member array)
     uint32_t count;      // members in this task
+    uint32_t o0, o1;     // member 0: first two operand codes (kOpZero when absent)
+    uint16_t outLds16;   // member 0: LDS output word (0xFFFF = none)
+    uint16_t nin16;      // member 0: operand count (0xFFFF = leaf / host inputs, 0xFFFE = too many: see member)
+    uint32_t outHbm;     // member 0: HBM arena buffer (kNone = none)
 };
 
 // An island's program is one contiguous dword blob  [tasks | members | operands | const cells]
@@ -131,6 +137,7 @@ struct Globals {
     float    sampleRateF;
     uint32_t pad_;
     double   sampleRate;
+    uint64_t trace;        // debug: device pointer to a per-task timestamp log for workgroup 0 of every launch, or 0
 };
 
 // Device view of a compiled plan (all pointers are device pointers).

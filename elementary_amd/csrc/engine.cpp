@@ -832,6 +832,46 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
     return (int)(L + 1);
 }
 
+int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, size_t cap) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (dry) return kNoDevice;
+    if (hipSetDevice(device) != hipSuccess) return kHipError;
+    int rc = swapInPending();
+    if (rc != kOk) return rc;
+    if (!current || cap < 4 * 192) return kInvalidPropertyValue;
+    const Plan& p = *current;
+    const size_t L = p.levelOffsets.size() - 1;
+    rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize);
+    if (rc != kOk) return rc;
+    unsigned long long* dTrace = nullptr;
+    HIP_OK(hipMalloc(&dTrace, 4 * 192 * 8));
+    HIP_OK(hipMemset(dTrace, 0, 4 * 192 * 8));
+    if (hGlobals.ringSlots != 1 || hGlobals.blockSlot != 0) {
+        hGlobals.ringSlots = 1; hGlobals.blockSlot = 0;
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, ringSlots) / 4), 1u, 0u});
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, blockSlot) / 4), 0u, 0u});
+    }
+    setGlobalsFor(0, nOut, (size_t)blockSize, hGlobals.sampleTime);
+    flushPending();
+    const uint64_t tp = (uint64_t)reinterpret_cast<uintptr_t>(dTrace);
+    for (size_t l = 0; l < L; ++l) {
+        const uint32_t lb = p.levelOffsets[l], le = p.levelOffsets[l + 1];
+        const uint64_t v = (l == level) ? tp : 0;
+        HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(dGlobals) + offsetof(Globals, trace), &v, 8, hipMemcpyHostToDevice, stream));
+        if (le > lb) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l]);
+    }
+    const uint64_t zero = 0;
+    HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(dGlobals) + offsetof(Globals, trace), &zero, 8, hipMemcpyHostToDevice, stream));
+    launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, dOutRing);
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(out, dTrace, 4 * 192 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dTrace);
+    mirrorRootFades(p, (uint32_t)blockSize, (uint32_t)nOut, 0);
+    hGlobals.sampleTime += blockSize;
+    st.blocksRendered++;
+    return kOk;
+}
+
 int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime) {
     std::lock_guard<std::mutex> lock(mu);
     if (dry) return kNoDevice;

@@ -98,6 +98,8 @@ public:
     // render `numBlocks` blocks with a HIP event pair around every kernel launch; msOut[l] = mean
     // duration of launch level l (l < numLevels), msOut[numLevels] = epilogue. Returns levels + 1.
     int timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap);
+    // debug: render one block of launch level `level` tracing workgroup 0; out = 4 waves x 192 u64
+    int traceLevel(size_t nOut, uint32_t level, unsigned long long* out, size_t cap);
 
     bool addSharedResource(const std::string& name, const float* const* ch, size_t nCh, size_t nSamples);
     void pruneSharedResources();

@@ -90,6 +90,8 @@ __device__ __forceinline__ Member member_uniform(const Ctx& c, uint32_t k) {   /
     Member m;
     m.rec = UNI(a.x); m.opnd = UNI(a.y); m.nin = UNI(a.z); m.outLds = UNI(a.w);
     m.outHbm = UNI(ldsu(w + 4)); m.scratch = UNI(ldsu(w + 5));
+    // pad0_/pad1_ carry the first two operand codes on the device
+    m.pad0_ = UNI(ldsu(c.operands + m.opnd)); m.pad1_ = UNI(ldsu(c.operands + m.opnd + 1));
     return m;
 }
 __device__ __forceinline__ Member member_lane(const Ctx& c, uint32_t k) {      // per-lane k
@@ -104,6 +106,8 @@ __device__ __forceinline__ uint32_t member_nin(const Ctx& c, const Member& m) {
     return m.nin == kNone ? c.numIn : m.nin;
 }
 __device__ __forceinline__ uint32_t opnd_uniform(const Ctx& c, const Member& m, uint32_t k) {
+    if (k == 0) return m.pad0_;      // decoded with the task header / member
+    if (k == 1) return m.pad1_;
     return UNI(ldsu(c.operands + m.opnd + k));
 }
 __device__ __forceinline__ uint32_t opnd_lane(const Ctx& c, const Member& m, uint32_t k) {
@@ -1092,12 +1096,30 @@ __device__ __forceinline__ void scan_mm1p(const Ctx& c, const Member& m) {
 }
 
 // ---- task dispatch ------------------------------------------------------------------------------
-struct TaskU { uint32_t opcode, stage, flags, s0, s1, first, count; };
+struct TaskU { uint32_t opcode, stage, flags, s0, s1, first, count, o0, o1, outLds, nin, outHbm; };
 
-template <typename F>
-__device__ __forceinline__ void for_members(const Ctx& c, const TaskU& t, F&& f) {
+// Visit the members of a task (wave-uniform). Sample-parallel math ops of a single-member task
+// (`lite`) take everything from the task header; other ops also need the member's record / scratch.
+template <bool Lite, typename F>
+__device__ __forceinline__ void for_members_x(const Ctx& c, const TaskU& t, F&& f) {
+    if (Lite && t.count == 1 && t.nin != 0xFFFEu) {
+        Member m;
+        m.rec = kNone; m.opnd = kNone; m.scratch = kNone;
+        m.nin = t.nin == 0xFFFFu ? (uint32_t)kNone : t.nin;
+        m.outLds = t.outLds == 0xFFFFu ? (uint32_t)kNone : t.outLds;
+        m.outHbm = t.outHbm; m.pad0_ = t.o0; m.pad1_ = t.o1;
+        if (m.nin > 2u && m.nin != kNone) {   // operands beyond the inlined two live in the table
+            m.opnd = UNI(ldsu(c.members + t.first * 8u + 1u));
+        } else if (m.nin == kNone) {
+            m.opnd = UNI(ldsu(c.members + t.first * 8u + 1u));
+        }
+        f(m);
+        return;
+    }
     for (uint32_t k = 0; k < t.count; ++k) { const Member m = member_uniform(c, t.first + k); f(m); }
 }
+template <typename F>
+__device__ __forceinline__ void for_members(const Ctx& c, const TaskU& t, F&& f) { for_members_x<false>(c, t, f); }
 
 // Stateful task: whole-wave scans for the double-state filters; otherwise a sample-parallel
 // pre-pass over all members, the lane-per-member chain, and a sample-parallel post-pass.
@@ -1198,9 +1220,9 @@ __device__ __forceinline__ void run_stateful(const Ctx& c, const TaskU& t) {
 template <int V>
 __device__ __forceinline__ void run_par(const Ctx& c, const TaskU& t, uint32_t i, uint32_t nlim) {
 #define PAR(OPC, FN) case OPC: for_members(c, t, [&](const Member& m) { FN<V>(c, m, i, nlim); }); break;
-#define UN(OPC)  case OPC: for_members(c, t, [&](const Member& m) { run_unary<OPC, V>(c, m, i, nlim); }); break;
-#define BI(OPC)  case OPC: for_members(c, t, [&](const Member& m) { run_binary<OPC, V>(c, m, i, nlim); }); break;
-#define RE(OPC)  case OPC: for_members(c, t, [&](const Member& m) { run_reduce<OPC, V>(c, m, i, nlim); }); break;
+#define UN(OPC)  case OPC: for_members_x<true>(c, t, [&](const Member& m) { run_unary<OPC, V>(c, m, i, nlim); }); break;
+#define BI(OPC)  case OPC: for_members_x<true>(c, t, [&](const Member& m) { run_binary<OPC, V>(c, m, i, nlim); }); break;
+#define RE(OPC)  case OPC: for_members_x<true>(c, t, [&](const Member& m) { run_reduce<OPC, V>(c, m, i, nlim); }); break;
     switch (t.opcode) {
         UN(OP_SIN) UN(OP_COS) UN(OP_TAN) UN(OP_TANH) UN(OP_ASINH) UN(OP_LN) UN(OP_LOG) UN(OP_LOG2)
         UN(OP_CEIL) UN(OP_FLOOR) UN(OP_ROUND) UN(OP_SQRT) UN(OP_EXP) UN(OP_ABS)
@@ -1242,7 +1264,7 @@ __device__ __forceinline__ void run_task(const Ctx& c, const TaskU& t, uint32_t 
     switch (V) {
         case 1: run_par<1>(c, t, i, nlim); break;
         case 2: run_par<2>(c, t, i, nlim); break;
-        case 4: run_par<4>(c, t, i, nlim); break;
+        case 4: run_par<2>(c, t, i, nlim); run_par<2>(c, t, i + 2, nlim); break;   // same lane, same 4 frames
         case 8: run_par<8>(c, t, i, nlim); break;
         default: break;   // the planner only emits 64, 128, 256 or 512-frame ranges
     }
@@ -1265,6 +1287,7 @@ __device__ __forceinline__ bool root_running(gcup recs, uint32_t rootRec, uint32
 __global__ __launch_bounds__(kThreads)
 void elemhip_island_kernel(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, const uint32_t* lcg,
                            uint32_t levelBegin) {
+    const uint64_t tStart = clock64();
     const uint32_t entry = pv.levelIslands[levelBegin + blockIdx.x];
     const Island isl = pv.islands[entry & 0xFFFFFFu];
     const uint32_t splitIdx = entry >> 24;
@@ -1294,18 +1317,35 @@ void elemhip_island_kernel(PlanView pv, uint32_t* recs, float* hbm, const Global
     const uint32_t lo = isl.split > 1 ? (splitIdx * c.stride) / isl.split : 0u;
     const uint32_t hi = isl.split > 1 ? ((splitIdx + 1) * c.stride) / isl.split : 0xFFFFu;
 
+    unsigned long long* trace = (blockIdx.x == 0 && g->trace) ? reinterpret_cast<unsigned long long*>(g->trace) + (size_t)levelBegin * 0 : nullptr;
+    const uint64_t tProlog = clock64();
     uint32_t stage = 0;
     const uint32_t tb = wave == 0 ? isl.waveTask[0] : wave == 1 ? isl.waveTask[1] : wave == 2 ? isl.waveTask[2] : isl.waveTask[3];
     const uint32_t te = wave == 0 ? isl.waveTask[1] : wave == 1 ? isl.waveTask[2] : wave == 2 ? isl.waveTask[3] : isl.waveTask[4];
     for (uint32_t ti = tb; ti < te; ++ti) {
-        const v4u h = lds4u(isl.ldsProg + ti * 4u);
-        const uint32_t d0 = UNI(h.x), d1 = UNI(h.y);
+        const v4u h = lds4u(isl.ldsProg + ti * 8u), h2 = lds4u(isl.ldsProg + ti * 8u + 4u);
+        const uint32_t d0 = UNI(h.x), d1 = UNI(h.y), d6 = UNI(h2.z);
         TaskU t;
         t.opcode = d0 & 0xFFFFu; t.stage = (d0 >> 16) & 0xFFu; t.flags = d0 >> 24;
         t.s0 = d1 & 0xFFFFu; t.s1 = d1 >> 16;
         t.first = UNI(h.z); t.count = UNI(h.w);
+        t.o0 = UNI(h2.x); t.o1 = UNI(h2.y); t.outLds = d6 & 0xFFFFu; t.nin = d6 >> 16; t.outHbm = UNI(h2.w);
         while (stage < t.stage) { __syncthreads(); ++stage; }
+        // ELEMHIP trace hook: [wave][slot] = {opcode | stage << 16, start, end} in shader clocks
+        const uint64_t t0 = trace ? clock64() : 0;
         run_task(c, t, lo, hi);
+        if (trace) {
+            const uint64_t t1 = clock64();
+            const uint32_t slot = ti - tb;
+            if (c.lane == 0 && slot < 62) {
+                unsigned long long* w = trace + (size_t)wave * 192 + 3 * (slot + 2);
+                w[0] = d0; w[1] = t0; w[2] = t1;
+            }
+        }
+    }
+    if (trace && c.lane == 0) {
+        unsigned long long* w = trace + (size_t)wave * 192;
+        w[0] = te - tb; w[1] = tStart; w[2] = tProlog; w[3] = clock64();
     }
     while (stage + 1 < isl.numStages) { __syncthreads(); ++stage; }
 }

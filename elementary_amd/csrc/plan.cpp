@@ -63,6 +63,12 @@ uint32_t leafArity(uint16_t op) {
     }
 }
 
+uint32_t leafArityOfOp(uint16_t op) {
+    if (op == OP_SVF_COEF) return leafArity(OP_SVF);
+    if (op == OP_SHELF_COEF) return leafArity(OP_SVFSHELF);
+    return leafArity(op);
+}
+
 struct NI {                      // per-node planning info
     Node* n = nullptr;
     int seq = 0;                 // owning root sequence
@@ -492,7 +498,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
                 // a non power-of-two tail (block sizes that are not 64 * 2^k) is cut further
                 while (un) {
                     uint32_t take = 1; while (take * 2 <= un && take * 2 <= 8) take *= 2;
-                    tasks.push_back(Task{op, (uint8_t)stage, 0, (uint16_t)(u0 * 64), (uint16_t)((u0 + take) * 64), first, count});
+                    tasks.push_back(Task{op, (uint8_t)stage, 0, (uint16_t)(u0 * 64), (uint16_t)((u0 + take) * 64), first, count, 0, 0, 0, 0, 0});
                     taskWave.push_back(waves[w % waves.size()]);
                     u0 += take; un -= take;
                 }
@@ -539,7 +545,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
                     for (uint32_t c = 0; c < cnt; ++c) members.push_back(makeMember(ni[kv.second[off + c]]));
                     const int w = leastLoaded();
                     load[w] += 1000;
-                    tasks.push_back(Task{(uint16_t)(kv.first & 0xFFFFu), (uint8_t)stage, (uint8_t)(kv.first >> 16), 0, (uint16_t)bs, first, cnt});
+                    tasks.push_back(Task{(uint16_t)(kv.first & 0xFFFFu), (uint8_t)stage, (uint8_t)(kv.first >> 16), 0, (uint16_t)bs, first, cnt, 0, 0, 0, 0, 0});
                     taskWave.push_back(w);
                 }
             }
@@ -549,7 +555,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
                     members.push_back(makeMember(ni[k]));
                     const int w = leastLoaded();
                     load[w] += 100;
-                    tasks.push_back(Task{kv.first, (uint8_t)stage, 0, 0, (uint16_t)bs, first, 1});
+                    tasks.push_back(Task{kv.first, (uint8_t)stage, 0, 0, (uint16_t)bs, first, 1, 0, 0, 0, 0, 0});
                     taskWave.push_back(w);
                 }
             }
@@ -573,6 +579,15 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
             for (uint32_t w = 0; w < kWaves; ++w) I.waveTask[w + 1] += I.waveTask[w];
             tasks.swap(sorted);
         }
+        for (Task& t : tasks) {   // inline member 0 into the task header
+            const Member& m0 = members[t.first];
+            const uint32_t nops = m0.nin == kNone ? std::min<uint32_t>(leafArityOfOp(t.opcode), kMaxHostIn) : m0.nin;
+            t.o0 = nops > 0 ? operands[m0.opnd] : (uint32_t)kOpZero;
+            t.o1 = nops > 1 ? operands[m0.opnd + 1] : (uint32_t)kOpZero;
+            t.outLds16 = m0.outLds == kNone ? (uint16_t)0xFFFF : (uint16_t)m0.outLds;
+            t.nin16 = m0.nin == kNone ? (uint16_t)0xFFFF : (m0.nin >= 0xFFFE ? (uint16_t)0xFFFE : (uint16_t)m0.nin);
+            t.outHbm = m0.outHbm;
+        }
         // a pure sample-parallel island that streams many HBM buffers (a mixer) runs as several
         // workgroups, each rendering a slice of the block
         {
@@ -583,10 +598,10 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
             I.split = (pure && imports.empty() && hbmReads >= 8 && bs >= 128) ? std::min<uint32_t>(8, bs / 64) : 1;
         }
         // pack the blob: [tasks | members | operands | cells]
-        static_assert(sizeof(Task) == 16 && sizeof(Member) == 32 && sizeof(ConstCell) == 8, "program layout");
+        static_assert(sizeof(Task) == 32 && sizeof(Member) == 32 && sizeof(ConstCell) == 8, "program layout");
         I.progBegin = (uint32_t)p.prog.size();
         I.numTasks = (uint32_t)tasks.size();
-        I.memOff = I.numTasks * 4u;
+        I.memOff = I.numTasks * 8u;
         I.opndOff = I.memOff + (uint32_t)members.size() * 8u;
         I.cellOff = I.opndOff + (uint32_t)operands.size();
         I.numCells = (uint32_t)cells.size();

@@ -83,6 +83,10 @@ int  elemhip_get_stats(elemhip_t*, elemhip_stats* out);
  * kernel launch on the engine's stream. msOut[l] = mean ms of launch level l, msOut[levels] = the
  * epilogue kernel. Returns the number of entries written (levels + 1) or a negated error code. */
 int  elemhip_time_launches(elemhip_t*, size_t nOut, size_t numBlocks, float* msOut, size_t cap);
+/* Tracing hook: render one block while workgroup 0 of launch level `level` logs shader-clock
+ * timestamps per task. out[wave*192 + 0..3] = {tasks, kernel start, prologue end, kernel end};
+ * out[wave*192 + 3*(k+2) + 0..2] = {opcode | stage<<16 | flags<<24, start, end} for the wave's k-th task. */
+int  elemhip_trace_level(elemhip_t*, size_t nOut, uint32_t level, unsigned long long* out, size_t cap);
 /* Debug/test hook: JSON description of the current render plan (islands, launch levels, LDS).
  * deviceOrdinal == -1 at create time gives a "dry" handle that runs all host logic (instruction
  * decode, graph mutation, plan build, gc) without a GPU; it cannot render (process returns 101). */
