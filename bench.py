@@ -189,6 +189,7 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "kernel": "elemhip_island_kernel", "launches_per_block": len(lv) - 1,
                 "kernel_us_per_launch": [1e3 * x for x in lv[:-1]], "epilogue_us": 1e3 * lv[-1],
+                "event_pair_overhead_us_subtracted": 1e3 * rt.last_event_overhead_ms,
                 "algorithmic_bytes_per_block": alg_bytes,
                 "note": "achieved = SURVEY §8(d) algorithmic bytes of one block / summed HIP-event duration of that "
                         "block's island-kernel launches; buffers inside an island live in LDS and never reach HBM",

@@ -808,9 +808,9 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
     }
     setGlobalsFor(0, nOut, (size_t)blockSize, hGlobals.sampleTime);
     flushPending();
-    std::vector<hipEvent_t> ev(2 * (L + 1));
+    std::vector<hipEvent_t> ev(2 * (L + 2));   // + one empty pair: the cost of the event pair itself
     for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -kHipError;
-    std::vector<double> acc(L + 1, 0.0);
+    std::vector<double> acc(L + 2, 0.0);
     for (size_t b = 0; b < numBlocks; ++b) {
         for (size_t l = 0; l < L; ++l) {
             const uint32_t lb = p.levelOffsets[l], le = p.levelOffsets[l + 1];
@@ -821,14 +821,19 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
         (void)hipEventRecord(ev[2 * L], stream);
         launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, dOutRing);
         (void)hipEventRecord(ev[2 * L + 1], stream);
+        (void)hipEventRecord(ev[2 * L + 2], stream);
+        (void)hipEventRecord(ev[2 * L + 3], stream);
         if (hipStreamSynchronize(stream) != hipSuccess) return -kHipError;
-        for (size_t l = 0; l <= L; ++l) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[2 * l], ev[2 * l + 1]); acc[l] += ms; }
+        for (size_t l = 0; l <= L + 1; ++l) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[2 * l], ev[2 * l + 1]); acc[l] += ms; }
         mirrorRootFades(p, (uint32_t)blockSize, (uint32_t)nOut, 0);
         hGlobals.sampleTime += blockSize;
         st.blocksRendered++;
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
-    for (size_t l = 0; l <= L; ++l) msOut[l] = (float)(acc[l] / (double)std::max<size_t>(numBlocks, 1));
+    // an empty event pair measures the marker-to-marker cost that every timed launch also pays
+    const double empty = acc[L + 1] / (double)std::max<size_t>(numBlocks, 1);
+    for (size_t l = 0; l <= L; ++l) msOut[l] = (float)std::max(0.0, acc[l] / (double)std::max<size_t>(numBlocks, 1) - empty);
+    if (cap > L + 1) msOut[L + 1] = (float)empty;
     return (int)(L + 1);
 }
 

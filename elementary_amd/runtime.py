@@ -107,6 +107,7 @@ class Runtime(CRuntime):
         if k < 0:
             raise ElemHipError(f"elemhip_time_launches failed: {describe(-k)}")
         self.sample_time += int(num_blocks) * self.block_size
+        self.last_event_overhead_ms = float(buf[k])   # empty event pair, already subtracted
         return [float(buf[i]) for i in range(k)]
 
     def describe_plan(self) -> Dict[str, Any]:
