@@ -78,6 +78,7 @@ def main() -> None:
 
     from elementary_amd import graphs
     from elementary_amd.runtime import Runtime
+    from elementary_amd.sharded import reduce_bus
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -112,7 +113,7 @@ def main() -> None:
                 torch.cuda.current_stream().synchronize()   # the engine renders on its own stream
             rt.process_blocks(c, 2, out_ptr=buf.data_ptr())
             if world > 1:
-                works.append(dist.reduce(buf[:c], dst=0, op=dist.ReduceOp.SUM, async_op=True))
+                works.append(reduce_bus(buf[:c], dst=0, async_op=True))
             done += c
             k += 1
         for w in works:

@@ -1,0 +1,122 @@
+"""Host side of the HIP engine without a GPU: the C-ABI library loads and exports every symbol
+include/elemhip.h declares, and a "dry" handle (deviceOrdinal -1: instruction decode, graph
+mutation, plan build and gc, no rendering) behaves like the reference for return codes and gc."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from elementary_amd import el, graphs
+from elementary_amd.runtime import Runtime, load_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "elemhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(elemhip_[a-z_]+)\s*\(", hdr)))
+    assert len(names) >= 20
+    lib = load_library()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_gpu_means_no_engine_not_a_fallback():
+    """Without a device a rendering handle cannot be created (the driver's CPU box has no GPU);
+    a dry handle refuses to render."""
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            Runtime(44100.0, 512, device=0)
+    rt = Runtime(44100.0, 512, device=-1)
+    assert rt.render(el.cycle(440))["result"] == 0
+    with pytest.raises(RuntimeError):
+        rt.process(None, 1, 512)
+
+
+def dry(sr=44100.0, bs=512):
+    return Runtime(sr, bs, device=-1)
+
+
+def test_return_codes_match_reference():
+    """runtime/elem/Types.h:51-86 through Runtime.h:170-433 and the nodes' setProperty."""
+    batches = [
+        [[0, 1, "nope"]],                                   # 1 unknown node type
+        [[0, 1, "const"], [0, 1, "const"]],                 # 3 node already exists
+        [[3, 99, "value", 1]],                              # 2 node not found
+        [[0, 1, "const"], [3, 1, "value", "hi"]],           # 5 invalid property type
+        [[0, 1, "seq"], [3, 1, "offset", -1]],              # 6 invalid property value
+        [[0, 1, "metro"], [3, 1, "interval", 0]],           # 6
+        [[0, 1, "svf"], [3, 1, "mode", 3]],                 # 5
+        [[2, 1, 2, 0]],                                     # 2
+        [[0, 1, "root"], [4, [1, 2]], [5]],                 # 2 (activateRoots on a missing node)
+        ["x"],                                              # 8 invalid instruction format
+        [[0, "a", "const"]],                                # 8
+        [[7, 1, 2], [0, 5, "const"], [5]],                  # unknown opcodes are ignored -> 0
+        [[0, 1, "root"], [0, 2, "const"], [2, 1, 2, 0], [3, 1, "channel", 0], [4, [1]], [5]],   # 0
+    ]
+    have_ref = oracle.have_ref()
+    expect = [1, 3, 2, 5, 6, 6, 5, 2, 2, 8, 8, 0, 0]
+    for b, want in zip(batches, expect):
+        got = dry().apply_instructions(b)
+        assert got == want, (b, got)
+        if oracle.have_port():
+            assert oracle.PortRuntime(44100.0, 512).apply_instructions(b) == want, b
+        if have_ref:
+            assert oracle.RefRuntime(44100.0, 512).apply_instructions(b) == want, b
+
+
+def test_plan_shape_for_the_benchmark_graph():
+    """C2: one island per voice (all 13 ops fused behind LDS), the two 128-input mixers as split
+    islands on the second launch level."""
+    rt = dry(graphs.C2_SAMPLE_RATE)
+    res = rt.render(*graphs.c2_graph())
+    assert res["result"] == 0 and res["nodesAdded"] == 4107
+    p = rt.describe_plan()
+    assert p["num_nodes"] == 4107 and p["num_roots"] == 2 and p["num_levels"] == 2
+    assert p["level_sizes"][0] == 256               # 256 voice workgroups
+    assert p["level_sizes"][1] == 16                # 2 mixers x 8 slices
+    assert p["max_lds_bytes"] < 64 * 1024
+    assert p["num_hbm_buffers"] == 32 + 256 + 2     # host inputs + voice exports + roots
+
+
+def test_plan_handles_deep_and_wide_graphs():
+    x = el.in_({"channel": 0})
+    for k in range(300):                             # 300-deep chain -> several islands in sequence
+        x = el.pole(0.5, el.mul(0.5, x))
+    rt = dry()
+    assert rt.render(x)["result"] == 0
+    p = rt.describe_plan()
+    assert p["num_levels"] >= 8 and p["max_lds_bytes"] <= 160 * 1024
+    wide = el.add(*[el.cycle(100.0 + k) for k in range(500)])
+    rt = dry()
+    assert rt.render(wide)["result"] == 0
+    assert rt.describe_plan()["num_nodes"] > 1500
+
+
+def test_gc_follows_render_sequence_membership():
+    """Runtime.h:220-272 / gc.test.js: nodes die only once no current or pending sequence holds them."""
+    rts = [dry()]
+    if oracle.have_port():
+        rts.append(oracle.PortRuntime(44100.0, 512))
+    results = []
+    for rt in rts:
+        rt.render(el.mul(2, 3))
+        a = rt.gc()
+        rt.render(el.mul(3, 4))       # old root keeps fading => still a current root => still held
+        b = rt.gc()
+        results.append((a, len(b)))
+    assert all(r == results[0] for r in results)
+    assert results[0][0] == []
+
+
+def test_shared_resources_are_insert_only():
+    rt = dry()
+    assert rt.add_shared_resource("ir", np.ones(16, dtype=np.float32)) is True
+    assert rt.add_shared_resource("ir", np.zeros(16, dtype=np.float32)) is False
+    rt.prune_shared_resources()
+    assert rt.add_shared_resource("ir", np.zeros(16, dtype=np.float32)) is True   # pruned: nobody held it

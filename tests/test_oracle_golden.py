@@ -1,0 +1,141 @@
+"""Pin the CPU checkers against the golden vectors the reference's own jest suites hold for the
+block-render path (tests/golden/offline_renderer_snapshots.json, transcribed from
+js/packages/offline-renderer/__tests__/__snapshots__ by tests/golden/make_golden.py).  Each scenario
+restates the jest test that produced the snapshot (file:line in the docstring)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from elementary_amd import el
+from elementary_amd.offline import OfflineRenderer
+from elementary_amd.reconciler import create_node
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "offline_renderer_snapshots.json")))
+
+
+def _engines():
+    e = []
+    if oracle.have_port():
+        e.append(("port", lambda sr, bs: oracle.PortRuntime(sr, bs)))
+    if oracle.have_ref():
+        e.append(("ref-float", lambda sr, bs: oracle.RefRuntime(sr, bs)))
+        e.append(("ref-double", lambda sr, bs: oracle.RefRuntime(sr, bs, use_double=True)))
+    return e
+
+
+ENGINES = _engines()
+
+
+@pytest.fixture(params=ENGINES, ids=[n for n, _ in ENGINES])
+def core_factory(request):
+    def make(**kw):
+        c = OfflineRenderer(request.param[1])
+        c.initialize(**kw)
+        return c
+    return make
+
+
+def f32(n):
+    return np.zeros(n, dtype=np.float32)
+
+
+def test_the_basics(core_factory):
+    """offline-renderer.test.js:5-23"""
+    core = core_factory(num_input_channels=1, num_output_channels=1)
+    core.render(el.mul(2, 3))
+    out = [f32(5120)]
+    core.process([f32(5120)], out)
+    assert out[0][512 * 8:512 * 9].tolist() == GOLD["offline-renderer:the basics 1"]
+
+
+def test_switch_and_switch_back(core_factory):
+    """offline-renderer.test.js:48-76"""
+    core = core_factory(num_input_channels=0, num_output_channels=1)
+    out = [f32(5120)]
+    core.render(el.mul(2, 3)); core.process([], out)
+    core.render(el.mul(3, 4)); core.process([], out)
+    assert out[0][4096:4128].tolist() == GOLD["offline-renderer:switch and switch back 1"]
+    core.render(el.mul(2, 3)); core.process([], out)
+    assert out[0][4096:4128].tolist() == GOLD["offline-renderer:switch and switch back 2"]
+
+
+def test_child_limit(core_factory):
+    """offline-renderer.test.js:78-95: `add` with 100 children"""
+    core = core_factory(num_input_channels=0, num_output_channels=1)
+    core.render(create_node("add", {}, [1] * 100))
+    out = [f32(5120)]
+    core.process([], out)
+    assert out[0][4096:4128].tolist() == GOLD["offline-renderer:child limit 1"]
+
+
+def test_render_stats_and_invalid_property(core_factory):
+    """offline-renderer.test.js:97-121"""
+    core = core_factory(num_input_channels=0, num_output_channels=1)
+    stats = core.render(el.mul(2, 3))
+    assert (stats["nodesAdded"], stats["edgesAdded"], stats["propsWritten"]) == (4, 3, 5)
+    with pytest.raises(RuntimeError):
+        core.render(el.const({"value": "hi"}))
+
+
+def test_delay_basics(core_factory):
+    """delays.test.js:5-30"""
+    core = core_factory(num_input_channels=1, num_output_channels=1)
+    core.render(el.delay({"size": 10}, 0.5, 0, el.in_({"channel": 0})))
+    core.process([f32(5120)], [f32(5120)])
+    out = [f32(4)]
+    core.process([np.array([1, 2, 3, 4], dtype=np.float32)], out)
+    assert out[0].tolist() == GOLD["delays:delay basics 1"]
+
+
+def test_delay_zero_time(core_factory):
+    """delays.test.js:32-58"""
+    core = core_factory(num_input_channels=1, num_output_channels=1)
+    core.render(el.delay({"size": 10}, 0, 0, el.in_({"channel": 0})))
+    core.process([f32(5120)], [f32(5120)])
+    out = [f32(4)]
+    core.process([np.array([1, 2, 3, 4], dtype=np.float32)], out)
+    assert out[0].tolist() == [1, 2, 3, 4]
+
+
+def test_sdelay_basics(core_factory):
+    """delays.test.js:60-91 (el.sdelay is called with a stray third argument there; it is ignored)"""
+    core = core_factory(num_input_channels=1, num_output_channels=1)
+    core.render(el.sdelay({"size": 10}, el.in_({"channel": 0})))
+    core.process([f32(5120)], [f32(5120)])
+    x = np.array([1, 2, 3, 4, 4, 3, 2, 1] + [0] * 16, dtype=np.float32)
+    out = [f32(24)]
+    core.process([x], out)
+    assert out[0].tolist() == GOLD["delays:sdelay basics 1"]
+
+
+def test_feedback_taps(core_factory):
+    """tap.test.js:5-50: a tapOut -> tapIn cycle costs exactly one block"""
+    core = core_factory(num_input_channels=1, num_output_channels=1)
+    core.render(el.tapOut({"name": "test"}, el.add(el.tapIn({"name": "test"}), el.in_({"channel": 0}))))
+    core.process([f32(5120)], [f32(5120)])
+    ones = np.ones(512, dtype=np.float32)
+    for k in (1, 2, 3):
+        out = [f32(512)]
+        core.process([ones], out)
+        assert out[0].tolist() == GOLD[f"tap:feedback taps {k}"]
+
+
+def test_time_node(core_factory):
+    """time.test.js:5-30 and :32-63 (setCurrentTime / setCurrentTimeMs)"""
+    core = core_factory(num_input_channels=1, num_output_channels=1)
+    core.render(el.time())
+    core.process([f32(5120)], [f32(5120)])
+    out = [f32(32)]
+    core.process([f32(32)], out)
+    assert out[0].tolist() == GOLD["time:time node 1"]
+    core = core_factory(num_input_channels=0, num_output_channels=1)
+    core.render(el.time())
+    core.process([], [f32(5120)])
+    out = [f32(8)]
+    core.set_current_time(50); core.process([], out)
+    assert out[0].tolist() == [50, 51, 52, 53, 54, 55, 56, 57]
+    core.set_current_time_ms(1000); core.process([], out)
+    assert out[0].tolist() == [44100 + i for i in range(8)]
