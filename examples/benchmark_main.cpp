@@ -1,0 +1,43 @@
+// examples/benchmark_main.cpp — the timing protocol of the reference's cli benchmark
+// (cli/Benchmark.cpp:31-112: Runtime(44100, 512), apply the instruction batch, 1 warm-up block,
+// N timed 512-frame process() calls into 2 scratch channels, report total / average) on the HIP
+// engine.  The reference evaluates a JS bundle in QuickJS to obtain the batch; here the batch is
+// read from a JSON file (e.g. written by `python -m elementary_amd.tools dump c1 batch.json`).
+//
+//   hipcc -O2 -Iinclude examples/benchmark_main.cpp -Lelementary_amd -lelemhip -Wl,-rpath,$PWD/elementary_amd -o bench_cli
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include <elemhip/Runtime.hpp>
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: %s batch.json [blocks=10000] [sampleRate=44100]\n", argv[0]); return 2; }
+    const size_t blocks = argc > 2 ? std::stoul(argv[2]) : 10000;
+    const double sr = argc > 3 ? std::stod(argv[3]) : 44100.0;
+    std::ifstream f(argv[1]);
+    std::string batch((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+
+    elemhip::Runtime<float> runtime(sr, 512);
+    const int rc = runtime.applyInstructionsJSON(batch);
+    if (rc) { std::fprintf(stderr, "applyInstructions: %s\n", elemhip_describe(rc)); return 1; }
+
+    std::vector<std::vector<float>> scratch(2, std::vector<float>(512));
+    std::vector<float*> ptrs = {scratch[0].data(), scratch[1].data()};
+    runtime.process(nullptr, 0, ptrs.data(), 2, 512, nullptr);                 // warm-up block (:70-77)
+
+    std::vector<double> deltas;
+    for (size_t i = 0; i < blocks; ++i) {
+        auto t0 = std::chrono::steady_clock::now();
+        runtime.process(nullptr, 0, ptrs.data(), 2, 512, nullptr);
+        auto t1 = std::chrono::steady_clock::now();
+        deltas.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());   // ns resolution, not truncated
+    }
+    const double sum = std::accumulate(deltas.begin(), deltas.end(), 0.0);
+    std::printf("[Running float]:\nTotal run time: %.0fus (%.3fs)\nAverage iteration time: %.2fus\nDone\n", sum, sum / 1e6, sum / deltas.size());
+    return 0;
+}
