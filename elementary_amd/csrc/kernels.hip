@@ -119,13 +119,13 @@ __device__ __forceinline__ uint32_t opnd_lane(const Ctx& c, const Member& m, uin
 // once per operand, outside the sample loop.
 struct PIn { uint32_t base, step; gcfp g; };
 __device__ __forceinline__ PIn pin_of(const Ctx& c, uint32_t o) {
-    const uint32_t kind = o & kOpKindMask, v = o & kOpValMask;
+    // arithmetic selects only: an if/else ladder here compiled to ~30 scalar instructions of control flow
+    const uint32_t kind = o >> 30, v = o & kOpValMask;
     PIn p;
-    p.g = nullptr;
-    if (kind == kOpLds)        { p.base = v; p.step = 1u; }
-    else if (kind == kOpConst) { p.base = v; p.step = 0u; }
-    else if (kind == kOpHbm)   { p.base = 0u; p.step = 0u; p.g = (gcfp)(c.hbm + (size_t)v * c.stride); }
-    else                       { p.base = 0u; p.step = 0u; }   // LDS word 0 reads 0.0f
+    p.step = (kind == 0u) ? 1u : 0u;                     // LDS buffer
+    p.base = (kind <= 1u) ? v : 0u;                      // buffer / broadcast cell; otherwise LDS word 0 (= 0.0f)
+    const uint64_t ga = (uint64_t)(uintptr_t)(float*)c.hbm + (uint64_t)v * c.stride * 4u;
+    p.g = (gcfp)(float*)(uintptr_t)((kind == 2u) ? ga : 0ull);
     return p;
 }
 __device__ __forceinline__ float pget(const PIn& p, uint32_t i) { return p.g ? p.g[i] : lds[p.base + i * p.step]; }
@@ -587,35 +587,38 @@ __device__ __forceinline__ SIn sin_of(uint32_t o) {
     return s;
 }
 
-template <int NIN>
-__device__ __forceinline__ void load_chunk(const SIn (&in)[NIN], uint32_t cmask, uint32_t t0, float (&x)[NIN][CH]) {
-#pragma unroll
-    for (int k = 0; k < NIN; ++k) {
-        if (cmask & (1u << k)) {
-#pragma unroll
-            for (int j = 0; j < CH; ++j) x[k][j] = in[k].cval;
-        } else {
-            const v4f a = ld4(in[k].base + t0);
-            const v4f b = ld4(in[k].base + t0 + 4);
-            x[k][0] = a.x; x[k][1] = a.y; x[k][2] = a.z; x[k][3] = a.w;
-            x[k][4] = b.x; x[k][5] = b.y; x[k][6] = b.z; x[k][7] = b.w;
-        }
-    }
-}
-
-// Generic chunked chain: `step(x[NIN]) -> y` carries the node state by reference. Two chunks per
-// trip (ping-pong registers): the next chunk's operands are in flight while the current chunk's
-// dependent arithmetic runs.
-template <int NIN, typename Step>
-__device__ __forceinline__ void chain_loop(const SIn (&in)[NIN], uint32_t cmask, uint32_t outBase, uint32_t n, Step&& step) {
+// Chunked chain with the broadcast-cell mask CM known at compile time: cell operands are plain
+// loop-invariant scalars (no loads, no register copies), buffer operands are streamed with two
+// ds_read_b128 per 8 frames, one chunk ahead of the dependent arithmetic (ping-pong registers).
+// `step(x[NIN]) -> y` carries the node state by reference.
+template <int NIN, uint32_t CM, typename Step>
+__device__ __forceinline__ void chain_loop_m(const SIn (&in)[NIN], uint32_t outBase, uint32_t n, Step&& step) {
+    constexpr int NS0 = NIN - __builtin_popcount(CM & ((1u << NIN) - 1u));
+    constexpr int NS = NS0 > 0 ? NS0 : 1;
     const uint32_t nFull = n & ~(uint32_t)(CH - 1);
-    auto run8 = [&](const float (&x)[NIN][CH], uint32_t t0) {
+    auto load = [&](uint32_t t0, float (&x)[NS][CH]) {
+        int s_ = 0;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            if (!((CM >> k) & 1u)) {
+                const v4f a = ld4(in[k].base + t0), b = ld4(in[k].base + t0 + 4);
+                x[s_][0] = a.x; x[s_][1] = a.y; x[s_][2] = a.z; x[s_][3] = a.w;
+                x[s_][4] = b.x; x[s_][5] = b.y; x[s_][6] = b.z; x[s_][7] = b.w;
+                ++s_;
+            }
+        }
+    };
+    auto run8 = [&](const float (&x)[NS][CH], uint32_t t0) {
         float y[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             float xs[NIN];
+            int s_ = 0;
 #pragma unroll
-            for (int k = 0; k < NIN; ++k) xs[k] = x[k][j];
+            for (int k = 0; k < NIN; ++k) {
+                if ((CM >> k) & 1u) xs[k] = in[k].cval;
+                else xs[k] = x[s_++][j];
+            }
             y[j] = step(xs);
         }
         v4f a, b;
@@ -623,14 +626,13 @@ __device__ __forceinline__ void chain_loop(const SIn (&in)[NIN], uint32_t cmask,
         st4(outBase + t0, a);
         st4(outBase + t0 + 4, b);
     };
-    float A[NIN][CH], B[NIN][CH];
+    float A[NS][CH], B[NS][CH];
     uint32_t t0 = 0;
-    if (nFull) load_chunk<NIN>(in, cmask, 0, A);
+    if (nFull && NS0 > 0) load(0, A);
     while (t0 + 2 * CH <= nFull) {
-        load_chunk<NIN>(in, cmask, t0 + CH, B);
+        if (NS0 > 0) load(t0 + CH, B);
         run8(A, t0);
-        const uint32_t tn = (t0 + 2 * CH < nFull) ? t0 + 2 * CH : t0;   // nothing left: harmless re-read
-        load_chunk<NIN>(in, cmask, tn, A);
+        if (NS0 > 0) load((t0 + 2 * CH < nFull) ? t0 + 2 * CH : t0, A);   // nothing left: harmless re-read
         run8(B, t0 + CH);
         t0 += 2 * CH;
     }
@@ -638,8 +640,49 @@ __device__ __forceinline__ void chain_loop(const SIn (&in)[NIN], uint32_t cmask,
     for (uint32_t t = nFull; t < n; ++t) {
         float xs[NIN];
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) xs[k] = (cmask & (1u << k)) ? in[k].cval : lds[in[k].base + t];
+        for (int k = 0; k < NIN; ++k) xs[k] = ((CM >> k) & 1u) ? in[k].cval : lds[in[k].base + t];
         lds[outBase + t] = step(xs);
+    }
+}
+
+// Dispatch on the task's cell mask (wave-uniform): every combination for up to 3 operands; for the
+// 6-operand biquad the two shapes that occur (coefficients constant / everything a signal).
+template <int NIN, typename Step>
+__device__ __forceinline__ void chain_loop(const SIn (&in)[NIN], uint32_t cmask, uint32_t outBase, uint32_t n, Step&& step) {
+    cmask &= (1u << NIN) - 1u;
+    if constexpr (NIN == 1) {
+        if (cmask) chain_loop_m<1, 1u>(in, outBase, n, step); else chain_loop_m<1, 0u>(in, outBase, n, step);
+    } else if constexpr (NIN == 2) {
+        switch (cmask) {
+            case 0: chain_loop_m<2, 0u>(in, outBase, n, step); break;
+            case 1: chain_loop_m<2, 1u>(in, outBase, n, step); break;
+            case 2: chain_loop_m<2, 2u>(in, outBase, n, step); break;
+            default: chain_loop_m<2, 3u>(in, outBase, n, step); break;
+        }
+    } else if constexpr (NIN == 3) {
+        switch (cmask) {
+            case 0: chain_loop_m<3, 0u>(in, outBase, n, step); break;
+            case 1: chain_loop_m<3, 1u>(in, outBase, n, step); break;
+            case 2: chain_loop_m<3, 2u>(in, outBase, n, step); break;
+            case 3: chain_loop_m<3, 3u>(in, outBase, n, step); break;
+            case 4: chain_loop_m<3, 4u>(in, outBase, n, step); break;
+            case 5: chain_loop_m<3, 5u>(in, outBase, n, step); break;
+            case 6: chain_loop_m<3, 6u>(in, outBase, n, step); break;
+            default: chain_loop_m<3, 7u>(in, outBase, n, step); break;
+        }
+    } else {
+        static_assert(NIN == 6, "chain arity");
+        if (cmask == 0x1Fu) chain_loop_m<6, 0x1Fu>(in, outBase, n, step);
+        else {
+            // mixed shapes: materialise the cells of constant operands as (degenerate) buffers is not
+            // possible, so fall back to per-frame reads — correct for any mask, just slower
+            for (uint32_t t = 0; t < n; ++t) {
+                float xs[NIN];
+#pragma unroll
+                for (int k = 0; k < NIN; ++k) xs[k] = ((cmask >> k) & 1u) ? in[k].cval : lds[in[k].base + t];
+                lds[outBase + t] = step(xs);
+            }
+        }
     }
 }
 
@@ -660,13 +703,23 @@ __device__ __forceinline__ void ser_phasor(const Ctx& c, const Member& m, uint32
     const SIn in[1] = {sin_of(opnd_lane(c, m, 0))};
     float phase = u2f(r[rec::S0]);
     const float rsr = 1.0f / c.srF;
-    chain_loop<1>(in, cm, m.outLds, c.n, [&](const float (&x)[1]) {
-        const float stepv = x[0] * rsr;
-        const float y = phase;
-        const float next = phase + stepv;
-        phase = next - floorf(next);
-        return y;
-    });
+    if ((cm & 1u) && in[0].cval * rsr >= 0.0f && phase >= 0.0f) {
+        // constant non-negative step: next >= 0, so next - floor(next) is exactly v_fract_f32(next)
+        const SIn st[1] = {SIn{0u, in[0].cval * rsr}};
+        chain_loop_m<1, 1u>(st, m.outLds, c.n, [&](const float (&x)[1]) {
+            const float y = phase;
+            phase = __builtin_amdgcn_fractf(phase + x[0]);
+            return y;
+        });
+    } else {
+        chain_loop<1>(in, cm, m.outLds, c.n, [&](const float (&x)[1]) {
+            const float stepv = x[0] * rsr;
+            const float y = phase;
+            const float next = phase + stepv;
+            phase = next - floorf(next);
+            return y;
+        });
+    }
     r[rec::S0] = f2u(phase);
 }
 
@@ -852,16 +905,37 @@ __device__ __forceinline__ float blep(float phase, float inc) {
 
 // serial part: only `phase += inc; if (phase >= 1) phase -= 1`. The out slot carries inc[t] in
 // (from the pre-pass) and the pre-tick phase[t] out (for the post-pass).
-__device__ __forceinline__ void ser_blep_phase(const Ctx& c, const Member& m) {
+__device__ __forceinline__ void ser_blep_phase(const Ctx& c, const Member& m, uint32_t cm) {
     gup r = c.recs + m.rec * kRecDwords;
     float phase = u2f(r[rec::S0]);
-    const SIn in[1] = {SIn{m.outLds, 0.0f}};
-    chain_loop<1>(in, 0u, m.outLds, c.n, [&](const float (&x)[1]) {
-        const float y = phase;
-        phase += x[0];
-        if (phase >= 1.0f) phase -= 1.0f;
-        return y;
-    });
+    if (cm & 1u) {
+        // constant frequency: the increment is one scalar, no pre-pass, nothing to load
+        const float inc = lds[opnd_lane(c, m, 0) & kOpValMask] / c.srF;
+        const SIn in[1] = {SIn{0u, inc}};
+        if (inc >= 0.0f && inc < 1.0f && phase >= 0.0f && phase < 1.0f) {
+            // t = phase + inc lies in [0, 2): `if (t >= 1) t -= 1` == t - floor(t) exactly == v_fract_f32
+            chain_loop_m<1, 1u>(in, m.outLds, c.n, [&](const float (&x)[1]) {
+                const float y = phase;
+                phase = __builtin_amdgcn_fractf(phase + x[0]);
+                return y;
+            });
+        } else {
+            chain_loop_m<1, 1u>(in, m.outLds, c.n, [&](const float (&x)[1]) {
+                const float y = phase;
+                phase += x[0];
+                if (phase >= 1.0f) phase -= 1.0f;
+                return y;
+            });
+        }
+    } else {
+        const SIn in[1] = {SIn{m.outLds, 0.0f}};
+        chain_loop_m<1, 0u>(in, m.outLds, c.n, [&](const float (&x)[1]) {
+            const float y = phase;
+            phase += x[0];
+            if (phase >= 1.0f) phase -= 1.0f;
+            return y;
+        });
+    }
     r[rec::S0] = f2u(phase);
 }
 
@@ -1135,7 +1209,7 @@ __device__ __forceinline__ void run_stateful(const Ctx& c, const TaskU& t) {
         });
     } else {
         const bool isBlep = (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_BLEPTRIANGLE);
-        if (isBlep) {   // pre-pass: inc[t] = f/sr into the out slot
+        if (isBlep && !(cm & 1u)) {   // pre-pass: inc[t] = f/sr into the out slot (skipped for a constant frequency)
             const float sr = c.srF;
             for_members(c, t, [&](const Member& m) {
                 if (member_nin(c, m) < 1) return;
@@ -1168,7 +1242,7 @@ __device__ __forceinline__ void run_stateful(const Ctx& c, const TaskU& t) {
                 case OP_ONCE:     ser_once(c, m, cm); break;
                 case OP_SEQ:      ser_seq(c, m, cm); break;
                 case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
-                    if (member_nin(c, m) < 1) szero(m, n); else ser_blep_phase(c, m);
+                    if (member_nin(c, m) < 1) szero(m, n); else ser_blep_phase(c, m, cm);
                     break;
                 default: break;
             }
@@ -1214,6 +1288,78 @@ __device__ __forceinline__ void run_stateful(const Ctx& c, const TaskU& t) {
         if (m.outHbm == kNone) return;
         for (uint32_t i = c.lane; i < n; i += 64) c.hbm[(size_t)m.outHbm * c.stride + i] = lds[m.outLds + i];
     });
+}
+
+// Fast path for the overwhelmingly common sample-parallel task: one node, one or two operands that
+// all live in LDS (buffers / broadcast cells), enough inputs for the node's arity. The planner
+// marks such tasks (flags bit 7); everything they need is in the 8-dword header, so there is no
+// operand-kind decoding and no member/operand table access: load, apply, store.
+template <int V>
+__device__ __forceinline__ void fast_load(uint32_t o, uint32_t i, float (&x)[V]) {
+    const uint32_t w = o & kOpValMask;
+    if ((o >> 30) == 0u) {
+        if constexpr (V == 1) x[0] = lds[w + i];
+        else if constexpr (V == 2) { const v2f a = *reinterpret_cast<const v2f*>(__builtin_assume_aligned(&lds[w + i], 8)); x[0] = a.x; x[1] = a.y; }
+        else {
+#pragma unroll
+            for (int q = 0; q < V; q += 4) { const v4f a = ld4(w + i + q); x[q] = a.x; x[q + 1] = a.y; x[q + 2] = a.z; x[q + 3] = a.w; }
+        }
+    } else {
+        const float v = lds[(o >> 30) == 1u ? w : 0u];
+#pragma unroll
+        for (int q = 0; q < V; ++q) x[q] = v;
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void run_fast(const Ctx& c, const TaskU& t, uint32_t i) {
+    float x[V], y[V];
+    fast_load<V>(t.o0, i, x);
+    const uint32_t op = t.opcode;
+    if (op >= OP_LE) {   // binary / two-operand reduce
+        fast_load<V>(t.o1, i, y);
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            float r;
+            switch (op) {
+                case OP_ADD: r = x[q] + y[q]; break;
+                case OP_SUB: r = x[q] - y[q]; break;
+                case OP_MUL: r = x[q] * y[q]; break;
+                case OP_DIV: r = reduce_eval(OP_DIV, x[q], y[q]); break;
+                case OP_MIN: r = reduce_eval(OP_MIN, x[q], y[q]); break;
+                case OP_MAX: r = reduce_eval(OP_MAX, x[q], y[q]); break;
+                case OP_MOD: r = fmodf(x[q], y[q]); break;
+                default:     r = binary_eval((uint16_t)op, x[q], y[q]); break;
+            }
+            x[q] = r;
+        }
+    } else {
+        switch (op) {   // one switch per task, the loops inside each case are straight-line
+#define FU(OPC) case OPC: _Pragma("unroll") for (int q = 0; q < V; ++q) x[q] = unary_eval(OPC, x[q]); break;
+            FU(OP_SIN) FU(OP_COS) FU(OP_TAN) FU(OP_TANH) FU(OP_ASINH) FU(OP_LN) FU(OP_LOG) FU(OP_LOG2)
+            FU(OP_CEIL) FU(OP_FLOOR) FU(OP_ROUND) FU(OP_SQRT) FU(OP_EXP)
+            default: _Pragma("unroll") for (int q = 0; q < V; ++q) x[q] = fabsf(x[q]); break;
+#undef FU
+        }
+    }
+    if (t.outLds != 0xFFFFu) {
+        const uint32_t w = t.outLds + i;
+        if constexpr (V == 1) lds[w] = x[0];
+        else if constexpr (V == 2) { v2f a; a.x = x[0]; a.y = x[1]; *reinterpret_cast<v2f*>(__builtin_assume_aligned(&lds[w], 8)) = a; }
+        else {
+#pragma unroll
+            for (int q = 0; q < V; q += 4) { v4f a; a.x = x[q]; a.y = x[q + 1]; a.z = x[q + 2]; a.w = x[q + 3]; st4(w + q, a); }
+        }
+    }
+    if (t.outHbm != kNone) {
+        gfp g = c.hbm + (size_t)t.outHbm * c.stride + i;
+        if constexpr (V == 1) g[0] = x[0];
+        else if constexpr (V == 2) { v2f a; a.x = x[0]; a.y = x[1]; *(gv2)g = a; }
+        else {
+#pragma unroll
+            for (int q = 0; q < V; q += 4) { v4f a; a.x = x[q]; a.y = x[q + 1]; a.z = x[q + 2]; a.w = x[q + 3]; *(gv4)(g + q) = a; }
+        }
+    }
 }
 
 // sample-parallel opcodes on the canonical mapping, V consecutive frames per lane
@@ -1333,6 +1479,13 @@ void elemhip_island_kernel(PlanView pv, uint32_t* recs, float* hbm, const Global
         while (stage < t.stage) { __syncthreads(); ++stage; }
         // ELEMHIP trace hook: [wave][slot] = {opcode | stage << 16, start, end} in shader clocks
         const uint64_t t0 = trace ? clock64() : 0;
+        if ((t.flags & 0x80u) && t.s1 <= c.n && isl.split <= 1u) {
+            const uint32_t V = (t.s1 - t.s0) >> 6, i = t.s0 + c.lane * V;
+            if (V == 2u) run_fast<2>(c, t, i);
+            else if (V == 8u) run_fast<8>(c, t, i);
+            else if (V == 4u) { run_fast<2>(c, t, i); run_fast<2>(c, t, i + 2u); }
+            else run_fast<1>(c, t, i);
+        } else
         run_task(c, t, lo, hi);
         if (trace) {
             const uint64_t t1 = clock64();

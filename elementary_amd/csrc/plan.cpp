@@ -587,6 +587,17 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
             t.outLds16 = m0.outLds == kNone ? (uint16_t)0xFFFF : (uint16_t)m0.outLds;
             t.nin16 = m0.nin == kNone ? (uint16_t)0xFFFF : (m0.nin >= 0xFFFE ? (uint16_t)0xFFFE : (uint16_t)m0.nin);
             t.outHbm = m0.outHbm;
+            // fast sample-parallel task (kernels.hip run_fast): single member, math opcode, all
+            // operands in LDS, arity satisfied (no zero-fill case), not a leaf
+            const bool unary = t.opcode >= OP_SIN && t.opcode <= OP_ABS;
+            const bool binary = t.opcode >= OP_LE && t.opcode <= OP_OR;
+            const bool reduce2 = t.opcode >= OP_ADD && t.opcode <= OP_MAX;
+            auto inLds = [](uint32_t o) { return (o & kOpKindMask) != kOpHbm; };
+            if (t.count == 1 && m0.nin != kNone && (m0.outLds == kNone || m0.outLds < 0xFFFFu) &&
+                ((unary && m0.nin >= 1 && inLds(t.o0)) || (binary && m0.nin >= 2 && inLds(t.o0) && inLds(t.o1)) ||
+                 (reduce2 && m0.nin == 2 && inLds(t.o0) && inLds(t.o1))) &&
+                (m0.outLds != kNone || m0.outHbm != kNone))
+                t.flags |= 0x80u;
         }
         // a pure sample-parallel island that streams many HBM buffers (a mixer) runs as several
         // workgroups, each rendering a slice of the block
