@@ -302,20 +302,47 @@ __device__ __forceinline__ void run_reduce(const Ctx& c, const Member& m, uint32
     }
     constexpr int KB = (V <= 2) ? 16 : (V == 4 ? 8 : 4);   // children in flight (KB * V registers)
     uint32_t k = 1;
+    // all HBM children (a mixer): one buffer descriptor over the arena, child offset in an SGPR —
+    // 4 instructions per child (v_readlane, s_and, s_mul, buffer_load) instead of a generic decode
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((float*)c.hbm, 0, 0x7FFFFFFF, 0x00020000);
+    const uint32_t strideBytes = c.stride * 4u;
     while (k < nin) {
         const uint32_t left = min(nin - k, 64u);
         const uint32_t mine = (c.lane < left) ? ldsu(c.operands + m.opnd + k + c.lane) : (uint32_t)kOpZero;
-        for (uint32_t b0 = 0; b0 < left; b0 += KB) {
-            float v[KB][V];
+        const bool allHbm = (V <= 2) && __all(c.lane >= left || ((mine >> 30) == 2u && (mine & kOpValMask) < (0x7FFFFFFFu / strideBytes)));
+        if (allHbm) {
+            constexpr int KH = (V == 1) ? 64 : 32;   // one memory round trip per 64 children
+            for (uint32_t b0 = 0; b0 < left; b0 += KH) {
+                float v[KH][V];
 #pragma unroll
-            for (int b = 0; b < KB; ++b)
-                if (b0 + b < left) vload<V>(pin_of(c, (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)(b0 + b))), i, v[b]);
-#pragma unroll
-            for (int b = 0; b < KB; ++b)
-                if (b0 + b < left) {
-#pragma unroll
-                    for (int q = 0; q < V; ++q) acc[q] = reduce_eval(OPC, acc[q], v[b][q]);
+                for (int b = 0; b < KH; ++b) {
+                    if (b0 + b < left) {
+                        const uint32_t code = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)(b0 + b));
+                        const uint32_t soff = (code & kOpValMask) * strideBytes;
+                        if constexpr (V == 1) v[b][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, i * 4u, soff, 0));
+                        else { const v2f t2 = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, i * 4u, soff, 0)); v[b][0] = t2.x; v[b][V - 1] = t2.y; }
+                    }
                 }
+#pragma unroll
+                for (int b = 0; b < KH; ++b)
+                    if (b0 + b < left) {
+#pragma unroll
+                        for (int q = 0; q < V; ++q) acc[q] = reduce_eval(OPC, acc[q], v[b][q]);
+                    }
+            }
+        } else {
+            for (uint32_t b0 = 0; b0 < left; b0 += KB) {
+                float v[KB][V];
+#pragma unroll
+                for (int b = 0; b < KB; ++b)
+                    if (b0 + b < left) vload<V>(pin_of(c, (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)(b0 + b))), i, v[b]);
+#pragma unroll
+                for (int b = 0; b < KB; ++b)
+                    if (b0 + b < left) {
+#pragma unroll
+                        for (int q = 0; q < V; ++q) acc[q] = reduce_eval(OPC, acc[q], v[b][q]);
+                    }
+            }
         }
         k += left;
     }
