@@ -173,6 +173,10 @@ enum : uint32_t {
     SEQ_INDEX = S0, SEQ_HOLDVAL = S1, SEQ_FIRST = S2, SEQ_CHANGE = S3, SEQ_RCHANGE = S4, SEQ_HAVE = S5,
     // taps (Feedback.h)
     TAP_SHARED = P0, TAP_PRIVATE = P2,
+    // sampleseq (SampleSeq.h:169-404): sample buffer, event table [len doubles | len floats], k-rate state, two readers
+    SSQ_BUF = P0, SSQ_BUFLEN = P2, SSQ_BUFPENDING = P3, SSQ_SEQ = P4, SSQ_SEQLEN = P6, SSQ_SEQPENDING = P7,
+    SSQ_DUR = 8, SSQ_RTDUR = 10, SSQ_PREV = 12, SSQ_NEXT = 13, SSQ_ACTIVE = 14, SSQ_FLAGS = 15,
+    SSQ_READER0 = 16, SSQ_READER_DWORDS = 8,   // per reader: gain, target, step, position, startTime(2), bufferSize, -
 };
 }
 

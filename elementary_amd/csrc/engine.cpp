@@ -55,7 +55,7 @@ static const std::unordered_map<std::string, uint16_t>& opTable() {
         {"pole", OP_POLE}, {"env", OP_ENV}, {"biquad", OP_BIQUAD}, {"prewarp", OP_PREWARP}, {"mm1p", OP_MM1P}, {"svf", OP_SVF}, {"svfshelf", OP_SVFSHELF},
         {"tapIn", OP_TAPIN}, {"tapOut", OP_TAPOUT},
         {"blepsaw", OP_BLEPSAW}, {"blepsquare", OP_BLEPSQUARE}, {"bleptriangle", OP_BLEPTRIANGLE},
-        {"time", OP_TIME}, {"metro", OP_METRO},
+        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ},
     };
     return t;
 }
@@ -290,6 +290,10 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
         case OP_MAXHOLD: r[rec::P0] = 0xFFFFFFFFu; break;                         // Core.h:336
         case OP_SEQ:     r[rec::SEQ_HOLD] = 0; r[rec::SEQ_LOOP] = 1; break;       // Core.h:566-568
         case OP_RAND:    r[rec::S0] = (uint32_t)std::rand(); break;               // Noise.h:42
+        case OP_SAMPLESEQ:                                                        // SampleSeq.h:66-68: fade step 0.02
+            r[rec::SSQ_PREV] = r[rec::SSQ_NEXT] = 0xFFFFFFFFu;
+            r[rec::SSQ_READER0 + 2] = fbits(0.02f); r[rec::SSQ_READER0 + rec::SSQ_READER_DWORDS + 2] = fbits(0.02f);
+            break;
         case OP_METRO: {                                                          // wasm/Metro.h:15
             const int64_t is = (int64_t)std::max(2.0, 1000.0 * 0.001 * sampleRate);
             r[rec::P0] = (uint32_t)((uint64_t)is & 0xFFFFFFFFu); r[rec::P1] = (uint32_t)((uint64_t)is >> 32);
@@ -466,6 +470,51 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
                 if (rc != kOk) return rc;
                 n.res = r;
                 writeParamPtr(n, rec::TAP_SHARED, r->dev.ptr);
+            }
+            break;
+        case OP_SAMPLESEQ:                                         // SampleSeq.h:181-255
+            if (key == "duration") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                if (v.num <= 0.0) return kInvalidPropertyValue;
+                uint64_t bits; std::memcpy(&bits, &v.num, 8);
+                writeParam(n, rec::SSQ_DUR, (uint32_t)(bits & 0xFFFFFFFFu));
+                writeParam(n, rec::SSQ_DUR + 1, (uint32_t)(bits >> 32));
+            }
+            if (key == "path") {
+                if (!v.isString()) return kInvalidPropertyType;
+                auto rit = resources.find(v.str);
+                if (rit == resources.end()) return kInvalidPropertyValue;
+                int rc = ensureResourceOnDevice(rit->second);
+                if (rc != kOk) return rc;
+                n.res = rit->second;
+                writeParamPtr(n, rec::SSQ_BUF, n.res->dev.ptr);
+                writeParam(n, rec::SSQ_BUFLEN, (uint32_t)(n.res->channels.empty() ? 0 : n.res->channels[0].size()));
+                writeParam(n, rec::SSQ_BUFPENDING, 1u);
+            }
+            if (key == "seq") {
+                if (!v.isArray()) return kInvalidPropertyType;
+                std::map<double, float> events;                     // std::map::insert keeps a key's first entry
+                for (const Value& e : v.arr) {
+                    if (!e.isObject()) return kInvalidPropertyType;
+                    const Value* val = e.find("value"); const Value* tm = e.find("time");
+                    if (!val || !tm || !val->isNumber() || !tm->isNumber()) return kInvalidPropertyType;
+                    events.insert({tm->num, (float)val->num});
+                }
+                const size_t len = events.size();
+                std::vector<uint32_t> blob(len * 3 + 2, 0u);        // [len doubles][len floats]
+                size_t k = 0;
+                for (auto& kv : events) {
+                    std::memcpy(&blob[2 * k], &kv.first, 8);
+                    std::memcpy(&blob[2 * len + k], &kv.second, 4);
+                    ++k;
+                }
+                int rc = allocRing(n, blob.size());
+                if (rc != kOk) return rc;
+                if (dry) std::memcpy(n.ring.ptr, blob.data(), blob.size() * 4);
+                else HIP_OK(hipMemcpy(n.ring.ptr, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+                writeParamPtr(n, rec::SSQ_SEQ, n.ring.ptr);
+                writeParam(n, rec::SSQ_SEQLEN, (uint32_t)len);
+                writeParam(n, rec::SSQ_SEQPENDING, 1u);
             }
             break;
         case OP_METRO:                                             // wasm/Metro.h:18-34

@@ -595,6 +595,109 @@ __device__ __forceinline__ void run_delay(const Ctx& c, const Member& m, uint32_
     WAVE_SYNC();
 }
 
+// SampleSeqNode<F,false> (builtins/SampleSeq.h:169-404): k-rate control from in[0][0], two
+// cross-fading BufferReader<float>s (detail::GainFade step 0.02/sample) added into a zeroed output.
+// Every lane replays the (tiny, uniform) control logic; the fade ramps are produced serially only
+// while a reader is still moving (<= 50 frames), the sample reads and the mix are frame-parallel.
+__device__ __forceinline__ void run_sampleseq(const Ctx& c, const Member& m, uint32_t s0, uint32_t s1) {
+    gup r = c.recs + m.rec * kRecDwords;
+    const uint32_t n = c.n;
+    const double dur = rec_ld_f64(r, rec::SSQ_DUR);
+    double rtDur = rec_ld_f64(r, rec::SSQ_RTDUR);
+    float gain[2], target[2], step[2]; uint32_t pos[2], bsz[2]; double start[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        gcup rr = r + rec::SSQ_READER0 + q * rec::SSQ_READER_DWORDS;
+        gain[q] = u2f(rr[0]); target[q] = u2f(rr[1]); step[q] = u2f(rr[2]); pos[q] = rr[3];
+        start[q] = rec_ld_f64(rr, 4); bsz[q] = rr[6];
+    }
+    int prev = (int)r[rec::SSQ_PREV], next = (int)r[rec::SSQ_NEXT];
+    uint32_t active = r[rec::SSQ_ACTIVE], flags = r[rec::SSQ_FLAGS];
+    auto resetReaders = [&]() {   // BufferReader::reset (:149-155)
+        gain[0] = gain[1] = 0.0f; target[0] = target[1] = 0.0f; start[0] = start[1] = 0.0;
+    };
+    if (dur != rtDur) { resetReaders(); rtDur = dur; }                                       // :289-296
+    const bool bufPending = r[rec::SSQ_BUFPENDING] != 0, seqPending = r[rec::SSQ_SEQPENDING] != 0;
+    if (bufPending) { resetReaders(); flags |= 2u; }                                         // :298-304
+    if (seqPending) { prev = -1; next = -1; flags |= 1u; }                                   // :306-316
+    gcfp buf = rec_ptr(r, rec::SSQ_BUF);
+    const uint32_t bufLen = r[rec::SSQ_BUFLEN], seqLen = r[rec::SSQ_SEQLEN];
+    gcfp values = rec_ptr(r, rec::SSQ_SEQ) + 2u * seqLen;
+    auto evTime = [&](uint32_t k) { gcup p = (gcup)(rec_ptr(r, rec::SSQ_SEQ)) + 2u * k; return rec_ld_f64(p, 0); };
+    const bool ok = member_nin(c, m) >= 1 && (flags & 1u) && seqLen > 0 && (flags & 2u) && buf != nullptr && dur > 0.0;
+    uint32_t avail[2] = {0u, 0u};
+    float g0[2] = {0.0f, 0.0f};
+    if (ok) {
+        auto setTarget = [&](int q, float g) { target[q] = g; step[q] = (g < gain[q]) ? -fabsf(step[q]) : fabsf(step[q]); };   // :33-41
+        auto toPos = [&](double p, uint32_t outOfRange) { return (p >= 0.0 && p < 4.0e9) ? (uint32_t)p : outOfRange; };
+        const double t = (double)fetch(c, opnd_uniform(c, m, 0), 0);                         // :332
+        const bool update = (prev < 0 && next < 0) || (prev >= 0 && t <= evTime((uint32_t)prev) + 1e-6)
+                         || (next >= 0 && t >= evTime((uint32_t)next) - 1e-6);               // :337-339
+        bool aligned = true;                                                                  // :94-103
+        if (fabsf(target[active] - 1.0f) <= 1e-6f) {
+            const double p = ((t - start[active]) / rtDur) * (double)(bsz[active] - 1u);
+            const int np = (fabs(p) < 9.2e18) ? (int)(long long)p : 0;
+            const int delta = (int)pos[active] - np;
+            aligned = abs(delta) < 16;
+        }
+        if (update || !aligned) {                                                             // updateEventBoundaries :257-281
+            uint32_t lo = 0, hi = seqLen;                                                     // upper_bound(t)
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (evTime(mid) > t) hi = mid; else lo = mid + 1; }
+            next = lo < seqLen ? (int)lo : -1;
+            if (lo == 0) { prev = -1; setTarget(0, 0.0f); setTarget(1, 0.0f); }
+            else {
+                prev = (int)lo - 1;
+                if (active == 0) setTarget(0, 0.0f); else setTarget(1, 0.0f);
+                active = (active + 1u) & 1u;
+                if (fabsf(values[prev] - 1.0f) <= 1e-6f) {                                    // engage :75-83
+                    const int q = (int)active;
+                    const double st = evTime((uint32_t)prev);
+                    if (q == 0) { start[0] = st; bsz[0] = bufLen; setTarget(0, 1.0f); } else { start[1] = st; bsz[1] = bufLen; setTarget(1, 1.0f); }
+                    const double p = ((t - st) / rtDur) * (double)(bufLen - 1u);
+                    const uint32_t np = min(toPos(p, bufLen), bufLen);
+                    if (q == 0) pos[0] = np; else pos[1] = np;
+                }
+            }
+        }
+        // fade ramps: gains used at frame i, serial only while moving (detail::GainFade::operator() :43-51)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            avail[q] = (pos[q] < bsz[q]) ? min(n, bsz[q] - pos[q]) : 0u;
+            float g = gain[q];
+            uint32_t k = 0;
+            for (; k < avail[q] && g != target[q]; ++k) {
+                if (c.lane == 0) lds[m.scratch + q * kSlotWords + k] = g;
+                g = clampf(g + step[q], 0.0f, 1.0f);
+            }
+            g0[q] = g;                       // constant from frame k on
+            for (uint32_t i = k + c.lane; i < avail[q]; i += 64) lds[m.scratch + q * kSlotWords + i] = g;
+            gain[q] = g;
+        }
+    }
+    (void)g0;
+    WAVE_SYNC();
+    for (uint32_t i = s0 + c.lane; i < s1; i += 64) {
+        float acc = 0.0f;                                                                     // :374-377
+        if (ok) {
+            if (i < avail[0]) acc += buf[pos[0] + i] * lds[m.scratch + i] ;
+            if (i < avail[1]) acc += buf[pos[1] + i] * lds[m.scratch + kSlotWords + i];
+        }
+        put(c, m, i, acc);
+    }
+    WAVE_SYNC();
+    if (c.lane == 0) {
+        rec_st_f64(r, rec::SSQ_RTDUR, rtDur);
+        r[rec::SSQ_PREV] = (uint32_t)prev; r[rec::SSQ_NEXT] = (uint32_t)next; r[rec::SSQ_ACTIVE] = active; r[rec::SSQ_FLAGS] = flags;
+        r[rec::SSQ_BUFPENDING] = 0; r[rec::SSQ_SEQPENDING] = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            gup rr = r + rec::SSQ_READER0 + q * rec::SSQ_READER_DWORDS;
+            rr[0] = f2u(gain[q]); rr[1] = f2u(target[q]); rr[2] = f2u(step[q]); rr[3] = pos[q] + avail[q];
+            rec_st_f64(rr, 4, start[q]); rr[6] = bsz[q];
+        }
+    }
+}
+
 // ---- lane-per-node recurrences ---------------------------------------------------------------
 // Entered by lanes [0, count) of the task's wave; `m` is that lane's node. Every operand of a
 // chain lives in LDS (the planner imports HBM operands first): a block buffer (16-byte aligned,
@@ -1421,6 +1524,7 @@ __device__ __forceinline__ void run_task(const Ctx& c, const TaskU& t, uint32_t 
         case OP_Z:      for_members(c, t, [&](const Member& m) { run_z(c, m, 0, c.n); }); return;
         case OP_SDELAY: for_members(c, t, [&](const Member& m) { run_sdelay(c, m, 0, c.n); }); return;
         case OP_DELAY:  for_members(c, t, [&](const Member& m) { run_delay(c, m, 0, c.n); }); return;
+        case OP_SAMPLESEQ: for_members(c, t, [&](const Member& m) { run_sampleseq(c, m, 0, c.n); }); return;
         case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_ONCE:
         case OP_SEQ: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF: case OP_SVFSHELF:
         case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:

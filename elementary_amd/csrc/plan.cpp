@@ -29,7 +29,7 @@ enum Kind : uint8_t { K_CONST, K_PAR, K_SINGLE, K_CHAIN };
 Kind kindOf(uint16_t op) {
     switch (op) {
         case OP_CONST: case OP_SR: return K_CONST;
-        case OP_RAND: case OP_Z: case OP_SDELAY: case OP_DELAY: return K_SINGLE;
+        case OP_RAND: case OP_Z: case OP_SDELAY: case OP_DELAY: case OP_SAMPLESEQ: return K_SINGLE;
         case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD:
         case OP_ONCE: case OP_SEQ: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
         case OP_SVFSHELF: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
@@ -43,6 +43,7 @@ uint32_t scratchSlots(uint16_t op) {
         case OP_SVF: return 6;        // a1,a2,a3 as double (coefficient pre-pass -> scan)
         case OP_SVFSHELF: return 10;  // a1,a2,a3,k,A
         case OP_DELAY: return 1;
+        case OP_SAMPLESEQ: return 2;  // per-reader fade gains
         default: return 0;
     }
 }
@@ -51,7 +52,7 @@ uint32_t scratchSlots(uint16_t op) {
 uint32_t leafArity(uint16_t op) {
     switch (op) {
         case OP_PHASOR: case OP_COUNTER: case OP_ONCE: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
-        case OP_Z: case OP_SDELAY: case OP_PREWARP: case OP_ROOT: case OP_TAPOUT: return 1;
+        case OP_Z: case OP_SDELAY: case OP_PREWARP: case OP_ROOT: case OP_TAPOUT: case OP_SAMPLESEQ: return 1;
         case OP_SPHASOR: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_SEQ: case OP_POLE: case OP_MM1P: return 2;
         case OP_ENV: case OP_SVF: case OP_DELAY: return 3;
         case OP_SVFSHELF: return 4;

@@ -119,7 +119,7 @@ enum Kind {
     K_ADD, K_SUB, K_MUL, K_DIV, K_MOD, K_MIN, K_MAX,
     K_ROOT, K_CONST, K_PHASOR, K_SPHASOR, K_SR, K_SEQ, K_COUNTER, K_ACCUM, K_LATCH, K_MAXHOLD, K_ONCE, K_RAND,
     K_DELAY, K_SDELAY, K_Z, K_POLE, K_ENV, K_BIQUAD, K_PREWARP, K_MM1P, K_SVF, K_SVFSHELF, K_TAPIN, K_TAPOUT,
-    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO,
+    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ,
 };
 
 // registry names: runtime/elem/DefaultNodeTypes.h:49-144 (hot-path subset) + wasm/Main.cpp:47-61
@@ -135,12 +135,44 @@ const std::unordered_map<std::string, Kind>& registry() {
         {"sdelay", K_SDELAY}, {"z", K_Z}, {"pole", K_POLE}, {"env", K_ENV}, {"biquad", K_BIQUAD}, {"prewarp", K_PREWARP},
         {"mm1p", K_MM1P}, {"svf", K_SVF}, {"svfshelf", K_SVFSHELF}, {"tapIn", K_TAPIN}, {"tapOut", K_TAPOUT},
         {"blepsaw", K_BLEPSAW}, {"blepsquare", K_BLEPSQUARE}, {"bleptriangle", K_BLEPTRIANGLE}, {"time", K_TIME},
-        {"metro", K_METRO},
+        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ},
     };
     return r;
 }
 
 using Buf = std::shared_ptr<std::vector<float>>;
+
+// detail::GainFade + detail::BufferReader<float> of builtins/SampleSeq.h:29-166
+struct SeqReader {
+    float gain = 0, target = 0, step = 0.02f;
+    const float* buffer = nullptr; size_t bufferSize = 0, position = 0;
+    double sampleDuration = 0, startTime = 0;
+    void setTarget(float g) { target = g; step = (target < gain) ? -std::abs(step) : std::abs(step); }          // :33-41
+    bool on() const { return std::abs(target - 1.0f) <= 1e-6f; }                                                 // :53-55
+    void engage(double start, double now, const float* b, size_t size) {                                         // :75-83
+        startTime = start; buffer = b; bufferSize = size; setTarget(1.0f);
+        const double p = ((now - startTime) / sampleDuration) * (double)(bufferSize - 1u);
+        position = (p >= 0.0 && p < 1.8e19) ? (size_t)p : bufferSize;   // size_t cast of a negative double: out of range
+        position = std::min(std::max<size_t>(position, 0), bufferSize);
+    }
+    bool aligned(double t) const {                                                                               // :94-103
+        if (!on()) return true;
+        const double p = ((t - startTime) / sampleDuration) * (double)(bufferSize - 1u);
+        const int np = (std::abs(p) < 9.2e18) ? (int)(int64_t)p : 0;   // x86-64 size_t cast of a double, then the :99 int cast
+        const int delta = (int)position - np;
+        return std::abs(delta) < 16;
+    }
+    void readAdding(float* out, size_t n) {                                                                      // :105-110, :43-51
+        for (size_t i = 0; i < n && position < bufferSize; ++i) {
+            const float x = buffer[position++];
+            float y;
+            if (gain == target) y = gain * x;
+            else { y = x * gain; gain = std::min(std::max(gain + step, 0.0f), 1.0f); }
+            out[i] += y;
+        }
+    }
+    void reset(double dur) { gain = 0; target = 0; sampleDuration = dur; startTime = 0; }                        // :149-155
+};
 
 struct Node {
     int32_t id = 0; Kind kind = K_CONST;
@@ -158,6 +190,13 @@ struct Node {
     std::vector<float> ring, newRing; int writeIndex = 0;
     std::vector<float> seq, newSeq; size_t seqIndex = 0;
     std::vector<float> tapPrivate; Buf tapShared, pendingTap; bool tapPending = false;
+    // sampleseq (SampleSeq.h:169-404)
+    double sampleDuration = 0, rtSampleDuration = 0;
+    std::vector<std::pair<double, float>> seqEvents, newSeqEvents; bool pendingEvents = false, haveEvents = false;
+    int prevEvent = -1, nextEvent = -1;            // -1 == end()
+    Buf sampleBuf, pendingSampleBuf; bool samplePending = false;
+    SeqReader readers[2]; size_t activeReader = 0; size_t sampleLen = 0, pendingSampleLen = 0;
+    size_t sampleBufSize() const { return sampleLen; }
     std::vector<float> out;      // this node's block buffer (one per node, never aliased)
 };
 
@@ -183,6 +222,7 @@ struct Oracle {
     std::unordered_map<int32_t, Node> nodes;
     std::set<int32_t> currentRoots;
     std::unordered_map<std::string, Buf> resources;
+    std::unordered_map<std::string, size_t> resourceLen;   // true sample count (tap-sized padding excluded)
     std::shared_ptr<Sequence> current, pending;
 
     Oracle(double sampleRate, int blockSize) : sr(sampleRate), bs(blockSize) {}
@@ -273,6 +313,27 @@ struct Oracle {
                 break;
             case K_TAPIN: case K_TAPOUT:                                                                  // Feedback.h:24-38, 70-84
                 if (key == "name") { if (!str) return 5; n.pendingTap = tapResource(v.s); n.tapPending = true; }
+                break;
+            case K_SAMPLESEQ:                                                                             // SampleSeq.h:181-255
+                if (key == "duration") { if (!num) return 5; if (v.n <= 0.0) return 6; n.sampleDuration = v.n; }
+                if (key == "path") {
+                    if (!str) return 5;
+                    auto r = resources.find(v.s);
+                    if (r == resources.end()) return 6;
+                    n.pendingSampleBuf = r->second; n.samplePending = true; n.pendingSampleLen = resourceLen[v.s];
+                }
+                if (key == "seq") {
+                    if (v.t != JV::Arr) return 5;
+                    std::map<double, float> m;
+                    for (const JV& e : v.a) {
+                        if (e.t != JV::Obj) return 5;
+                        const JV* val = nullptr; const JV* tm = nullptr;
+                        for (auto& kv : e.o) { if (kv.first == "value") val = &kv.second; if (kv.first == "time") tm = &kv.second; }
+                        if (!val || !tm || val->t != JV::Num || tm->t != JV::Num) return 5;
+                        m.insert({tm->n, (float)val->n});   // std::map::insert keeps the first entry of a key
+                    }
+                    n.newSeqEvents.assign(m.begin(), m.end()); n.pendingEvents = true;
+                }
                 break;
             case K_METRO:                                                                                 // wasm/Metro.h:18-34
                 if (key == "interval") { if (!num) return 5; if (0 >= v.n) return 6; n.interval = (int64_t)std::max(2.0, v.n * 0.001 * sr); }
@@ -688,6 +749,35 @@ struct Oracle {
                 }
                 break;
             }
+            case K_SAMPLESEQ: {                                                                           // SampleSeq.h:283-379
+                const double dur = n.sampleDuration;
+                if (dur != n.rtSampleDuration) { n.readers[0].reset(dur); n.readers[1].reset(dur); n.rtSampleDuration = dur; }
+                if (n.samplePending) { n.sampleBuf = n.pendingSampleBuf; n.sampleLen = n.pendingSampleLen; n.samplePending = false; n.readers[0].reset(dur); n.readers[1].reset(dur); }
+                if (n.pendingEvents) { n.seqEvents.swap(n.newSeqEvents); n.pendingEvents = false; n.haveEvents = true; n.prevEvent = n.nextEvent = -1; }
+                if (nIn < 1 || !n.haveEvents || n.seqEvents.empty() || !n.sampleBuf || dur <= 0.0) { zero(); break; }
+                const auto& ev = n.seqEvents;
+                const double t = (double)in[0][0];
+                const bool update = (n.prevEvent < 0 && n.nextEvent < 0)
+                    || (n.prevEvent >= 0 && t <= ev[(size_t)n.prevEvent].first + 1e-6)
+                    || (n.nextEvent >= 0 && t >= ev[(size_t)n.nextEvent].first - 1e-6);
+                if (update || !n.readers[n.activeReader].aligned(t)) {                                    // updateEventBoundaries :257-281
+                    size_t ub = 0;
+                    while (ub < ev.size() && !(ev[ub].first > t)) ++ub;                                   // upper_bound
+                    n.nextEvent = ub < ev.size() ? (int)ub : -1;
+                    if (ub == 0) { n.prevEvent = -1; n.readers[0].setTarget(0.0f); n.readers[1].setTarget(0.0f); }
+                    else {
+                        n.prevEvent = (int)ub - 1;
+                        n.readers[n.activeReader].setTarget(0.0f);
+                        n.activeReader = (n.activeReader + 1) & 1;
+                        if (std::abs(ev[(size_t)n.prevEvent].second - 1.0f) <= 1e-6f)
+                            n.readers[n.activeReader].engage(ev[(size_t)n.prevEvent].first, t, n.sampleBuf->data(), n.sampleBufSize());
+                    }
+                }
+                zero();
+                n.readers[0].readAdding(out, N);
+                n.readers[1].readAdding(out, N);
+                break;
+            }
             case K_TIME:                                                                                  // wasm/SampleTime.h:14-22
                 for (size_t i = 0; i < N; ++i) out[i] = (float)(double)((uint64_t)sampleTime + (uint64_t)i);
                 break;
@@ -778,6 +868,7 @@ int elemoracle_add_shared_resource(void* h, const char* name, const float* const
     auto* o = static_cast<Oracle*>(h);
     if (o->resources.count(name)) return 0;   // insert-only (SharedResource.h:61-63)
     auto r = std::make_shared<std::vector<float>>(nCh ? std::vector<float>(ch[0], ch[0] + nSamples) : std::vector<float>());
+    o->resourceLen[name] = r->size();
     if (r->size() < (size_t)o->bs) r->resize((size_t)o->bs, 0.0f);
     o->resources.emplace(name, r);
     return 1;

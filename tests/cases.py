@@ -72,3 +72,37 @@ NODE_CASES = {
 }
 
 
+
+
+def sampleseq_scenario(make, block=32, sr=44100.0):
+    """sampleseq.test.js:5-76 ("sampleseq basics") extended: the time input is a ref'd const the
+    host steps; covers onset/offset fades, a backwards jump, a seq swap, a duration change, a new
+    sample buffer and running past the end of the sample. Returns [blocks, 1, block]."""
+    import numpy as np
+    rt = make(sr, block)
+    ramp = (np.arange(300, dtype=np.float32) / 300.0 + 0.25).astype(np.float32)
+    assert rt.add_shared_resource("/v/ones", np.ones(128, np.float32))
+    assert rt.add_shared_resource("/v/ramp", ramp)
+    t_node, set_time = rt.renderer.create_ref("const", {"value": 0}, [])
+    seq_node, set_seq = rt.renderer.create_ref("sampleseq", {
+        "duration": 128, "path": "/v/ones",
+        "seq": [{"time": 0, "value": 0}, {"time": 128, "value": 1}, {"time": 256, "value": 0}, {"time": 512, "value": 1}],
+    }, [t_node])
+    assert rt.render(seq_node)["result"] == 0
+    ys = []
+
+    def run(times):
+        for t in times:
+            if t is not None:
+                assert set_time({"value": t}) == 0
+            ys.append(rt.process(None, 1, block))
+
+    run([None] * 4)                                   # before the first onset; root fade-in settles
+    run([129, 129 + block, 129 + 2 * block])         # onset: fade in 0, .02, .04 ...
+    run([260, 260 + block])                           # offset: fade out
+    run([64, 520, 520 + block, 520 + 2 * block, 520 + 3 * block, 520 + 4 * block])   # backwards jump, 2nd onset, run off the end
+    assert set_seq({"seq": [{"time": 10, "value": 1}, {"time": 700, "value": 0}, {"time": 10, "value": 0}]}) == 0
+    run([40, 40 + block, 300])                        # new seq (duplicate time keeps the first entry); misaligned jump
+    assert set_seq({"duration": 300, "path": "/v/ramp"}) == 0
+    run([100, 100 + block, 100 + 2 * block, 720, 0])
+    return np.stack(ys)

@@ -30,7 +30,7 @@ def _engines():
     return hip, chk
 
 
-from cases import NODE_CASES
+from cases import NODE_CASES, sampleseq_scenario
 
 
 @pytest.mark.parametrize("name", sorted(NODE_CASES))
@@ -125,3 +125,12 @@ def test_root_fade_and_switch_back(gpu_required):
         outs.append(np.stack(ys))
     assert float(np.abs(outs[0] - outs[1]).max()) <= TOL
     assert np.allclose(outs[1][-1], 6.0)
+
+
+@pytest.mark.parametrize("block", [32, 512])
+def test_sampleseq_scenario(gpu_required, block):
+    """sampleseq.test.js:5-76 script (onset/offset fades, jumps, seq/buffer/duration swaps)."""
+    hip, chk = _engines()
+    a, b = sampleseq_scenario(hip, block=block), sampleseq_scenario(chk, block=block)
+    assert np.abs(b).max() > 0.5
+    assert float(np.abs(a - b).max()) <= TOL

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle
-from cases import NODE_CASES
+from cases import NODE_CASES, sampleseq_scenario
 from elementary_amd import graphs
 from helpers import render_pair
 
@@ -60,3 +60,12 @@ def test_gc_matches_reference():
         res.append((sorted(first), sorted(second), sorted(third)))
     assert res[0] == res[1]
     assert res[0][0] == [] and len(res[0][2]) > 0
+
+
+def test_sampleseq_scenario_bit_exact():
+    """builtins/SampleSeq.h: restatement vs the reference engine over the sampleseq.test.js script."""
+    a, b = sampleseq_scenario(port), sampleseq_scenario(ref)
+    assert np.array_equal(a, b)
+    assert np.abs(b).max() > 0.5
+    a, b = sampleseq_scenario(port, block=512), sampleseq_scenario(ref, block=512)
+    assert np.array_equal(a, b)
