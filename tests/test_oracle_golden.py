@@ -35,6 +35,10 @@ def core_factory(request):
         c = OfflineRenderer(request.param[1])
         c.initialize(**kw)
         return c
+
+    def same(got, want):      # the CPU engines reproduce the recorded float32 snapshots exactly
+        assert got.tolist() == list(want)
+    make.same = same
     return make
 
 
@@ -48,7 +52,7 @@ def test_the_basics(core_factory):
     core.render(el.mul(2, 3))
     out = [f32(5120)]
     core.process([f32(5120)], out)
-    assert out[0][512 * 8:512 * 9].tolist() == GOLD["offline-renderer:the basics 1"]
+    core_factory.same(out[0][512 * 8:512 * 9], GOLD["offline-renderer:the basics 1"])
 
 
 def test_switch_and_switch_back(core_factory):
@@ -57,9 +61,9 @@ def test_switch_and_switch_back(core_factory):
     out = [f32(5120)]
     core.render(el.mul(2, 3)); core.process([], out)
     core.render(el.mul(3, 4)); core.process([], out)
-    assert out[0][4096:4128].tolist() == GOLD["offline-renderer:switch and switch back 1"]
+    core_factory.same(out[0][4096:4128], GOLD["offline-renderer:switch and switch back 1"])
     core.render(el.mul(2, 3)); core.process([], out)
-    assert out[0][4096:4128].tolist() == GOLD["offline-renderer:switch and switch back 2"]
+    core_factory.same(out[0][4096:4128], GOLD["offline-renderer:switch and switch back 2"])
 
 
 def test_child_limit(core_factory):
@@ -68,7 +72,7 @@ def test_child_limit(core_factory):
     core.render(create_node("add", {}, [1] * 100))
     out = [f32(5120)]
     core.process([], out)
-    assert out[0][4096:4128].tolist() == GOLD["offline-renderer:child limit 1"]
+    core_factory.same(out[0][4096:4128], GOLD["offline-renderer:child limit 1"])
 
 
 def test_render_stats_and_invalid_property(core_factory):
@@ -87,7 +91,7 @@ def test_delay_basics(core_factory):
     core.process([f32(5120)], [f32(5120)])
     out = [f32(4)]
     core.process([np.array([1, 2, 3, 4], dtype=np.float32)], out)
-    assert out[0].tolist() == GOLD["delays:delay basics 1"]
+    core_factory.same(out[0], GOLD["delays:delay basics 1"])
 
 
 def test_delay_zero_time(core_factory):
@@ -97,7 +101,7 @@ def test_delay_zero_time(core_factory):
     core.process([f32(5120)], [f32(5120)])
     out = [f32(4)]
     core.process([np.array([1, 2, 3, 4], dtype=np.float32)], out)
-    assert out[0].tolist() == [1, 2, 3, 4]
+    core_factory.same(out[0], [1, 2, 3, 4])
 
 
 def test_sdelay_basics(core_factory):
@@ -108,7 +112,7 @@ def test_sdelay_basics(core_factory):
     x = np.array([1, 2, 3, 4, 4, 3, 2, 1] + [0] * 16, dtype=np.float32)
     out = [f32(24)]
     core.process([x], out)
-    assert out[0].tolist() == GOLD["delays:sdelay basics 1"]
+    core_factory.same(out[0], GOLD["delays:sdelay basics 1"])
 
 
 def test_feedback_taps(core_factory):
@@ -120,7 +124,7 @@ def test_feedback_taps(core_factory):
     for k in (1, 2, 3):
         out = [f32(512)]
         core.process([ones], out)
-        assert out[0].tolist() == GOLD[f"tap:feedback taps {k}"]
+        core_factory.same(out[0], GOLD[f"tap:feedback taps {k}"])
 
 
 def test_time_node(core_factory):
@@ -130,12 +134,52 @@ def test_time_node(core_factory):
     core.process([f32(5120)], [f32(5120)])
     out = [f32(32)]
     core.process([f32(32)], out)
-    assert out[0].tolist() == GOLD["time:time node 1"]
+    core_factory.same(out[0], GOLD["time:time node 1"])
     core = core_factory(num_input_channels=0, num_output_channels=1)
     core.render(el.time())
     core.process([], [f32(5120)])
     out = [f32(8)]
     core.set_current_time(50); core.process([], out)
-    assert out[0].tolist() == [50, 51, 52, 53, 54, 55, 56, 57]
+    core_factory.same(out[0], [50, 51, 52, 53, 54, 55, 56, 57])
     core.set_current_time_ms(1000); core.process([], out)
-    assert out[0].tolist() == [44100 + i for i in range(8)]
+    core_factory.same(out[0], [44100 + i for i in range(8)])
+
+
+def test_sampleseq_basics(core_factory):
+    """sampleseq.test.js:5-129 against its four recorded snapshots."""
+    core = core_factory(num_input_channels=0, num_output_channels=1, block_size=32,
+                        virtual_file_system={"/v/ones": np.ones(128, np.float32)})
+    time, set_time = core.create_ref("const", {"value": 0}, [])
+    core.render(el.sampleseq({"path": "/v/ones", "duration": 128, "seq": [
+        {"time": 0, "value": 0}, {"time": 128, "value": 1}, {"time": 256, "value": 0}, {"time": 512, "value": 1}]}, time))
+    core.process([], [f32(10 * 512)])
+    out = [f32(32)]
+    core.process([], out)
+    core_factory.same(out[0], GOLD["sampleseq:sampleseq basics 1"])
+    set_time({"value": 129}); core.process([], out)
+    assert all(0 <= out[0][i] < 1 and out[0][i] > out[0][i - 1] for i in range(1, 32))
+    for i in range(2):
+        set_time({"value": 129 + (i + 1) * 32}); core.process([], out)
+    core_factory.same(out[0], GOLD["sampleseq:sampleseq basics 2"])
+    set_time({"value": 64}); core.process([], out)
+    assert all(0 <= out[0][i] < 1 and out[0][i] < out[0][i - 1] for i in range(1, 32))
+    for _ in range(10):
+        core.process([], out)
+    core_factory.same(out[0], GOLD["sampleseq:sampleseq basics 3"])
+    set_time({"value": 520}); core.process([], out)
+    assert all(0 <= v < 1 for v in out[0])
+    for i in range(2):
+        set_time({"value": 520 + (i + 1) * 32}); core.process([], out)
+    core_factory.same(out[0], GOLD["sampleseq:sampleseq basics 4"])
+
+
+def test_maxhold_snapshots(core_factory):
+    """maxhold.test.js:5-31 and :33-70."""
+    for props, key, x in (({}, "maxhold:maxhold basics 1", [1, 2, 3, 4, 3, 2, 1]),
+                          ({"hold": 1}, "maxhold:maxhold hold time 1", [1, 2, 3, 4, 3, 2, 1, 1] + [1] * 40)):
+        core = core_factory(num_input_channels=1, num_output_channels=1)
+        core.render(el.maxhold(props, el.in_({"channel": 0}), 0))
+        core.process([f32(5120)], [f32(5120)])
+        out = [f32(len(x))]
+        core.process([np.asarray(x, np.float32)], out)
+        core_factory.same(out[0], GOLD[key])
