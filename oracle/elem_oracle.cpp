@@ -13,6 +13,7 @@
 //
 // Build: g++ -std=c++17 -O2 -ffp-contract=off (oracle/Makefile `port`). No FMA contraction: the
 // reference's float recurrences are only reproducible op for op.
+#include "fftconv_oracle.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -119,7 +120,7 @@ enum Kind {
     K_ADD, K_SUB, K_MUL, K_DIV, K_MOD, K_MIN, K_MAX,
     K_ROOT, K_CONST, K_PHASOR, K_SPHASOR, K_SR, K_SEQ, K_COUNTER, K_ACCUM, K_LATCH, K_MAXHOLD, K_ONCE, K_RAND,
     K_DELAY, K_SDELAY, K_Z, K_POLE, K_ENV, K_BIQUAD, K_PREWARP, K_MM1P, K_SVF, K_SVFSHELF, K_TAPIN, K_TAPOUT,
-    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ,
+    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ, K_CONVOLVE,
 };
 
 // registry names: runtime/elem/DefaultNodeTypes.h:49-144 (hot-path subset) + wasm/Main.cpp:47-61
@@ -135,7 +136,7 @@ const std::unordered_map<std::string, Kind>& registry() {
         {"sdelay", K_SDELAY}, {"z", K_Z}, {"pole", K_POLE}, {"env", K_ENV}, {"biquad", K_BIQUAD}, {"prewarp", K_PREWARP},
         {"mm1p", K_MM1P}, {"svf", K_SVF}, {"svfshelf", K_SVFSHELF}, {"tapIn", K_TAPIN}, {"tapOut", K_TAPOUT},
         {"blepsaw", K_BLEPSAW}, {"blepsquare", K_BLEPSQUARE}, {"bleptriangle", K_BLEPTRIANGLE}, {"time", K_TIME},
-        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ},
+        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ}, {"convolve", K_CONVOLVE},
     };
     return r;
 }
@@ -197,6 +198,8 @@ struct Node {
     Buf sampleBuf, pendingSampleBuf; bool samplePending = false;
     SeqReader readers[2]; size_t activeReader = 0; size_t sampleLen = 0, pendingSampleLen = 0;
     size_t sampleBufSize() const { return sampleLen; }
+    // convolve (wasm/Convolve.h:23-92)
+    std::shared_ptr<fftconv_oracle::TwoStageConvolver> convolver, pendingConvolver;
     std::vector<float> out;      // this node's block buffer (one per node, never aliased)
 };
 
@@ -333,6 +336,16 @@ struct Oracle {
                         m.insert({tm->n, (float)val->n});   // std::map::insert keeps the first entry of a key
                     }
                     n.newSeqEvents.assign(m.begin(), m.end()); n.pendingEvents = true;
+                }
+                break;
+            case K_CONVOLVE:                                                                              // wasm/Convolve.h:34-56
+                if (key == "path") {
+                    if (!str) return 5;
+                    auto r = resources.find(v.s);
+                    if (r == resources.end()) return 6;
+                    auto co = std::make_shared<fftconv_oracle::TwoStageConvolver>();
+                    co->init(512, 4096, r->second->data(), resourceLen[v.s]);
+                    n.pendingConvolver = co;
                 }
                 break;
             case K_METRO:                                                                                 // wasm/Metro.h:18-34
@@ -778,6 +791,11 @@ struct Oracle {
                 n.readers[1].readAdding(out, N);
                 break;
             }
+            case K_CONVOLVE:                                                                              // wasm/Convolve.h:58-84
+                if (n.pendingConvolver) { n.convolver = n.pendingConvolver; n.pendingConvolver.reset(); }
+                if (nIn == 0 || !n.convolver) { zero(); break; }
+                n.convolver->process(in[0], out, N);
+                break;
             case K_TIME:                                                                                  // wasm/SampleTime.h:14-22
                 for (size_t i = 0; i < N; ++i) out[i] = (float)(double)((uint64_t)sampleTime + (uint64_t)i);
                 break;
