@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Secondary configurations of BASELINE.json (C1, C3, C4, C5) on ONE GPU, each with the CPU engine
+timed beside it on one host core.  bench.py (C2) is the headline number; this script produces the
+other rows of DESIGN.md's measurement table.  One JSON line per configuration.
+
+    python benchmarks/bench_configs.py [c1] [c3] [c4] [c5] [--blocks N]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+BLOCK = 512
+
+
+def _cpu_engine(sr, use_ref=True):
+    import oracle
+    if use_ref and oracle.have_ref():
+        return oracle.RefRuntime(sr, BLOCK, bench_build=os.path.exists(oracle.REF_BENCH_SO)), "reference"
+    return oracle.PortRuntime(sr, BLOCK), "port"
+
+
+def _time_cpu(rt, n_in, n_out, x=None, budget=6.0, warm=8):
+    import numpy as np
+    xin = None if n_in == 0 else (x if x is not None else np.zeros((n_in, BLOCK), np.float32))
+    for _ in range(warm):
+        rt.process(xin, n_out, BLOCK)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        rt.process(xin, n_out, BLOCK)
+    per = (time.perf_counter() - t0) / 20
+    m = int(max(50, min(5000, budget / per)))
+    t0 = time.perf_counter()
+    for _ in range(m):
+        rt.process(xin, n_out, BLOCK)
+    return (time.perf_counter() - t0) / m, m
+
+
+def _time_gpu(rt, n_in, n_out, blocks, xin=None):
+    import torch
+    out = torch.empty((min(blocks, 256), n_out, BLOCK), dtype=torch.float32, device="cuda")
+    chunk = out.shape[0]
+
+    def run(total):
+        done = 0
+        while done < total:
+            c = min(chunk, total - done)
+            rt.process_blocks(c, n_out, out_ptr=out.data_ptr(), in_ptr=(xin.data_ptr() if xin is not None else 0), num_inputs=n_in)
+            done += c
+    run(chunk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(blocks)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / blocks
+
+
+def c1(args):
+    from elementary_amd import graphs
+    from elementary_amd.runtime import Runtime
+    rt = Runtime(44100.0, BLOCK, device=0)
+    assert rt.render(*graphs.c1_graph())["result"] == 0
+    g = _time_gpu(rt, 0, 2, args.blocks)
+    cpu, kind = _cpu_engine(44100.0)
+    assert cpu.render(*graphs.c1_graph())["result"] == 0
+    c, m = _time_cpu(cpu, 0, 2)
+    lv = rt.time_launches(2, 200)
+    return {"config": "C1 cli/Benchmark graph (18 nodes, sr 44100)", "gpu_us_per_block": 1e6 * g, "gpu_samples_per_s": BLOCK / g,
+            "cpu_us_per_block": 1e6 * c, "cpu_kind": kind, "cpu_blocks_timed": m, "speedup": c / g,
+            "launch_us": [1e3 * v for v in lv], "note": "latency-bound: one serial phasor -> svf chain per channel"}
+
+
+def c3(args):
+    import numpy as np
+    import torch
+    from elementary_amd import graphs
+    from elementary_amd.runtime import Runtime
+    ch = graphs.C3_CHANNELS
+    rt = Runtime(graphs.C3_SAMPLE_RATE, BLOCK, device=0)
+    irs = [graphs.c3_impulse_response(c) for c in range(ch)]
+    for c in range(ch):
+        assert rt.add_shared_resource(f"ir{c}", irs[c])
+    assert rt.render(*graphs.c3_graph(ch))["result"] == 0
+    x = graphs.c3_input(ch, 64 * BLOCK)
+    xin = torch.from_numpy(np.ascontiguousarray(x.reshape(ch, 64, BLOCK).transpose(1, 0, 2))).cuda().repeat(4, 1, 1).contiguous()
+    g = _time_gpu(rt, ch, ch, args.blocks, xin)
+    lv = rt.time_launches(ch, 200)
+    cpu, kind = _cpu_engine(graphs.C3_SAMPLE_RATE, use_ref=False)   # convolve exists only in the restatement (and the wasm build)
+    for c in range(ch):
+        assert cpu.add_shared_resource(f"ir{c}", irs[c])
+    assert cpu.render(*graphs.c3_graph(ch))["result"] == 0
+    c, m = _time_cpu(cpu, ch, ch, x[:, :BLOCK].copy())
+    alg = graphs.c3_algorithmic_bytes(ch)
+    conv_us = 1e3 * lv[1] if len(lv) > 2 else None
+    return {"config": "C3 8-channel convolution reverb, 96 000-tap IRs, sr 48000", "gpu_us_per_block": 1e6 * g,
+            "gpu_samples_per_s": BLOCK / g, "cpu_us_per_block": 1e6 * c, "cpu_kind": kind + " (plain radix-2 FFT, not Ooura)",
+            "cpu_blocks_timed": m, "speedup": c / g, "launch_us": [1e3 * v for v in lv],
+            "algorithmic_bytes_per_block": alg, "conv_kernel_us": conv_us,
+            "conv_kernel_GBps_algorithmic": (alg / (conv_us * 1e-6) / 1e9) if conv_us else None,
+            "spectra_bytes_read_per_block": ch * 2 * 188 * 512 * 8}
+
+
+def c4(args):
+    from elementary_amd import graphs
+    from elementary_amd.runtime import Runtime
+    inst = args.instances
+    rt = Runtime(graphs.C4_SAMPLE_RATE, BLOCK, device=0)
+    roots = [graphs.c4_instance(k) for k in range(inst)]
+    t0 = time.perf_counter()
+    assert rt.render(*roots)["result"] == 0
+    build = time.perf_counter() - t0
+    g = _time_gpu(rt, 0, inst, args.blocks)
+    lv = rt.time_launches(inst, 100)
+    cpu, kind = _cpu_engine(graphs.C4_SAMPLE_RATE)
+    sub = min(inst, 16)
+    assert cpu.render(*roots[:sub])["result"] == 0
+    c, m = _time_cpu(cpu, 0, sub, budget=4.0)
+    c_all = c * inst / sub
+    return {"config": f"C4 {inst} independent offline render instances on one GPU (of 1024 over 8), sr 48000",
+            "gpu_us_per_block_step": 1e6 * g, "gpu_instance_samples_per_s": inst * BLOCK / g,
+            "cpu_us_per_block_step_1core": 1e6 * c_all, "cpu_kind": kind, "cpu_sample": f"{sub} instances x {m} blocks, scaled to {inst}",
+            "speedup_vs_1core": c_all / g, "launch_us": [1e3 * v for v in lv], "plan_build_ms": 1e3 * build,
+            "algorithmic_bytes_per_block_step": graphs.c4_algorithmic_bytes(inst)}
+
+
+def c5(args):
+    """Dynamic graph: 128 live C2 voices; each batch replaces one voice the way the reconciler does
+    (new voice nodes + new mix adds + new roots), gc() every 16 batches."""
+    from elementary_amd import graphs
+    from elementary_amd.runtime import Runtime
+    voices = 128
+    rt = Runtime(graphs.C2_SAMPLE_RATE, BLOCK, device=0)
+
+    def roots_for(gen):
+        # voice slot s plays voice index s + 128 * (number of times it was replaced)
+        vs = [graphs.c2_voice(s + voices * gen[s]) for s in range(voices)]
+        from elementary_amd import el
+        return [el.add(*[vs[s] for s in range(voices) if s % 2 == ch]) for ch in range(2)]
+    gen = [0] * voices
+    assert rt.render(*roots_for(gen))["result"] == 0
+    static = _time_gpu(rt, 0, 2, 2048)
+    commit_ms, first_block_ms, nodes_added = [], [], []
+    t_start = time.perf_counter()
+    blocks = 0
+    for b in range(args.batches):
+        gen[b % voices] += 1
+        t0 = time.perf_counter()
+        res = rt.render(*roots_for(gen))
+        t1 = time.perf_counter()
+        assert res["result"] == 0
+        rt.process(None, 2, BLOCK)
+        t2 = time.perf_counter()
+        commit_ms.append(1e3 * (t1 - t0)); first_block_ms.append(1e3 * (t2 - t1)); nodes_added.append(res["nodesAdded"])
+        rt.process_blocks(32, 2)
+        blocks += 33
+        if b % 16 == 15:
+            rt.gc()
+    total = time.perf_counter() - t_start
+    commit_ms.sort(); first_block_ms.sort()
+    pct = lambda a, q: a[min(len(a) - 1, int(q * len(a)))]
+    st = rt.stats()
+    return {"config": "C5 dynamic graph: 128 live voices (~2060 nodes), one voice replaced per batch, gc every 16",
+            "static_us_per_block": 1e6 * static, "batches": args.batches, "nodes_added_per_batch": sum(nodes_added) / len(nodes_added),
+            "render_call_ms_p50": pct(commit_ms, 0.5), "render_call_ms_p99": pct(commit_ms, 0.99),
+            "first_block_after_commit_ms_p50": pct(first_block_ms, 0.5), "first_block_after_commit_ms_p99": pct(first_block_ms, 0.99),
+            "plan_build_ms_last": st["last_plan_build_ms"], "frames_per_s_under_mutation": blocks * BLOCK / total,
+            "note": "render call = Python reconciler + JSON + apply_instructions (graph mutation + plan build + upload); "
+                    "33 blocks rendered per batch"}
+
+
+def main():
+    import torch   # before libelemhip.so: both must bind the same HIP runtime, torch's loads first
+    assert torch.cuda.is_available(), "needs a GPU"
+    torch.cuda.init()
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="*", default=["c1", "c3", "c4", "c5"])
+    ap.add_argument("--blocks", type=int, default=2048)
+    ap.add_argument("--instances", type=int, default=128)
+    ap.add_argument("--batches", type=int, default=64)
+    args = ap.parse_args()
+    for name in args.configs:
+        out = {"c1": c1, "c3": c3, "c4": c4, "c5": c5}[name](args)
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

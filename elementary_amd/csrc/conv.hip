@@ -1,0 +1,258 @@
+// conv.hip — the `convolve` node (reference: wasm/Convolve.h:23-92 -> fftconvolver::TwoStageFFTConvolver,
+// an un-vendored third-party library) as a uniformly partitioned frequency-domain convolver for gfx950.
+//
+// What the reference computes is a zero-latency linear convolution of the node's input with channel 0
+// of a shared resource (trailing |h| < 1e-6 dropped), restarted from silence whenever `path` is set.
+// The reference's head(512) / tail0(512, one 4096 period late) / tail(4096, two periods late) schedule
+// exists to spread CPU work; on the GPU the same sum is evaluated with ONE partition size (512):
+//
+//     Y_b = H_0 X_b + H_1 X_{b-1} + sum_{p>=2} H_p X_{b-p}          (1024-point spectra, 512 bins + packed Nyquist)
+//
+//   * main workgroup (one per node, the latency path): FFT of the current input block, the two newest
+//     products, + the pre-multiplied older-partition sum, inverse FFT, overlap-add.
+//   * helper workgroups (8 bin groups x S slices per node, off the latency path): during block b they
+//     build the older-partition sum of block b+1 from spectra that are already final; every IR spectrum
+//     is read once per block, coalesced, by exactly one wave.
+// A call of fewer than 512 frames re-transforms the partially filled input block exactly like the
+// reference does (FFTConvolver::process with a partial _inputBuffer); a call that straddles two input
+// blocks computes the second block's older-partition sum in the main workgroup (slow path, odd sizes only).
+// Results differ from the reference's Ooura-FFT arithmetic by float rounding (~1e-7 relative); the parity
+// bar for this node is 1e-6 abs on |y| <~ 1 (SURVEY.md 8(d) C3 note).
+#include <hip/hip_runtime.h>
+
+#include "device.h"
+#include "launch.h"
+
+using namespace elemhip;
+
+namespace {
+
+typedef __attribute__((address_space(1))) float* gfp;
+typedef __attribute__((address_space(1))) const float* gcfp;
+typedef __attribute__((address_space(1))) uint32_t* gup;
+typedef __attribute__((address_space(1))) const uint32_t* gcup;
+typedef float c2 __attribute__((ext_vector_type(2)));   // complex float (x = re, y = im)
+typedef __attribute__((address_space(1))) c2* gf2p;
+typedef __attribute__((address_space(1))) const c2* gcf2p;
+__device__ __forceinline__ c2 mk(float re, float im) { c2 v; v.x = re; v.y = im; return v; }
+
+__device__ c2 kTwiddle[conv::kFft];     // cis(-2 pi k / 1024), rounded from double on the host
+
+__device__ __forceinline__ c2 cmul(c2 a, c2 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// spectrum product; bin 0 carries two real bins (DC, Nyquist)
+__device__ __forceinline__ c2 smul(c2 h, c2 x, bool packed) {
+    return packed ? mk(h.x * x.x, h.y * x.y) : cmul(h, x);
+}
+__device__ __forceinline__ c2 cadd(c2 a, c2 b) { return mk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ c2 csub(c2 a, c2 b) { return mk(a.x - b.x, a.y - b.y); }
+
+// 1024-point forward FFT, Stockham radix-4 autosort, 256 threads, 5 passes LDS a -> b -> a ...; the
+// result lands in `b` (odd number of passes), in natural order.
+__device__ __forceinline__ void fft1024(c2* a, c2* b, const c2* W, uint32_t tid) {
+#pragma unroll
+    for (uint32_t s = 0; s < 5; ++s) {
+        const uint32_t Ns = 1u << (2u * s), k = tid & (Ns - 1u), tw = 256u >> (2u * s);
+        c2 v0 = a[tid], v1 = a[tid + 256u], v2 = a[tid + 512u], v3 = a[tid + 768u];
+        if (s > 0) { v1 = cmul(v1, W[k * tw]); v2 = cmul(v2, W[2u * k * tw]); v3 = cmul(v3, W[3u * k * tw]); }
+        const c2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), t = csub(v1, v3);
+        const c2 a3 = mk(t.y, -t.x);                      // (v1 - v3) * -i
+        const uint32_t idx = ((tid - k) << 2) + k;
+        b[idx] = cadd(a0, a2); b[idx + Ns] = cadd(a1, a3); b[idx + 2u * Ns] = csub(a0, a2); b[idx + 3u * Ns] = csub(a1, a3);
+        __syncthreads();
+        c2* t2 = a; a = b; b = t2;
+    }
+}
+
+__device__ __forceinline__ bool root_running(gcup recs, uint32_t rootRec, uint32_t numOut) {   // Core.h:28-31, GraphRenderSequence.h:218-219
+    gcup r = recs + rootRec * kRecDwords;
+    const float tg = __uint_as_float(r[rec::ROOT_TARGET]), g = __uint_as_float(r[rec::ROOT_GAIN]);
+    const int ch = (int)r[rec::ROOT_CHANNEL];
+    return (tg > 0.5f || !(fabsf(tg - g) <= 1e-6f)) && ch >= 0 && (uint32_t)ch < numOut;
+}
+
+struct State {
+    gup hdr; gcf2p H; gf2p X; gf2p pre; gf2p preSlow; gfp inbuf; gfp overlap;
+    uint32_t P, S;
+};
+__device__ __forceinline__ State state_of(gup base) {
+    State st;
+    st.hdr = base; st.P = base[conv::H_P]; st.S = base[conv::H_S];
+    gf2p f = (gf2p)(base + conv::kHeaderDwords);
+    st.H = (gcf2p)f;
+    st.X = f + (size_t)st.P * 512u;
+    st.pre = st.X + (size_t)st.P * 512u;
+    st.preSlow = st.pre + (size_t)2u * st.S * 512u;
+    st.inbuf = (gfp)(st.preSlow + 512u);
+    st.overlap = st.inbuf + 512u;
+    return st;
+}
+
+// sum_{p=2}^{P-1} H_p[k] X_{b-p}[k] restricted to partitions p = 2 + q, q = q0, q0 + dq, ...
+__device__ __forceinline__ c2 older_sum(const State& st, uint32_t b, uint32_t k, uint32_t q0, uint32_t dq) {
+    const uint32_t P = st.P, bm = b % P;
+    const bool packed = k == 0u;
+    c2 acc = mk(0.0f, 0.0f);
+    uint32_t q = q0;
+    for (; q + 3u * dq + 2u < P; q += 4u * dq) {      // four independent load pairs in flight
+        c2 h[4], x[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t p = 2u + q + u * dq;
+            const uint32_t slot = bm >= p ? bm - p : bm + P - p;
+            h[u] = st.H[(size_t)p * 512u + k];
+            x[u] = st.X[(size_t)slot * 512u + k];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) acc = cadd(acc, smul(h[u], x[u], packed));
+    }
+    for (; q + 2u < P; q += dq) {
+        const uint32_t p = 2u + q;
+        const uint32_t slot = bm >= p ? bm - p : bm + P - p;
+        acc = cadd(acc, smul(st.H[(size_t)p * 512u + k], st.X[(size_t)slot * 512u + k], packed));
+    }
+    return acc;
+}
+
+__device__ void conv_main(const ConvDesc d, gup recs, gfp hbm, const Globals* g, c2* A, c2* B, c2* W, c2* Xk) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = g->numSamples, stride = g->blockStride;
+    gfp out = hbm + (size_t)d.outHbm * stride;
+    gcup r = (gcup)(recs + d.rec * kRecDwords);
+    const uint64_t sp = (uint64_t)r[rec::CONV_STATE] | ((uint64_t)r[rec::CONV_STATE + 1] << 32);
+    uint32_t inKind = d.inKind;
+    if (inKind == 3u) inKind = g->numIn > 0 ? 1u : 0u;                 // leaf: host channel 0 (arena buffer 0)
+    if (sp == 0ull || inKind == 0u) {                                 // Convolve.h:70-71
+        for (uint32_t i = tid; i < n; i += 256u) out[i] = 0.0f;
+        return;
+    }
+    const State st = state_of((gup)reinterpret_cast<uint32_t*>(sp));
+    if (st.P == 0u) {                                                 // empty / all-below-threshold IR: FFTConvolver with no segments
+        for (uint32_t i = tid; i < n; i += 256u) out[i] = 0.0f;
+        return;
+    }
+    gcfp in = (gcfp)(hbm + (size_t)(inKind == 1u ? (d.inKind == 3u ? 0u : d.inIdx) : 0u) * stride);
+    const float cval = inKind == 2u ? __uint_as_float(((gcup)recs)[d.inIdx * kRecDwords + rec::P0]) : 0.0f;
+    for (uint32_t i = tid; i < conv::kFft; i += 256u) W[i] = kTwiddle[i];
+
+    uint32_t fill = st.hdr[conv::H_FILL], blk = st.hdr[conv::H_BLK];
+    const uint32_t blk0 = blk;
+    uint32_t processed = 0;
+    while (processed < n) {
+        const uint32_t chunk = min(n - processed, 512u - fill);
+        // where this block's older-partition sum comes from (read before the barriers below: the slow path updates the header)
+        const bool haveHelpers = st.hdr[conv::H_PREVALID0 + (blk & 1u)] == blk;
+        const bool haveSlow = st.hdr[conv::H_PRESLOW_FOR] == blk;
+        // 1. time-domain input block, zero-padded to 1024
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < 2; ++q) {
+            const uint32_t i = tid + 256u * q;
+            float v = 0.0f;
+            if (i < fill) v = st.inbuf[i];
+            else if (i < fill + chunk) {
+                const uint32_t j = processed + i - fill;
+                v = inKind == 1u ? in[j] : cval;                      // inKind 4: cval == 0
+                st.inbuf[i] = v;
+            }
+            A[i] = mk(v, 0.0f);
+            A[i + 512u] = mk(0.0f, 0.0f);
+        }
+        __syncthreads();
+        fft1024(A, B, W, tid);                                        // -> B
+        // 2. keep the block spectrum (packed), form Y, lay out conj(Y) for the inverse transform
+        const uint32_t prevSlot = (blk % st.P) == 0u ? st.P - 1u : (blk % st.P) - 1u;
+#pragma unroll
+        for (uint32_t q = 0; q < 2; ++q) {
+            const uint32_t k = tid + 256u * q;
+            const bool packed = k == 0u;
+            const c2 x = packed ? mk(B[0].x, B[512].x) : B[k];
+            Xk[k] = x;
+            c2 acc = mk(0.0f, 0.0f);
+            if (st.P > 2u) {
+                if (haveHelpers) {
+                    gcf2p ps = (gcf2p)st.pre + (size_t)(blk & 1u) * st.S * 512u + k;
+                    for (uint32_t s = 0; s < st.S; ++s) acc = cadd(acc, ps[(size_t)s * 512u]);
+                } else if (haveSlow) {
+                    acc = st.preSlow[k];
+                } else {
+                    acc = older_sum(st, blk, k, 0u, 1u);
+                    st.preSlow[k] = acc;
+                }
+            }
+            if (st.P > 1u) acc = cadd(acc, smul(st.H[512u + k], st.X[(size_t)prevSlot * 512u + k], packed));
+            acc = cadd(acc, smul(st.H[k], x, packed));
+            if (packed) { A[0] = mk(acc.x, 0.0f); A[512] = mk(acc.y, 0.0f); }
+            else { A[k] = mk(acc.x, -acc.y); A[1024u - k] = acc; }
+        }
+        if (!haveHelpers && !haveSlow && st.P > 2u && tid == 0u) st.hdr[conv::H_PRESLOW_FOR] = blk;
+        __syncthreads();
+        fft1024(A, B, W, tid);                                        // -> B; y[i] = Re B[i] (H carries the 1/1024)
+        // 3. overlap-add and emit
+        for (uint32_t i = tid; i < chunk; i += 256u) out[processed + i] = B[fill + i].x + st.overlap[fill + i];
+        __syncthreads();
+        fill += chunk;
+        if (fill == 512u) {
+            for (uint32_t j = tid; j < 512u; j += 256u) {
+                st.overlap[j] = B[512u + j].x;
+                st.X[(size_t)(blk % st.P) * 512u + j] = Xk[j];
+            }
+            fill = 0u; blk += 1u;
+        }
+        processed += chunk;
+    }
+    __syncthreads();
+    if (tid == 0u) {
+        st.hdr[conv::H_FILL_NEXT] = fill; st.hdr[conv::H_BLK_NEXT] = blk;
+        // the helpers of this launch are producing the older-partition sum of block blk0 + 1
+        st.hdr[conv::H_PREVALID0 + ((blk0 + 1u) & 1u)] = blk0 + 1u;
+    }
+}
+
+__device__ void conv_helper(const ConvDesc d, uint32_t h, gup recs, const Globals* g, c2* red) {
+    gcup r = (gcup)(recs + d.rec * kRecDwords);
+    const uint64_t sp = (uint64_t)r[rec::CONV_STATE] | ((uint64_t)r[rec::CONV_STATE + 1] << 32);
+    uint32_t inKind = d.inKind;
+    if (inKind == 3u) inKind = g->numIn > 0 ? 1u : 0u;
+    if (sp == 0ull || inKind == 0u) return;
+    const State st = state_of((gup)reinterpret_cast<uint32_t*>(sp));
+    if (st.P <= 2u) return;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t k = (h % conv::kBinGroups) * 64u + lane;
+    const uint32_t b = st.hdr[conv::H_BLK] + 1u;
+    for (uint32_t s = h / conv::kBinGroups; s < st.S; s += d.slices) {
+        const c2 acc = older_sum(st, b, k, s * 4u + w, 4u * st.S);
+        __syncthreads();
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (w == 0u) {
+            c2 t = cadd(cadd(red[lane], red[64u + lane]), cadd(red[128u + lane], red[192u + lane]));
+            st.pre[((size_t)(b & 1u) * st.S + s) * 512u + k] = t;
+        }
+    }
+}
+
+} // namespace
+
+__global__ __launch_bounds__(256)
+void elemhip_convolve_kernel(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin) {
+    __shared__ c2 A[conv::kFft], B[conv::kFft], W[conv::kFft], Xk[512];
+    const uint32_t entry = pv.convWork[workBegin + blockIdx.x];
+    const ConvDesc d = pv.convs[entry & 0xFFFFu];
+    const uint32_t role = entry >> 16;
+    if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
+    if (role == 0u) conv_main(d, (gup)recs, (gfp)hbm, g, A, B, W, Xk);
+    else conv_helper(d, role - 1u, (gup)recs, g, A);
+}
+
+namespace elemhip {
+
+void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g,
+                     uint32_t workBegin, uint32_t numWorkgroups) {
+    hipLaunchKernelGGL(elemhip_convolve_kernel, dim3(numWorkgroups), dim3(256), 0, s, pv, recs, hbm, g, workBegin);
+}
+
+hipError_t upload_convolve_tables(const float* twiddleReIm /* 2 * 1024 floats */) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(kTwiddle), twiddleReIm, sizeof(float) * 2 * conv::kFft);
+}
+
+} // namespace elemhip

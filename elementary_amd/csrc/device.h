@@ -27,6 +27,7 @@ enum : uint32_t {
                            // lane-per-node ds_read_b128 (lane stride 516 words = 4 banks mod 64) conflict-free
     kSlot0       = 4,      // first slot word; words 0..3 read as 0.0f
     kMaxBlock    = 512,    // max frames per block the LDS slots are sized for
+    kMaxOut      = 256,    // output bus channels per process call
     kMaxHostIn   = 32,     // host input channels addressable by leaf nodes (Types.h:142 uses 32 too)
     kNone        = 0xFFFFFFFFu,
 };
@@ -120,6 +121,35 @@ struct RootEntry {
     uint32_t hbm;        // HBM arena buffer holding the root's faded output
 };
 
+// convolve (wasm/Convolve.h:23-92): one descriptor per node of the plan; rendered by the
+// partitioned-FFT kernel in conv.hip instead of an island program.
+struct ConvDesc {
+    uint32_t rec;        // node record: p0/p1 = device pointer to the node's convolver state (conv:: layout)
+    uint32_t inKind;     // 0 no input channel: zero output, state untouched; 1 HBM arena buffer; 2 const (record);
+                         // 3 leaf: host input 0 when the block has host inputs, else as 0; 4 silent input
+    uint32_t inIdx;
+    uint32_t outHbm;     // HBM arena buffer receiving the output
+    uint32_t rootRec;    // owning root (the node renders only while that root runs)
+    uint32_t slices;     // helper workgroups per bin group the plan launches for this node
+    uint32_t pad_[2];
+};
+
+// Convolver state: one device allocation per `path` assignment, zero-initialised except H.
+//   header[16] | H[P][512] float2 | X[P][512] float2 | pre[2][S][512] float2 | preSlow[512] float2 | inbuf[512] | overlap[512]
+// Spectra are 1024-point real-FFT bins 0..511 with the (real) Nyquist bin packed into bin 0's imaginary part.
+namespace conv {
+enum : uint32_t {
+    kBlock = 512, kFft = 1024, kBinGroups = 8, kMaxSlices = 8, kSlicePartitions = 96,
+    H_P = 0,            // partitions = ceil(trimmed IR length / 512)
+    H_S = 1,            // partial-sum slices the helpers produce
+    H_FILL = 2, H_BLK = 3,             // frames already in the current input block / index of that block
+    H_FILL_NEXT = 4, H_BLK_NEXT = 5,   // written by the node's main workgroup, committed by the epilogue
+    H_PREVALID0 = 6,    // [2]: block index whose older-partition sum pre[i] holds
+    H_PRESLOW_FOR = 8,  // block index preSlow holds (only when a call straddles two input blocks)
+    kHeaderDwords = 16,
+};
+}
+
 struct TapEntry {
     uint32_t rec;        // tapOut record: p0/p1 shared tap buffer ptr, p2/p3 private delay buffer ptr
     uint32_t rootRec;    // owning root (promotion only while that root is active)
@@ -135,9 +165,11 @@ struct Globals {
     uint32_t ringSlots;
     uint32_t blockStride;  // floats between arena buffers (= blockSize)
     float    sampleRateF;
-    uint32_t pad_;
+    uint32_t inBlocks;     // multi-block path: input blocks available behind inRing
     double   sampleRate;
     uint64_t trace;        // debug: device pointer to a per-task timestamp log for workgroup 0 of every launch, or 0
+    uint64_t inRing;       // multi-block path: device pointer to [inBlocks][numIn][blockStride] host-input blocks; the
+                           // epilogue stages the NEXT block's inputs into arena buffers 0..numIn-1 (0 = host copies them)
 };
 
 // Device view of a compiled plan (all pointers are device pointers).
@@ -147,8 +179,13 @@ struct PlanView {
     const uint32_t*  prog;           // island program blobs
     const RootEntry* roots;          // in render-sequence order
     const TapEntry*  taps;           // in render-sequence order
+    const ConvDesc*  convs;          // convolve nodes of the plan
+    const uint32_t*  convWork;       // per launch level: one entry per conv workgroup = conv index | role << 16
+                                     // (role 0 = the node's main workgroup, role h > 0 = helper h - 1)
     uint32_t numRoots;
     uint32_t numTaps;
+    uint32_t numConvs;
+    uint32_t pad_;
 };
 
 struct Patch {
@@ -173,6 +210,8 @@ enum : uint32_t {
     SEQ_INDEX = S0, SEQ_HOLDVAL = S1, SEQ_FIRST = S2, SEQ_CHANGE = S3, SEQ_RCHANGE = S4, SEQ_HAVE = S5,
     // taps (Feedback.h)
     TAP_SHARED = P0, TAP_PRIVATE = P2,
+    // convolve: device pointer to the conv:: state
+    CONV_STATE = P0,
     // sampleseq (SampleSeq.h:169-404): sample buffer, event table [len doubles | len floats], k-rate state, two readers
     SSQ_BUF = P0, SSQ_BUFLEN = P2, SSQ_BUFPENDING = P3, SSQ_SEQ = P4, SSQ_SEQLEN = P6, SSQ_SEQPENDING = P7,
     SSQ_DUR = 8, SSQ_RTDUR = 10, SSQ_PREV = 12, SSQ_NEXT = 13, SSQ_ACTIVE = 14, SSQ_FLAGS = 15,

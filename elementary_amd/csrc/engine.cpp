@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -55,7 +56,7 @@ static const std::unordered_map<std::string, uint16_t>& opTable() {
         {"pole", OP_POLE}, {"env", OP_ENV}, {"biquad", OP_BIQUAD}, {"prewarp", OP_PREWARP}, {"mm1p", OP_MM1P}, {"svf", OP_SVF}, {"svfshelf", OP_SVFSHELF},
         {"tapIn", OP_TAPIN}, {"tapOut", OP_TAPOUT},
         {"blepsaw", OP_BLEPSAW}, {"blepsquare", OP_BLEPSQUARE}, {"bleptriangle", OP_BLEPTRIANGLE},
-        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ},
+        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE},
     };
     return t;
 }
@@ -118,6 +119,14 @@ Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), devi
     if (hipMalloc(&dGlobals, sizeof(Globals)) != hipSuccess) { fail(kHipError); return; }
     (void)hipMemcpy(dGlobals, &hGlobals, sizeof(Globals), hipMemcpyHostToDevice);
 
+    {   // FFT twiddles for `convolve` (conv.hip): cis(-2 pi k / 1024) rounded from double
+        std::vector<float> tw(2 * conv::kFft);
+        for (uint32_t k = 0; k < conv::kFft; ++k) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)conv::kFft;
+            tw[2 * k] = (float)std::cos(a); tw[2 * k + 1] = (float)std::sin(a);
+        }
+        if (upload_convolve_tables(tw.data()) != hipSuccess) { fail(kHipError); return; }
+    }
     // LCG jump-ahead table for `rand` (Noise.h:28-32): s_k = A[k]*s_0 + C[k] (mod 2^32)
     std::vector<uint32_t> lcg(2 * (kMaxBlock + 1));
     uint32_t A = 1, Cc = 0;
@@ -164,7 +173,8 @@ void Engine::setStream(hipStream_t s) {
     if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
 }
 
-void Engine::freeDeferred() {
+void Engine::freeDeferred() {   // called right after a stream synchronize
+    patchCursor = 0;
     for (void* p : deferredFree) (void)hipFree(p);
     deferredFree.clear();
 }
@@ -232,6 +242,58 @@ int Engine::allocRing(Node& n, size_t floats) {
     HIP_OK(hipMemset(p, 0, bytes));
     if (n.ring.ptr) deferredFree.push_back(n.ring.ptr);
     n.ring.ptr = p; n.ring.bytes = bytes;
+    return kOk;
+}
+
+// A new impulse response = a new convolver starting from silence (Convolve.h:47-51: a fresh
+// TwoStageFFTConvolver per `path` assignment). Builds the conv:: state: header + IR partition spectra.
+int Engine::setConvolverIr(Node& n, const ResourcePtr& res) {
+    std::vector<float> h;
+    if (!res->channels.empty()) h = res->channels[0];
+    // trailing |h| < 1e-6 is dropped by the two-stage convolver as a whole and again by each of its
+    // three uniform convolvers over ir[0:4096), ir[4096:8192), ir[8192:) (fftconv_oracle.h)
+    size_t len = h.size();
+    while (len > 0 && std::fabs(h[len - 1]) < 0.000001f) --len;
+    h.resize(len);
+    for (size_t lo : {(size_t)0, (size_t)4096}) {
+        size_t hi = std::min(len, lo + 4096);
+        while (hi > lo && std::fabs(h[hi - 1]) < 0.000001f) h[--hi] = 0.0f;
+    }
+    const uint32_t B = conv::kBlock, N = conv::kFft;
+    const uint32_t P = (uint32_t)((len + B - 1) / B);
+    const uint32_t older = P > 2 ? P - 2 : 0;
+    const uint32_t S = std::min<uint32_t>(conv::kMaxSlices, std::max<uint32_t>(1, (older + conv::kSlicePartitions - 1) / conv::kSlicePartitions));
+    const size_t words = conv::kHeaderDwords + 2 * ((size_t)2 * P + 2 * S + 1) * 512 + 1024;
+    std::vector<uint32_t> blob(conv::kHeaderDwords + (size_t)P * 1024, 0u);
+    blob[conv::H_P] = P; blob[conv::H_S] = S;
+    // IR partition spectra in double, scaled by 1/1024 (exact), rounded to float, Nyquist packed into bin 0
+    std::vector<std::complex<double>> a(N), tw(N / 2);
+    for (uint32_t k = 0; k < N / 2; ++k) { const double ang = -2.0 * 3.14159265358979323846 * k / N; tw[k] = {std::cos(ang), std::sin(ang)}; }
+    for (uint32_t p = 0; p < P; ++p) {
+        for (uint32_t i = 0; i < N; ++i) { const size_t j = (size_t)p * B + i; a[i] = (i < B && j < len) ? (double)h[j] : 0.0; }
+        for (uint32_t i = 1, j = 0; i < N; ++i) {            // bit reversal
+            uint32_t bit = N >> 1;
+            for (; j & bit; bit >>= 1) j ^= bit;
+            j ^= bit;
+            if (i < j) std::swap(a[i], a[j]);
+        }
+        for (uint32_t m = 2; m <= N; m <<= 1)
+            for (uint32_t s0 = 0; s0 < N; s0 += m)
+                for (uint32_t k = 0; k < m / 2; ++k) {
+                    const std::complex<double> u = a[s0 + k], t = a[s0 + k + m / 2] * tw[k * (N / m)];
+                    a[s0 + k] = u + t; a[s0 + k + m / 2] = u - t;
+                }
+        float* dst = reinterpret_cast<float*>(blob.data() + conv::kHeaderDwords + (size_t)p * 1024);
+        const double sc = 1.0 / (double)N;
+        dst[0] = (float)(a[0].real() * sc); dst[1] = (float)(a[N / 2].real() * sc);
+        for (uint32_t k = 1; k < N / 2; ++k) { dst[2 * k] = (float)(a[k].real() * sc); dst[2 * k + 1] = (float)(a[k].imag() * sc); }
+    }
+    int rc = allocRing(n, words);
+    if (rc != kOk) return rc;
+    if (dry) std::memcpy(n.ring.ptr, blob.data(), blob.size() * 4);
+    else HIP_OK(hipMemcpy(n.ring.ptr, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+    writeParamPtr(n, rec::CONV_STATE, n.ring.ptr);
+    if (n.convSlices != S) { n.convSlices = S; planStale = true; }
     return kOk;
 }
 
@@ -472,6 +534,15 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
                 writeParamPtr(n, rec::TAP_SHARED, r->dev.ptr);
             }
             break;
+        case OP_CONVOLVE:                                          // wasm/Convolve.h:34-56
+            if (key == "path") {
+                if (!v.isString()) return kInvalidPropertyType;
+                auto rit = resources.find(v.str);
+                if (rit == resources.end()) return kInvalidPropertyValue;
+                int rc = setConvolverIr(n, rit->second);
+                if (rc != kOk) return rc;
+            }
+            break;
         case OP_SAMPLESEQ:                                         // SampleSeq.h:181-255
             if (key == "duration") {
                 if (!v.isNumber()) return kInvalidPropertyType;
@@ -558,7 +629,8 @@ int Engine::activateRoots(const std::vector<int32_t>& ids) {   // Runtime.h:368-
 }
 
 int Engine::commit() {   // Runtime.h:202-206
-    if (shouldRebuild) {
+    if (shouldRebuild || (planStale && (current || pending))) {
+        planStale = false;
         auto t0 = std::chrono::steady_clock::now();
         auto p = buildPlan();
         if (!p) return kUnsupportedGraph;
@@ -714,16 +786,16 @@ void Engine::flushPending() {
     }
     size_t off = 0;
     while (off < patches.size()) {
-        const size_t cnt = std::min<size_t>(patchCap, patches.size() - off);
-        std::memcpy(hPatches, patches.data() + off, cnt * sizeof(Patch));
-        launch_patches(stream, hPatches, (uint32_t)cnt, dRecs, reinterpret_cast<uint32_t*>(dGlobals));
+        // the patch kernel reads the pinned staging area when it RUNS: hand every launch its own
+        // stretch of it and only rewind once the stream has drained
+        if (patchCursor >= patchCap) { HIP_WARN(hipStreamSynchronize(stream)); patchCursor = 0; }
+        const size_t cnt = std::min<size_t>(patchCap - patchCursor, patches.size() - off);
+        std::memcpy(hPatches + patchCursor, patches.data() + off, cnt * sizeof(Patch));
+        launch_patches(stream, hPatches + patchCursor, (uint32_t)cnt, dRecs, reinterpret_cast<uint32_t*>(dGlobals));
+        patchCursor += cnt;
         off += cnt;
-        if (off < patches.size()) HIP_WARN(hipStreamSynchronize(stream));
     }
-    if (!patches.empty()) {
-        // the staging buffer is reused by the next call; kernels of this call run after the patch kernel
-        patches.clear();
-    }
+    patches.clear();
 }
 
 int Engine::setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime) {
@@ -737,6 +809,19 @@ int Engine::setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime)
         patchG(offsetof(Globals, sampleTime) + 4, (uint32_t)((uint64_t)sampleTime >> 32));
     }
     return kOk;
+}
+
+void Engine::setInRing(const float* ring, uint32_t blocks) {
+    const uint64_t v = (uint64_t)(uintptr_t)ring;
+    if (hGlobals.inRing != v) {
+        hGlobals.inRing = v;
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, inRing) / 4), (uint32_t)(v & 0xFFFFFFFFu), 0u});
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, inRing) / 4 + 1), (uint32_t)(v >> 32), 0u});
+    }
+    if (hGlobals.inBlocks != blocks) {
+        hGlobals.inBlocks = blocks;
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, inBlocks) / 4), blocks, 0u});
+    }
 }
 
 int Engine::swapInPending() {   // Runtime.h:277-285: newest sequence wins
@@ -765,6 +850,8 @@ void Engine::enqueueBlock(const Plan& p) {
     for (size_t l = 0; l < L; ++l) {
         const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
         if (e > b) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l]);
+        const uint32_t cb = p.convLevelOffsets[l], ce = p.convLevelOffsets[l + 1];
+        if (ce > cb) launch_convolve(stream, p.view, dRecs, dHbm, dGlobals, cb, ce - cb);
     }
     launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, dOutRing);
 }
@@ -789,7 +876,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     if (dry) return kNoDevice;
     if (hipSetDevice(device) != hipSuccess) return kHipError;
     if (n > (size_t)blockSize) return kBlockTooLarge;
-    if (nIn > kMaxHostIn || nOut > 64) return kTooManyChannels;
+    if (nIn > kMaxHostIn || nOut > kMaxOut) return kTooManyChannels;
     int rc = swapInPending();
     if (rc != kOk) return rc;
     if (!current) return kOk;   // no render sequence yet: outputs untouched (Runtime.h:287-289)
@@ -801,6 +888,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
         patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, blockSlot) / 4), 0u, 0u});
     }
     setGlobalsFor(nIn, nOut, n, sampleTime);
+    setInRing(nullptr, 0);
     rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize);
     if (rc != kOk) return rc;
 
@@ -856,6 +944,7 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
         patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, blockSlot) / 4), 0u, 0u});
     }
     setGlobalsFor(0, nOut, (size_t)blockSize, hGlobals.sampleTime);
+    setInRing(nullptr, 0);
     flushPending();
     std::vector<hipEvent_t> ev(2 * (L + 2));   // + one empty pair: the cost of the event pair itself
     for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -kHipError;
@@ -865,6 +954,8 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
             const uint32_t lb = p.levelOffsets[l], le = p.levelOffsets[l + 1];
             (void)hipEventRecord(ev[2 * l], stream);
             if (le > lb) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l]);
+            if (p.convLevelOffsets[l + 1] > p.convLevelOffsets[l])
+                launch_convolve(stream, p.view, dRecs, dHbm, dGlobals, p.convLevelOffsets[l], p.convLevelOffsets[l + 1] - p.convLevelOffsets[l]);
             (void)hipEventRecord(ev[2 * l + 1], stream);
         }
         (void)hipEventRecord(ev[2 * L], stream);
@@ -906,6 +997,7 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
         patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, blockSlot) / 4), 0u, 0u});
     }
     setGlobalsFor(0, nOut, (size_t)blockSize, hGlobals.sampleTime);
+    setInRing(nullptr, 0);
     flushPending();
     const uint64_t tp = (uint64_t)reinterpret_cast<uintptr_t>(dTrace);
     for (size_t l = 0; l < L; ++l) {
@@ -930,13 +1022,14 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
     std::lock_guard<std::mutex> lock(mu);
     if (dry) return kNoDevice;
     if (hipSetDevice(device) != hipSuccess) return kHipError;
-    if (nIn > kMaxHostIn || nOut > 64) return kTooManyChannels;
+    if (nIn > kMaxHostIn || nOut > kMaxOut) return kTooManyChannels;
     int rc = swapInPending();
     if (rc != kOk) return rc;
     if (!current || numBlocks == 0) return kOk;
     Plan& p = *current;
     const size_t bs = (size_t)blockSize;
-    const bool graphOk = useGraph && nIn == 0;
+    const bool graphOk = useGraph;
+    const bool haveIn = nIn > 0 && inDev != nullptr;
     const size_t G = graphOk ? (size_t)graphBlocks : 1;
     rc = ensureOutRing(std::max<size_t>(nOut, 1) * bs * G);
     if (rc != kOk) return rc;
@@ -951,6 +1044,9 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, ringSlots) / 4), (uint32_t)G, 0u});
             patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, blockSlot) / 4), 0u, 0u});
         }
+        // host inputs: block 0 of the chunk is copied here, the epilogue of block k stages block k + 1
+        setInRing(haveIn ? inDev + done * nIn * bs : nullptr, haveIn ? (uint32_t)chunk : 0u);
+        if (haveIn) HIP_OK(hipMemcpyAsync(dHbm, inDev + done * nIn * bs, nIn * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
         flushPending();
         if (graphOk && chunk == G) {
             if (!p.graphExec || p.graphBlocks != (int)G) {
@@ -968,11 +1064,7 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             HIP_OK(hipGraphLaunch(p.graphExec, stream));
             st.graphReplays++;
         } else {
-            for (size_t b = 0; b < chunk; ++b) {
-                if (nIn > 0 && inDev)
-                    HIP_OK(hipMemcpyAsync(dHbm, inDev + (done + b) * nIn * bs, nIn * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
-                enqueueBlock(p);
-            }
+            for (size_t b = 0; b < chunk; ++b) enqueueBlock(p);
         }
         if (outDev && nOut > 0)
             HIP_OK(hipMemcpyAsync(outDev + done * nOut * bs, dOutRing, chunk * nOut * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));

@@ -65,6 +65,7 @@ struct Node {
     // device-side resources owned by the node
     DevBuf ring;                // delay / sdelay ring, tapOut private buffer, seq data
     ResourcePtr res;            // tap buffer / sample data held by the node
+    uint32_t convSlices = 1;    // convolve: helper slices its current impulse response wants (conv.hip)
 };
 
 struct Plan;   // plan.cpp
@@ -127,6 +128,7 @@ private:
     std::set<int32_t> currentRoots;
     std::unordered_map<std::string, ResourcePtr> resources;
     bool shouldRebuild = false;
+    bool planStale = false;                // a property changed the launch shape of the plan (convolve IR length)
 
     // record arena
     uint32_t* dRecs = nullptr;
@@ -139,6 +141,7 @@ private:
     std::vector<Patch> patches;            // param patches to apply before the next block
     Patch* hPatches = nullptr;             // pinned staging
     uint32_t patchCap = 0;
+    size_t patchCursor = 0;                // next free staging slot (rewound after a stream sync)
 
     // device globals, host mirror
     Globals* dGlobals = nullptr;
@@ -163,6 +166,7 @@ private:
     void writeParamPtr(Node& n, uint32_t dword, const void* p);
     int  allocRing(Node& n, size_t floats);
     int  ensureResourceOnDevice(const ResourcePtr& r);
+    int  setConvolverIr(Node& n, const ResourcePtr& res);
     ResourcePtr tapResource(const std::string& name);
     void rootUpdateStep(Node& n);
     void flushPending();                   // fresh records + patches -> device (stream-ordered)
@@ -173,6 +177,7 @@ private:
     void enqueueBlock(const Plan& p);
     void mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn);
     int  setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime);
+    void setInRing(const float* ring, uint32_t blocks);
     std::shared_ptr<Plan> buildPlan();
 };
 
@@ -186,6 +191,9 @@ struct Plan {
     uint32_t numTasks = 0, numMembers = 0, numOperands = 0;
     std::vector<RootEntry> roots;
     std::vector<TapEntry> taps;
+    std::vector<ConvDesc> convs;           // convolve nodes (conv.hip)
+    std::vector<uint32_t> convWork;        // conv workgroups, level-major
+    std::vector<uint32_t> convLevelOffsets; // numLevels + 1
     std::vector<int32_t> rootIds;          // same order as `roots`
     std::set<int32_t> nodeIds;             // every node the render sequence references (gc)
     uint32_t numHbmBuffers = kMaxHostIn;

@@ -1640,8 +1640,10 @@ void elemhip_island_kernel(PlanView pv, uint32_t* recs, float* hbm, const Global
 __global__ __launch_bounds__(1024)
 void elemhip_epilogue_kernel(PlanView pv, uint32_t* recs_, const float* hbm_, Globals* g, float* outRing) {
     gup recs = (gup)recs_; gcfp hbm = (gcfp)hbm_;
-    __shared__ int rootChan[1024];   // channel of root r if it ran this block, else -1
-    const uint32_t n = g->numSamples, numOut = g->numOut, stride = g->blockStride;
+    __shared__ int rootChan[1024];        // channel of root r if it ran this block, else -1
+    __shared__ uint16_t chanList[1024];   // running roots grouped by channel, render-sequence order inside a channel
+    __shared__ uint16_t chanStart[kMaxOut + 1];
+    const uint32_t n = g->numSamples, numOut = min(g->numOut, (uint32_t)kMaxOut), stride = g->blockStride;
     gfp out = (gfp)(outRing + (size_t)g->blockSlot * numOut * stride);
     const uint32_t nr = min(pv.numRoots, 1024u);
     for (uint32_t r = threadIdx.x; r < nr; r += blockDim.x) {
@@ -1649,11 +1651,23 @@ void elemhip_epilogue_kernel(PlanView pv, uint32_t* recs_, const float* hbm_, Gl
         rootChan[r] = root_running(recs, rr, numOut) ? (int)recs[rr * kRecDwords + rec::ROOT_CHANNEL] : -1;
     }
     __syncthreads();
+    if (threadIdx.x < numOut) {           // thread ch counts its roots
+        uint32_t cnt = 0;
+        for (uint32_t r = 0; r < nr; ++r) cnt += rootChan[r] == (int)threadIdx.x;
+        chanStart[threadIdx.x + 1] = (uint16_t)cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { chanStart[0] = 0; for (uint32_t c = 0; c < numOut; ++c) chanStart[c + 1] += chanStart[c]; }
+    __syncthreads();
+    if (threadIdx.x < numOut) {
+        uint32_t q = chanStart[threadIdx.x];
+        for (uint32_t r = 0; r < nr; ++r) if (rootChan[r] == (int)threadIdx.x) chanList[q++] = (uint16_t)r;
+    }
+    __syncthreads();
     for (uint32_t idx = threadIdx.x; idx < numOut * n; idx += blockDim.x) {
         const uint32_t ch = idx / n, i = idx - ch * n;
         float acc = 0.0f;
-        for (uint32_t r = 0; r < nr; ++r)
-            if (rootChan[r] == (int)ch) acc += hbm[(size_t)pv.roots[r].hbm * stride + i];
+        for (uint32_t q = chanStart[ch]; q < chanStart[ch + 1]; ++q) acc += hbm[(size_t)pv.roots[chanList[q]].hbm * stride + i];
         for (uint32_t r = nr; r < pv.numRoots; ++r) {   // > 1024 roots: slow path
             const RootEntry re = pv.roots[r];
             if (root_running(recs, re.rec, numOut) && recs[re.rec * kRecDwords + rec::ROOT_CHANNEL] == ch)
@@ -1681,10 +1695,24 @@ void elemhip_epilogue_kernel(PlanView pv, uint32_t* recs_, const float* hbm_, Gl
         if (gcur != tg && (rr[rec::ROOT_HASIN] || g->numIn > 0) /* fade.process ran (Core.h:74-77) */)
             rr[rec::ROOT_GAIN] = f2u(clampf(gcur + step * (float)(int)n, 0.0f, 1.0f));
     }
+    // convolve nodes: commit the input-block position their main workgroups reached (conv.hip)
+    for (uint32_t k = threadIdx.x; k < pv.numConvs; k += blockDim.x) {
+        gup st = (gup)rec_ptr(recs + pv.convs[k].rec * kRecDwords, rec::CONV_STATE);
+        if (!st) continue;
+        st[conv::H_FILL] = st[conv::H_FILL_NEXT];
+        st[conv::H_BLK] = st[conv::H_BLK_NEXT];
+    }
+    const uint32_t nextSlot = (g->blockSlot + 1) % g->ringSlots;
+    if (g->inRing && nextSlot < g->inBlocks) {   // stage the next block's host inputs (elemhip_process_blocks)
+        const uint32_t words = g->numIn * stride;
+        gcfp src = (gcfp)reinterpret_cast<const float*>(g->inRing) + (size_t)nextSlot * words;
+        gfp dst = (gfp)const_cast<float*>(hbm_);
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         g->sampleTime += (int64_t)n;
-        g->blockSlot = (g->blockSlot + 1) % g->ringSlots;
+        g->blockSlot = nextSlot;
     }
 }
 

@@ -9,6 +9,9 @@ hipError_t configure_kernels(uint32_t maxLdsBytes);
 void launch_level(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, const uint32_t* lcg,
                   uint32_t levelBegin, uint32_t numIslands, uint32_t ldsBytes);
 void launch_epilogue(hipStream_t s, const PlanView& pv, uint32_t* recs, const float* hbm, Globals* g, float* outRing);
+void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g,
+                     uint32_t workBegin, uint32_t numWorkgroups);
+hipError_t upload_convolve_tables(const float* twiddleReIm);
 void launch_patches(hipStream_t s, const Patch* patches, uint32_t count, uint32_t* recs, uint32_t* globals);
 
 } // namespace elemhip

@@ -24,12 +24,13 @@ namespace elemhip {
 
 namespace {
 
-enum Kind : uint8_t { K_CONST, K_PAR, K_SINGLE, K_CHAIN };
+enum Kind : uint8_t { K_CONST, K_PAR, K_SINGLE, K_CHAIN, K_CONV };
 
 Kind kindOf(uint16_t op) {
     switch (op) {
         case OP_CONST: case OP_SR: return K_CONST;
         case OP_RAND: case OP_Z: case OP_SDELAY: case OP_DELAY: case OP_SAMPLESEQ: return K_SINGLE;
+        case OP_CONVOLVE: return K_CONV;   // always an island of its own, rendered by conv.hip
         case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD:
         case OP_ONCE: case OP_SEQ: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
         case OP_SVFSHELF: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
@@ -214,7 +215,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
             deps.insert(rep(s.island));
         }
         int target = -1;
-        if (!deps.empty()) {
+        const bool sealed = x.kind == K_CONV;
+        if (!deps.empty() && !sealed) {
             uint32_t total = w;
             for (int d : deps) total += weight[d];
             std::vector<int> dv(deps.begin(), deps.end());
@@ -261,6 +263,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
         }
         x.island = target;
         weight[target] += w;
+        if (sealed) weight[target] += maxIslandNodes;   // nothing joins a convolve island
         for (int d : deps) if (rep(d) != target) succ[rep(d)].insert(target);
         for (int f : foreign) if (rep(f) != target) succ[rep(f)].insert(target);
     }
@@ -282,7 +285,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
     for (size_t k = 0; k < ni.size(); ++k) {
         NI& x = ni[k];
         if (x.kind == K_CONST) continue;
-        if (x.n->op == OP_ROOT) x.exported = true;
+        if (x.n->op == OP_ROOT || x.kind == K_CONV) x.exported = true;
         if (x.kind == K_CHAIN) x.needLds = true;
     }
     for (size_t k = 0; k < ni.size(); ++k) {
@@ -331,10 +334,29 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
 
     // ---- 3/4. per-island schedule, LDS allocation, task emission -------------------------------------
     p.islands.resize(ib.size());
+    std::vector<int> convLevel;              // launch level of p.convs[i]
     for (size_t ii = 0; ii < ib.size(); ++ii) {
         IslandBuild& B = ib[ii];
         Island& I = p.islands[ii];
         I.rootRec = seqRoots[B.seq]->rec;
+        if (ni[B.nodes[0]].kind == K_CONV) {     // one node, no island program: a ConvDesc instead
+            NI& x = ni[B.nodes[0]];
+            ConvDesc d{};
+            d.rec = x.n->rec; d.outHbm = x.hbm; d.rootRec = I.rootRec; d.slices = std::max<uint32_t>(1, x.n->convSlices);
+            if (x.n->inlets.empty()) d.inKind = 3;                                      // leaf: host input 0
+            else {
+                const Inlet& in = x.n->inlets[0];
+                auto it = idx.find(in.source);
+                if (it == idx.end() || in.channel != 0) d.inKind = 4;
+                else if (ni[it->second].kind == K_CONST) { d.inKind = 2; d.inIdx = ni[it->second].n->rec; }
+                else { d.inKind = 1; d.inIdx = ni[it->second].hbm; }
+            }
+            I = Island{};
+            I.rootRec = d.rootRec; I.split = 0;                                         // no island-kernel workgroup
+            convLevel.push_back(B.level);
+            p.convs.push_back(d);
+            continue;
+        }
 
         // imports needed in LDS: external producers (or host inputs) feeding chain members
         struct Import { uint32_t hbm; int lastUse; uint32_t lds; };
@@ -645,6 +667,14 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
             p.levelLdsBytes[ib[i].level] = std::max(p.levelLdsBytes[ib[i].level], p.islands[i].ldsWords * 4u);
         }
     }
+    if (p.convs.size() > 0xFFFFu) { std::fprintf(stderr, "[elemhip] plan: too many convolve nodes\n"); return nullptr; }
+    p.convLevelOffsets.assign((size_t)numLevels + 1, 0);
+    for (int l = 0; l < numLevels; ++l) {    // per level: every node's main workgroup first, then the helpers
+        for (size_t c = 0; c < p.convs.size(); ++c) if (convLevel[c] == l) p.convWork.push_back((uint32_t)c);
+        for (size_t c = 0; c < p.convs.size(); ++c) if (convLevel[c] == l)
+            for (uint32_t h = 0; h < conv::kBinGroups * p.convs[c].slices; ++h) p.convWork.push_back((uint32_t)c | ((h + 1u) << 16));
+        p.convLevelOffsets[(size_t)l + 1] = (uint32_t)p.convWork.size();
+    }
     for (size_t s = 0; s < seqRoots.size(); ++s) {
         Node* r = seqRoots[s];
         NI& x = ni[idx.at(r->id)];
@@ -685,6 +715,8 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     const size_t oProg = place(p.prog.size() * 4);
     const size_t oRoots = place(p.roots.size() * sizeof(RootEntry));
     const size_t oTaps = place(p.taps.size() * sizeof(TapEntry));
+    const size_t oConvs = place(p.convs.size() * sizeof(ConvDesc));
+    const size_t oConvWork = place(p.convWork.size() * 4);
     std::vector<uint8_t> host(std::max<size_t>(off, 16), 0);
     auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(host.data() + o, src, bytes); };
     put(oIslands, p.islands.data(), p.islands.size() * sizeof(Island));
@@ -692,6 +724,8 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     put(oProg, p.prog.data(), p.prog.size() * 4);
     put(oRoots, p.roots.data(), p.roots.size() * sizeof(RootEntry));
     put(oTaps, p.taps.data(), p.taps.size() * sizeof(TapEntry));
+    put(oConvs, p.convs.data(), p.convs.size() * sizeof(ConvDesc));
+    put(oConvWork, p.convWork.data(), p.convWork.size() * 4);
     if (dry) return plan;
     if (hipMalloc(&p.dev.ptr, host.size()) != hipSuccess) return nullptr;
     p.dev.bytes = host.size();
@@ -702,6 +736,9 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     p.view.prog = reinterpret_cast<const uint32_t*>(d + oProg);
     p.view.roots = reinterpret_cast<const RootEntry*>(d + oRoots);
     p.view.taps = reinterpret_cast<const TapEntry*>(d + oTaps);
+    p.view.convs = reinterpret_cast<const ConvDesc*>(d + oConvs);
+    p.view.convWork = reinterpret_cast<const uint32_t*>(d + oConvWork);
+    p.view.numConvs = (uint32_t)p.convs.size();
     p.view.numRoots = (uint32_t)p.roots.size();
     p.view.numTaps = (uint32_t)p.taps.size();
     return plan;
@@ -722,7 +759,7 @@ std::string Engine::describePlan() {
     kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.numTasks);
     kv("num_members", p.numMembers); kv("num_operands", p.numOperands); kv("num_nodes", p.nodeIds.size());
     kv("num_hbm_buffers", p.numHbmBuffers); kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());
-    kv("num_taps", p.taps.size());
+    kv("num_taps", p.taps.size()); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());
     s += "\"level_sizes\":[";
     for (size_t l = 0; l + 1 < p.levelOffsets.size(); ++l) { if (l) s += ","; s += std::to_string(p.levelOffsets[l + 1] - p.levelOffsets[l]); }
     s += "],\"root_ids\":[";

@@ -101,3 +101,48 @@ def c4_instance(k: int) -> NodeRepr:
 
 def c4_algorithmic_bytes(instances: int, block: int = 512) -> int:
     return instances * (31 * block * 4 + block * 4)
+
+
+# ---- C3: 8-channel FFT convolution reverb, 2 s impulse responses at 48 kHz ----------
+C3_SAMPLE_RATE = 48000.0
+C3_CHANNELS = 8
+C3_IR_LEN = 96000
+C3_IR_DECAY = 0.9999375019530843        # exp(-1/16000) per sample
+
+
+def _lcg_stream(seed: int, n: int):
+    import numpy as np
+    out = np.empty(n, dtype=np.float64)
+    s = seed & 0xFFFFFFFF
+    for i in range(n):
+        s = (1664525 * s + 1013904223) & 0xFFFFFFFF
+        out[i] = s / 2147483648.0 - 1.0
+    return out
+
+
+def c3_impulse_response(ch: int, length: int = C3_IR_LEN):
+    """ir[n] = lcg(n) * r^n, ir[0] = 1, unit energy, float32; distinct LCG seed per channel."""
+    import numpy as np
+    ir = _lcg_stream(1 + ch, length) * np.power(C3_IR_DECAY, np.arange(length, dtype=np.float64))
+    ir[0] = 1.0
+    return (ir / np.sqrt(np.sum(ir * ir))).astype(np.float32)
+
+
+def c3_graph(channels: int = C3_CHANNELS) -> List[NodeRepr]:
+    """per channel: root(ch)(convolve{path: "ir<ch>"}(in{channel: ch}))"""
+    return [el.convolve({"path": f"ir{ch}"}, el.in_({"channel": ch})) for ch in range(channels)]
+
+
+def c3_input(channels: int, frames: int, amp: float = 0.25):
+    import numpy as np
+    return np.stack([(_lcg_stream(101 + ch, frames) * amp).astype(np.float32) for ch in range(channels)])
+
+
+def c3_algorithmic_bytes(channels: int = C3_CHANNELS, ir_len: int = C3_IR_LEN, block: int = 512) -> int:
+    """per channel-block the reference's two-stage partitioning reads (8 + 8) spectra
+    of 513 bins and 1/8 of the 4096-partition tail spectra (8 B per bin), plus 4 KB of block I/O."""
+    tail = max(0, ir_len - 8192)
+    tail_parts = (tail + 4095) // 4096
+    head_parts = min(16, (min(ir_len, 8192) + 511) // 512)
+    per_ch = head_parts * 513 * 8 + tail_parts * 4097 * 8 // 8 + 2 * block * 4
+    return channels * per_ch
