@@ -123,6 +123,7 @@ int elemhip_get_stats(elemhip_t* h, elemhip_stats* out) {
     out->num_islands = s.numIslands; out->num_levels = s.numLevels; out->num_tasks = s.numTasks;
     out->num_nodes_in_plan = s.numNodesInPlan; out->max_lds_bytes = s.maxLdsBytes; out->num_hbm_buffers = s.numHbmBuffers;
     out->graph_replays = s.graphReplays; out->graph_captures = s.graphCaptures;
+    out->batch_launches = s.batchLaunches;
     return elemhip::kOk;
 }
 

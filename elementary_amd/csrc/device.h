@@ -21,8 +21,8 @@ enum : uint32_t {
     kRecDwords   = 32,     // dwords per node record
     kParam0      = 0,      // first param dword
     kState0      = 8,      // first state dword
-    kWaves       = 4,      // waves per island workgroup
-    kThreads     = 256,
+    kWaves       = 8,      // waves per island workgroup: two per SIMD, so a wave stalled on a serial recurrence leaves issue slots
+    kThreads     = 512,
     kSlotWords   = 516,    // LDS words per block-buffer slot: 512 + 4 keeps slots 16-byte aligned and makes
                            // lane-per-node ds_read_b128 (lane stride 516 words = 4 banks mod 64) conflict-free
     kSlot0       = 4,      // first slot word; words 0..3 read as 0.0f
@@ -95,19 +95,27 @@ struct Task {
 struct Island {
     uint32_t progBegin;            // dword offset of the blob in PlanView::prog
     uint32_t progDwords;
-    uint32_t numTasks;             // sorted by (wave, stage); wave w owns tasks [waveTask[w], waveTask[w+1])
+    uint32_t numTasks;             // per copy; sorted by (wave, stage); wave w owns tasks [waveTask[w], waveTask[w+1])
     uint32_t waveTask[kWaves + 1];
     uint32_t split;                // > 1: the island is pure sample-parallel and runs as `split` workgroups,
-                                   // workgroup k rendering frames [k, k+1) * blockSize / split
-    uint32_t memOff;               // dword offsets inside the blob
+                                   // workgroup k rendering frames [k, k+1) * blockSize / split; 0: no island workgroup (convolve)
+    uint32_t memOff;               // dword offsets inside one program copy
     uint32_t opndOff;
-    uint32_t cellOff;
+    uint32_t cellOff;              // dword offset (whole blob) of the ConstCell table
     uint32_t numCells;             // ConstCell pairs: LDS broadcast cells to fill at start
     uint32_t ldsProg;              // LDS word where the blob is staged (after slots and cells)
-    uint32_t ldsWords;             // total dynamic LDS words
+    uint32_t ldsWords;             // total dynamic LDS words (blob + stage counters included)
     uint32_t rootRec;              // record of the RootNode whose render sequence owns the island
     uint32_t numStages;
-    uint32_t pad_;
+    // multi-block launches (elemhip_process_blocks): a stateful island keeps `copies` blocks in flight, each with
+    // its own set of LDS block buffers and its own program copy [tasks | members | operands] addressing that set;
+    // stages of one block are ordered by LDS completion counters instead of workgroup barriers (kernels.hip).
+    uint32_t copies;
+    uint32_t copyDwords;           // dwords per program copy
+    uint32_t stageOff;             // dword offset (whole blob) of the stage tables: tasksInStage[S] | prevNonEmpty[S] | begin[4][S+1] | phaseStart[copies+1]
+    uint32_t stateless;            // 1: only stateless sample-parallel nodes: blocks of a batch may run in any order / in parallel
+    uint32_t ldsCounters;          // LDS word of the completion counters [numStages][copies]
+    uint32_t schedOff;             // dword offset (whole blob): walkOffsets[kWaves+1] | walk entries (8 dwords each), 16-byte aligned
 };
 
 struct ConstCell {

@@ -189,6 +189,7 @@ int Engine::ensureHbm(size_t buffers) {
     HIP_OK(hipMemset(nb, 0, floats * sizeof(float)));
     if (dHbm) deferredFree.push_back(dHbm);
     dHbm = nb; hbmBuffers = want;
+    if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
     return kOk;
 }
 
@@ -750,6 +751,9 @@ void Engine::pruneSharedResources() {   // SharedResource.h:94-102
 int Engine::setOption(const std::string& key, double value) {
     std::lock_guard<std::mutex> lock(mu);
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
+    if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(64, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
+    if (key == "pipeline_copies") { pipelineCopies = std::max(1, std::min(4, (int)value)); planStale = true; return kOk; }   // next commit re-plans
+    if (key == "time_batch") { timeBatch = std::max(1, std::min(64, (int)value)); return kOk; }
     if (key == "graph_blocks") { graphBlocks = std::max(1, (int)value); if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; } return kOk; }
     return kInvalidPropertyValue;
 }
@@ -949,31 +953,41 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
     std::vector<hipEvent_t> ev(2 * (L + 2));   // + one empty pair: the cost of the event pair itself
     for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -kHipError;
     std::vector<double> acc(L + 2, 0.0);
+    // timeBatch > 1: time the multi-block launches elemhip_process_blocks issues (msOut = per LAUNCH of `batch` blocks)
+    const uint32_t batch = (timeBatch > 1 && batchEligible(p, nOut)) ? (uint32_t)timeBatch : 1u;
+    const uint32_t arenaFloats = batch > 1 ? p.numHbmBuffers * (uint32_t)blockSize : 0u;
+    if (batch > 1) {
+        rc = ensureHbm((size_t)p.numHbmBuffers * batch); if (rc != kOk) return -rc;
+        rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize * batch); if (rc != kOk) return -rc;
+    }
+    lastTimeBatch = batch;
     for (size_t b = 0; b < numBlocks; ++b) {
         for (size_t l = 0; l < L; ++l) {
             const uint32_t lb = p.levelOffsets[l], le = p.levelOffsets[l + 1];
             (void)hipEventRecord(ev[2 * l], stream);
-            if (le > lb) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l]);
+            if (le > lb) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l], batch, arenaFloats);
             if (p.convLevelOffsets[l + 1] > p.convLevelOffsets[l])
                 launch_convolve(stream, p.view, dRecs, dHbm, dGlobals, p.convLevelOffsets[l], p.convLevelOffsets[l + 1] - p.convLevelOffsets[l]);
             (void)hipEventRecord(ev[2 * l + 1], stream);
         }
         (void)hipEventRecord(ev[2 * L], stream);
-        launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, dOutRing);
+        if (batch > 1) launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, dOutRing, batch, arenaFloats);
+        else launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, dOutRing);
         (void)hipEventRecord(ev[2 * L + 1], stream);
         (void)hipEventRecord(ev[2 * L + 2], stream);
         (void)hipEventRecord(ev[2 * L + 3], stream);
         if (hipStreamSynchronize(stream) != hipSuccess) return -kHipError;
         for (size_t l = 0; l <= L + 1; ++l) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[2 * l], ev[2 * l + 1]); acc[l] += ms; }
-        mirrorRootFades(p, (uint32_t)blockSize, (uint32_t)nOut, 0);
-        hGlobals.sampleTime += blockSize;
-        st.blocksRendered++;
+        for (uint32_t k = 0; k < batch; ++k) mirrorRootFades(p, (uint32_t)blockSize, (uint32_t)nOut, 0);
+        hGlobals.sampleTime += (int64_t)blockSize * batch;
+        st.blocksRendered += batch;
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     // an empty event pair measures the marker-to-marker cost that every timed launch also pays
     const double empty = acc[L + 1] / (double)std::max<size_t>(numBlocks, 1);
     for (size_t l = 0; l <= L; ++l) msOut[l] = (float)std::max(0.0, acc[l] / (double)std::max<size_t>(numBlocks, 1) - empty);
     if (cap > L + 1) msOut[L + 1] = (float)empty;
+    if (cap > L + 2) msOut[L + 2] = (float)batch;   // blocks per timed launch
     return (int)(L + 1);
 }
 
@@ -983,14 +997,14 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
     if (hipSetDevice(device) != hipSuccess) return kHipError;
     int rc = swapInPending();
     if (rc != kOk) return rc;
-    if (!current || cap < 4 * 192) return kInvalidPropertyValue;
+    if (!current || cap < kWaves * 192) return kInvalidPropertyValue;
     const Plan& p = *current;
     const size_t L = p.levelOffsets.size() - 1;
     rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize);
     if (rc != kOk) return rc;
     unsigned long long* dTrace = nullptr;
-    HIP_OK(hipMalloc(&dTrace, 4 * 192 * 8));
-    HIP_OK(hipMemset(dTrace, 0, 4 * 192 * 8));
+    HIP_OK(hipMalloc(&dTrace, kWaves * 192 * 8));
+    HIP_OK(hipMemset(dTrace, 0, kWaves * 192 * 8));
     if (hGlobals.ringSlots != 1 || hGlobals.blockSlot != 0) {
         hGlobals.ringSlots = 1; hGlobals.blockSlot = 0;
         patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, ringSlots) / 4), 1u, 0u});
@@ -1000,22 +1014,55 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
     setInRing(nullptr, 0);
     flushPending();
     const uint64_t tp = (uint64_t)reinterpret_cast<uintptr_t>(dTrace);
+    const uint32_t batch = (timeBatch > 1 && batchEligible(p, nOut)) ? (uint32_t)timeBatch : 1u;
+    const uint32_t arenaFloats = batch > 1 ? p.numHbmBuffers * (uint32_t)blockSize : 0u;
+    if (batch > 1) {
+        rc = ensureHbm((size_t)p.numHbmBuffers * batch); if (rc != kOk) return rc;
+        rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize * batch); if (rc != kOk) return rc;
+    }
     for (size_t l = 0; l < L; ++l) {
         const uint32_t lb = p.levelOffsets[l], le = p.levelOffsets[l + 1];
         const uint64_t v = (l == level) ? tp : 0;
         HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(dGlobals) + offsetof(Globals, trace), &v, 8, hipMemcpyHostToDevice, stream));
-        if (le > lb) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l]);
+        if (le > lb) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l], batch, arenaFloats);
     }
     const uint64_t zero = 0;
     HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(dGlobals) + offsetof(Globals, trace), &zero, 8, hipMemcpyHostToDevice, stream));
-    launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, dOutRing);
+    if (batch > 1) launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, dOutRing, batch, arenaFloats);
+    else launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, dOutRing);
     HIP_OK(hipStreamSynchronize(stream));
-    HIP_OK(hipMemcpy(out, dTrace, 4 * 192 * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(out, dTrace, kWaves * 192 * 8, hipMemcpyDeviceToHost));
     (void)hipFree(dTrace);
-    mirrorRootFades(p, (uint32_t)blockSize, (uint32_t)nOut, 0);
-    hGlobals.sampleTime += blockSize;
-    st.blocksRendered++;
+    for (uint32_t k = 0; k < batch; ++k) mirrorRootFades(p, (uint32_t)blockSize, (uint32_t)nOut, 0);
+    hGlobals.sampleTime += (int64_t)blockSize * batch;
+    st.blocksRendered += batch;
     return kOk;
+}
+
+// A multi-block launch carries no per-block root/tap/convolver bookkeeping: it is used only while every
+// running root's fade is settled (Core.h:28-31) and the plan has neither taps nor convolvers.
+bool Engine::batchEligible(const Plan& p, size_t nOut) const {
+    if (!p.taps.empty() || !p.convs.empty()) return false;
+    for (int32_t id : p.rootIds) {
+        auto it = nodes.find(id);
+        if (it == nodes.end()) return false;
+        const Node& r = it->second;
+        const bool on = r.target > 0.5f;
+        const bool settled = std::fabs(r.target - r.gain) <= 1e-6f;
+        const bool running = (on || !settled) && r.channel >= 0 && (uint32_t)r.channel < nOut;
+        if (running && r.gain != r.target) return false;
+    }
+    return true;
+}
+
+void Engine::enqueueBatch(const Plan& p, uint32_t batch) {
+    const uint32_t arenaFloats = p.numHbmBuffers * (uint32_t)blockSize;
+    const size_t L = p.levelOffsets.size() - 1;
+    for (size_t l = 0; l < L; ++l) {
+        const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
+        if (e > b) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats);
+    }
+    launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, dOutRing, batch, arenaFloats);
 }
 
 int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime) {
@@ -1037,6 +1084,28 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
     setGlobalsFor(nIn, nOut, bs, sampleTime);
     size_t done = 0;
     while (done < numBlocks) {
+        if (batchBlocks > 1 && numBlocks - done > 1 && batchEligible(p, nOut)) {
+            // ---- multi-block launches: one kernel per level renders `chunk` blocks (kernels.hip) ----
+            const size_t chunk = std::min((size_t)batchBlocks, numBlocks - done);
+            rc = ensureHbm((size_t)p.numHbmBuffers * (size_t)batchBlocks);
+            if (rc != kOk) return rc;
+            rc = ensureOutRing(std::max<size_t>(nOut, 1) * bs * (size_t)batchBlocks);
+            if (rc != kOk) return rc;
+            setInRing(nullptr, 0);
+            hGlobals.blockSlot = 0;
+            if (haveIn)   // host inputs of block b -> arena buffers 0..nIn-1 of block b's arena
+                HIP_OK(hipMemcpy2DAsync(dHbm, (size_t)p.numHbmBuffers * bs * sizeof(float), inDev + done * nIn * bs, nIn * bs * sizeof(float),
+                                        nIn * bs * sizeof(float), chunk, hipMemcpyDeviceToDevice, stream));
+            flushPending();
+            enqueueBatch(p, (uint32_t)chunk);
+            if (outDev && nOut > 0)
+                HIP_OK(hipMemcpyAsync(outDev + done * nOut * bs, dOutRing, chunk * nOut * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            hGlobals.sampleTime += (int64_t)(chunk * bs);
+            done += chunk;
+            st.blocksRendered += chunk;
+            st.batchLaunches++;
+            continue;
+        }
         const size_t chunk = std::min(G, numBlocks - done);
         // ring geometry for this chunk
         if (hGlobals.ringSlots != (uint32_t)G || hGlobals.blockSlot != 0) {

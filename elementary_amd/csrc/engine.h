@@ -75,7 +75,7 @@ struct Stats {
     uint64_t plansBuilt = 0;
     double   lastPlanBuildMs = 0.0;
     uint32_t numIslands = 0, numLevels = 0, numTasks = 0, numNodesInPlan = 0, maxLdsBytes = 0, numHbmBuffers = 0;
-    uint64_t graphReplays = 0, graphCaptures = 0;
+    uint64_t graphReplays = 0, graphCaptures = 0, batchLaunches = 0;
 };
 
 class Engine {
@@ -111,6 +111,7 @@ public:
     // dry-engine introspection for host-logic tests: adopt the pending plan and describe it as JSON
     std::string describePlan();
     int setOption(const std::string& key, double value);
+    uint32_t lastTimedBatch() const { return lastTimeBatch; }
 
 private:
     friend struct PlanBuilder;
@@ -159,6 +160,10 @@ private:
     uint32_t maxLdsConfigured = 0;
     bool useGraph = true;
     int  graphBlocks = 8;
+    int  batchBlocks = 16;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)
+    int  pipelineCopies = 4;               // blocks a stateful island keeps in flight inside a multi-block launch
+    int  timeBatch = 1;
+    uint32_t lastTimeBatch = 1;            // blocks per launch the last timeLaunches actually used                    // timeLaunches: blocks per timed launch
 
     uint32_t allocRec();
     void writeParam(Node& n, uint32_t dword, uint32_t value);
@@ -175,6 +180,8 @@ private:
     int  ensureOutRing(size_t floats);
     int  swapInPending();
     void enqueueBlock(const Plan& p);
+    void enqueueBatch(const Plan& p, uint32_t batch);
+    bool batchEligible(const Plan& p, size_t nOut) const;
     void mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn);
     int  setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime);
     void setInRing(const float* ring, uint32_t blocks);

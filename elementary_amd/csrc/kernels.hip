@@ -45,6 +45,7 @@ struct Ctx {
     uint32_t        lane;
     float           srF;
     double          sr;
+    int64_t         sampleTime;   // of the block being rendered (a multi-block launch advances it per block)
 };
 
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -415,7 +416,7 @@ __device__ __forceinline__ void run_prewarp(const Ctx& c, const Member& m, uint3
 // SampleTimeNode (wasm/SampleTime.h:11-24), MetronomeNode (wasm/Metro.h:40-55)
 template <int V>
 __device__ __forceinline__ void run_time(const Ctx& c, const Member& m, uint32_t i, uint32_t nlim) {
-    const int64_t st = c.g->sampleTime;
+    const int64_t st = c.sampleTime;
     vmap<V>(c, m, i, nlim, [&](uint32_t t) { return (float)(double)((uint64_t)st + (uint64_t)t); });
 }
 template <int V>
@@ -423,7 +424,7 @@ __device__ __forceinline__ void run_metro(const Ctx& c, const Member& m, uint32_
     gcup r = c.recs + m.rec * kRecDwords;
     const int64_t is64 = (int64_t)((uint64_t)r[rec::P0] | ((uint64_t)r[rec::P1] << 32));
     const double is = (double)is64;
-    const int64_t st = c.g->sampleTime;
+    const int64_t st = c.sampleTime;
     vmap<V>(c, m, i, nlim, [&](uint32_t t) {
         const double tt = (double)((uint64_t)st + (uint64_t)t) / is;
         return ((tt - floor(tt)) < 0.5) ? 1.0f : 0.0f;
@@ -1446,22 +1447,18 @@ __device__ __forceinline__ void run_fast(const Ctx& c, const TaskU& t, uint32_t 
     float x[V], y[V];
     fast_load<V>(t.o0, i, x);
     const uint32_t op = t.opcode;
-    if (op >= OP_LE) {   // binary / two-operand reduce
+    if (op >= OP_LE) {   // binary / two-operand reduce: one switch per task, straight-line loops inside each case
         fast_load<V>(t.o1, i, y);
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-            float r;
-            switch (op) {
-                case OP_ADD: r = x[q] + y[q]; break;
-                case OP_SUB: r = x[q] - y[q]; break;
-                case OP_MUL: r = x[q] * y[q]; break;
-                case OP_DIV: r = reduce_eval(OP_DIV, x[q], y[q]); break;
-                case OP_MIN: r = reduce_eval(OP_MIN, x[q], y[q]); break;
-                case OP_MAX: r = reduce_eval(OP_MAX, x[q], y[q]); break;
-                case OP_MOD: r = fmodf(x[q], y[q]); break;
-                default:     r = binary_eval((uint16_t)op, x[q], y[q]); break;
-            }
-            x[q] = r;
+        switch (op) {
+#define FB(OPC, EXPR) case OPC: _Pragma("unroll") for (int q = 0; q < V; ++q) x[q] = (EXPR); break;
+            FB(OP_ADD, x[q] + y[q]) FB(OP_SUB, x[q] - y[q]) FB(OP_MUL, x[q] * y[q])
+            FB(OP_DIV, reduce_eval(OP_DIV, x[q], y[q])) FB(OP_MIN, reduce_eval(OP_MIN, x[q], y[q])) FB(OP_MAX, reduce_eval(OP_MAX, x[q], y[q]))
+            FB(OP_MOD, fmodf(x[q], y[q]))
+            FB(OP_LE, binary_eval(OP_LE, x[q], y[q])) FB(OP_LEQ, binary_eval(OP_LEQ, x[q], y[q])) FB(OP_GE, binary_eval(OP_GE, x[q], y[q]))
+            FB(OP_GEQ, binary_eval(OP_GEQ, x[q], y[q])) FB(OP_POW, binary_eval(OP_POW, x[q], y[q])) FB(OP_EQ, binary_eval(OP_EQ, x[q], y[q]))
+            FB(OP_AND, binary_eval(OP_AND, x[q], y[q]))
+            default: _Pragma("unroll") for (int q = 0; q < V; ++q) x[q] = binary_eval(OP_OR, x[q], y[q]); break;
+#undef FB
         }
     } else {
         switch (op) {   // one switch per task, the loops inside each case are straight-line
@@ -1561,21 +1558,40 @@ __device__ __forceinline__ bool root_running(gcup recs, uint32_t rootRec, uint32
 } // namespace
 
 // ---- kernels ---------------------------------------------------------------------------------------
+// One launch renders one island level for `batch` consecutive blocks (1 = the realtime path).
+//   * batch == 1, or a stateless island: stages are separated by workgroup barriers; a stateless island's
+//     blocks are spread over gridDim.y (nothing carries over from block to block).
+//   * stateful island, batch > 1: software pipeline over blocks. The island keeps `copies` (D) blocks in
+//     flight, block b in buffer set b % D with its own program copy. The planner cuts the S stages into D phases
+//     of consecutive stages (balanced by estimated cost); in macro-step m every wave runs its phase-p tasks of block m - p. A task of
+//     stage s waits (LDS counters) until the previous non-empty stage of ITS block is complete and until
+//     block b - D has left the pipeline, so its buffer set is free. Every wait refers to work of an earlier
+//     macro/micro step and all waves walk the steps in the same order, so the schedule cannot deadlock.
+//     Node state lives in the node records; the same wave renders a node for every block, in block order.
+__device__ __forceinline__ void wait_counter(uint32_t word, uint32_t need) {
+    uint32_t* p = reinterpret_cast<uint32_t*>(lds + word);
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+}
+
 __global__ __launch_bounds__(kThreads)
 void elemhip_island_kernel(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, const uint32_t* lcg,
-                           uint32_t levelBegin) {
+                           uint32_t levelBegin, uint32_t batch, uint32_t arenaFloats) {
     const uint64_t tStart = clock64();
     const uint32_t entry = pv.levelIslands[levelBegin + blockIdx.x];
     const Island isl = pv.islands[entry & 0xFFFFFFu];
     const uint32_t splitIdx = entry >> 24;
     const uint32_t numOut = g->numOut;
     if (!root_running((gcup)recs, isl.rootRec, numOut)) return;
+    const bool pipe = batch > 1u && !isl.stateless;
+    if (pipe && blockIdx.y != 0u) return;                       // a stateful island renders all its blocks in one workgroup
+    if (!pipe && blockIdx.y >= batch) return;
 
     // stage the island program in LDS (one coalesced copy), then fill the broadcast cells
     uint32_t* progLds = reinterpret_cast<uint32_t*>(lds + isl.ldsProg);
     gcup prog = (gcup)(pv.prog + isl.progBegin);
     for (uint32_t k = threadIdx.x; k < isl.progDwords; k += kThreads) progLds[k] = prog[k];
     if (threadIdx.x < kSlot0) lds[threadIdx.x] = 0.0f;
+    for (uint32_t k = threadIdx.x; k < isl.numStages * isl.copies; k += kThreads) reinterpret_cast<uint32_t*>(lds + isl.ldsCounters)[k] = 0u;
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < isl.numCells; k += kThreads) {
         const uint32_t word = progLds[isl.cellOff + 2 * k], rec_ = progLds[isl.cellOff + 2 * k + 1];
@@ -1589,62 +1605,106 @@ void elemhip_island_kernel(PlanView pv, uint32_t* recs, float* hbm, const Global
     c.n = g->numSamples; c.stride = g->blockStride; c.numIn = g->numIn;
     c.lane = threadIdx.x & 63u;
     c.srF = g->sampleRateF; c.sr = g->sampleRate;
+    const int64_t sampleTime0 = g->sampleTime;
+    c.sampleTime = sampleTime0;
     const uint32_t wave = UNI(threadIdx.x >> 6);
     // frames this workgroup renders (whole block unless the island is split)
     const uint32_t lo = isl.split > 1 ? (splitIdx * c.stride) / isl.split : 0u;
     const uint32_t hi = isl.split > 1 ? ((splitIdx + 1) * c.stride) / isl.split : 0xFFFFu;
 
-    unsigned long long* trace = (blockIdx.x == 0 && g->trace) ? reinterpret_cast<unsigned long long*>(g->trace) + (size_t)levelBegin * 0 : nullptr;
+    unsigned long long* trace = (blockIdx.x == 0 && blockIdx.y == 0 && g->trace) ? reinterpret_cast<unsigned long long*>(g->trace) : nullptr;
     const uint64_t tProlog = clock64();
-    uint32_t stage = 0;
-    const uint32_t tb = wave == 0 ? isl.waveTask[0] : wave == 1 ? isl.waveTask[1] : wave == 2 ? isl.waveTask[2] : isl.waveTask[3];
-    const uint32_t te = wave == 0 ? isl.waveTask[1] : wave == 1 ? isl.waveTask[2] : wave == 2 ? isl.waveTask[3] : isl.waveTask[4];
-    for (uint32_t ti = tb; ti < te; ++ti) {
-        const v4u h = lds4u(isl.ldsProg + ti * 8u), h2 = lds4u(isl.ldsProg + ti * 8u + 4u);
-        const uint32_t d0 = UNI(h.x), d1 = UNI(h.y), d6 = UNI(h2.z);
-        TaskU t;
-        t.opcode = d0 & 0xFFFFu; t.stage = (d0 >> 16) & 0xFFu; t.flags = d0 >> 24;
-        t.s0 = d1 & 0xFFFFu; t.s1 = d1 >> 16;
-        t.first = UNI(h.z); t.count = UNI(h.w);
-        t.o0 = UNI(h2.x); t.o1 = UNI(h2.y); t.outLds = d6 & 0xFFFFu; t.nin = d6 >> 16; t.outHbm = UNI(h2.w);
-        while (stage < t.stage) { __syncthreads(); ++stage; }
-        // ELEMHIP trace hook: [wave][slot] = {opcode | stage << 16, start, end} in shader clocks
-        const uint64_t t0 = trace ? clock64() : 0;
-        if ((t.flags & 0x80u) && t.s1 <= c.n && isl.split <= 1u) {
-            const uint32_t V = (t.s1 - t.s0) >> 6, i = t.s0 + c.lane * V;
-            if (V == 2u) run_fast<2>(c, t, i);
-            else if (V == 8u) run_fast<8>(c, t, i);
-            else if (V == 4u) { run_fast<2>(c, t, i); run_fast<2>(c, t, i + 2u); }
-            else run_fast<1>(c, t, i);
-        } else
-        run_task(c, t, lo, hi);
-        if (trace) {
-            const uint64_t t1 = clock64();
-            const uint32_t slot = ti - tb;
-            if (c.lane == 0 && slot < 62) {
-                unsigned long long* w = trace + (size_t)wave * 192 + 3 * (slot + 2);
-                w[0] = d0; w[1] = t0; w[2] = t1;
+    const uint32_t S = isl.numStages, D = pipe ? isl.copies : 1u;
+    const uint32_t tabT = isl.ldsProg + isl.stageOff, tabPrev = tabT + S, tabBegin = tabPrev + S + wave * (S + 1u);
+
+    const uint32_t lastStage = S - 1u;                           // the planner never leaves the last stage empty
+    const uint32_t myBlocks = (batch - blockIdx.y + gridDim.y - 1u) / gridDim.y;
+    const uint32_t steps = myBlocks * S;
+    uint32_t traceSlot = 0;
+    // pipelined walk: this wave's own (stage, phase) slots, macro-step by macro-step
+    const uint32_t walkOffs = isl.ldsProg + isl.schedOff;
+    const uint32_t e0 = UNI(ldsu(walkOffs + wave)), e1 = UNI(ldsu(walkOffs + wave + 1u));
+    const uint32_t walkBase = walkOffs + kWaves + 1u;            // the planner pads in front of the offsets: entries are 16-byte aligned
+    const uint32_t lastT = UNI(ldsu(tabT + lastStage));
+    uint32_t pm = 0, pe = e0;
+    uint32_t bbi = 0, bs_ = 0;                  // barrier walk: block of this workgroup, stage
+    const uint32_t steps2 = pipe ? (batch + D - 1u) * (e1 - e0) : steps;
+    for (uint32_t it = 0; it < steps2; ++it) {
+        uint32_t b, s, tb, te, prev = kNone, prevT = 0;
+        if (pipe) {
+            const v4u ea = lds4u(walkBase + pe * 8u), eb = lds4u(walkBase + pe * 8u + 4u);
+            s = UNI(ea.x); b = pm - UNI(ea.y);                   // wraps when pm < phase: caught by b >= batch
+            tb = UNI(ea.z); te = UNI(ea.w); prev = UNI(eb.x); prevT = UNI(eb.y);
+            if (++pe == e1) { pe = e0; ++pm; }
+            if (b >= batch) continue;
+        } else {
+            b = blockIdx.y + bbi * gridDim.y;
+            s = bs_;
+            if (++bs_ == S) { bs_ = 0u; ++bbi; }
+            if (it > 0u) __syncthreads();
+            tb = UNI(ldsu(tabBegin + s)); te = UNI(ldsu(tabBegin + s + 1u));
+        }
+        if (tb == te) continue;
+        const uint32_t use = !pipe ? 0u : (D == 3u ? b / 3u : (D == 4u ? b >> 2 : (D == 2u ? b >> 1 : b)));
+        const uint32_t copy = pipe ? b - use * D : 0u;
+        const uint32_t progBase = isl.ldsProg + copy * isl.copyDwords;
+        c.members = progBase + isl.memOff; c.operands = progBase + isl.opndOff;
+        c.hbm = (gfp)hbm + (size_t)b * arenaFloats;
+        c.sampleTime = sampleTime0 + (int64_t)b * (int64_t)c.n;
+        if (pipe) {
+            // completion counters are per (stage, buffer set): block b is use number b / D of set b % D. (One counter per
+            // stage would let a wave that runs a block ahead satisfy the count meant for a slower wave's task.)
+            if (prev != kNone) wait_counter(isl.ldsCounters + prev * D + copy, (use + 1u) * prevT);
+            if (use > 0u) wait_counter(isl.ldsCounters + lastStage * D + copy, use * lastT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        for (uint32_t ti = tb; ti < te; ++ti) {
+            const v4u h = lds4u(progBase + ti * 8u), h2 = lds4u(progBase + ti * 8u + 4u);
+            const uint32_t d0 = UNI(h.x), d1 = UNI(h.y), d6 = UNI(h2.z);
+            TaskU t;
+            t.opcode = d0 & 0xFFFFu; t.stage = (d0 >> 16) & 0xFFu; t.flags = d0 >> 24;
+            t.s0 = d1 & 0xFFFFu; t.s1 = d1 >> 16;
+            t.first = UNI(h.z); t.count = UNI(h.w);
+            t.o0 = UNI(h2.x); t.o1 = UNI(h2.y); t.outLds = d6 & 0xFFFFu; t.nin = d6 >> 16; t.outHbm = UNI(h2.w);
+            // ELEMHIP trace hook: [wave][slot] = {opcode | stage << 16, start, end} in shader clocks
+            const uint64_t t0 = trace ? clock64() : 0;
+            if ((t.flags & 0x80u) && t.s1 <= c.n && isl.split <= 1u) {
+                const uint32_t V = (t.s1 - t.s0) >> 6, i = t.s0 + c.lane * V;
+                if (V == 2u) run_fast<2>(c, t, i);
+                else if (V == 8u) run_fast<8>(c, t, i);
+                else if (V == 4u) { run_fast<2>(c, t, i); run_fast<2>(c, t, i + 2u); }
+                else run_fast<1>(c, t, i);
+            } else
+            run_task(c, t, lo, hi);
+            if (trace) {
+                const uint64_t t1 = clock64();
+                if (c.lane == 0 && traceSlot < 62) {
+                    unsigned long long* w = trace + (size_t)wave * 192 + 3 * (traceSlot + 2);
+                    w[0] = d0 | ((unsigned long long)b << 32); w[1] = t0; w[2] = t1;
+                }
+                ++traceSlot;
             }
+        }
+        if (pipe) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (c.lane == 0)
+                __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(lds + isl.ldsCounters + s * D + copy), te - tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     if (trace && c.lane == 0) {
         unsigned long long* w = trace + (size_t)wave * 192;
-        w[0] = te - tb; w[1] = tStart; w[2] = tProlog; w[3] = clock64();
+        w[0] = traceSlot; w[1] = tStart; w[2] = tProlog; w[3] = clock64();
     }
-    while (stage + 1 < isl.numStages) { __syncthreads(); ++stage; }
 }
 
 // Epilogue: one workgroup. (1) zero + sum running roots into the output bus in render-sequence
 // order (GraphRenderSequence.h:286-295, 227-231); (2) promote tap buffers of active roots
 // (:306-308, Feedback.h:90-109); (3) advance root fades (GainFade.h:70-71); (4) advance the block.
-__global__ __launch_bounds__(1024)
-void elemhip_epilogue_kernel(PlanView pv, uint32_t* recs_, const float* hbm_, Globals* g, float* outRing) {
-    gup recs = (gup)recs_; gcfp hbm = (gcfp)hbm_;
+// output bus of one block: zero + sum the running roots per channel in render-sequence order
+__device__ __forceinline__ void bus_sum(const PlanView& pv, gcup recs, gcfp hbm, gfp out, uint32_t n, uint32_t numOut, uint32_t stride) {
     __shared__ int rootChan[1024];        // channel of root r if it ran this block, else -1
     __shared__ uint16_t chanList[1024];   // running roots grouped by channel, render-sequence order inside a channel
     __shared__ uint16_t chanStart[kMaxOut + 1];
-    const uint32_t n = g->numSamples, numOut = min(g->numOut, (uint32_t)kMaxOut), stride = g->blockStride;
-    gfp out = (gfp)(outRing + (size_t)g->blockSlot * numOut * stride);
     const uint32_t nr = min(pv.numRoots, 1024u);
     for (uint32_t r = threadIdx.x; r < nr; r += blockDim.x) {
         const uint32_t rr = pv.roots[r].rec;
@@ -1675,6 +1735,26 @@ void elemhip_epilogue_kernel(PlanView pv, uint32_t* recs_, const float* hbm_, Gl
         }
         out[(size_t)ch * stride + i] = acc;
     }
+}
+
+// Epilogue of a multi-block launch: workgroup b sums block b's roots into output-ring slot b. The host only
+// batches blocks while every running root's fade is settled and the plan has no taps / convolvers, so there
+// is no per-block state to advance besides the sample clock.
+__global__ __launch_bounds__(1024)
+void elemhip_epilogue_batch_kernel(PlanView pv, uint32_t* recs_, const float* hbm_, Globals* g, float* outRing,
+                                   uint32_t batch, uint32_t arenaFloats) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = g->numSamples, numOut = min(g->numOut, (uint32_t)kMaxOut), stride = g->blockStride;
+    bus_sum(pv, (gcup)recs_, (gcfp)hbm_ + (size_t)b * arenaFloats, (gfp)(outRing + (size_t)b * numOut * stride), n, numOut, stride);
+    if (b == 0 && threadIdx.x == 0) { g->sampleTime += (int64_t)n * (int64_t)batch; g->blockSlot = 0; }
+}
+
+__global__ __launch_bounds__(1024)
+void elemhip_epilogue_kernel(PlanView pv, uint32_t* recs_, const float* hbm_, Globals* g, float* outRing) {
+    gup recs = (gup)recs_; gcfp hbm = (gcfp)hbm_;
+    const uint32_t n = g->numSamples, numOut = min(g->numOut, (uint32_t)kMaxOut), stride = g->blockStride;
+    gfp out = (gfp)(outRing + (size_t)g->blockSlot * numOut * stride);
+    bus_sum(pv, recs, hbm, out, n, numOut, stride);
     for (uint32_t k = 0; k < pv.numTaps; ++k) {
         const TapEntry te = pv.taps[k];
         gcup rr = recs + te.rootRec * kRecDwords;
@@ -1736,12 +1816,19 @@ hipError_t configure_kernels(uint32_t maxLdsBytes) {
 }
 
 void launch_level(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, const uint32_t* lcg,
-                  uint32_t levelBegin, uint32_t numIslands, uint32_t ldsBytes) {
-    hipLaunchKernelGGL(elemhip_island_kernel, dim3(numIslands), dim3(kThreads), ldsBytes, s, pv, recs, hbm, g, lcg, levelBegin);
+                  uint32_t levelBegin, uint32_t numIslands, uint32_t ldsBytes, uint32_t batch, uint32_t arenaFloats) {
+    // gridDim.y: blocks of a batch that stateless islands render concurrently
+    const uint32_t gy = batch > 1u ? (batch < 8u ? batch : 8u) : 1u;
+    hipLaunchKernelGGL(elemhip_island_kernel, dim3(numIslands, gy), dim3(kThreads), ldsBytes, s, pv, recs, hbm, g, lcg, levelBegin, batch, arenaFloats);
 }
 
 void launch_epilogue(hipStream_t s, const PlanView& pv, uint32_t* recs, const float* hbm, Globals* g, float* outRing) {
     hipLaunchKernelGGL(elemhip_epilogue_kernel, dim3(1), dim3(1024), 0, s, pv, recs, hbm, g, outRing);
+}
+
+void launch_epilogue_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, const float* hbm, Globals* g, float* outRing,
+                           uint32_t batch, uint32_t arenaFloats) {
+    hipLaunchKernelGGL(elemhip_epilogue_batch_kernel, dim3(batch), dim3(1024), 0, s, pv, recs, hbm, g, outRing, batch, arenaFloats);
 }
 
 void launch_patches(hipStream_t s, const Patch* patches, uint32_t count, uint32_t* recs, uint32_t* globals) {

@@ -11,6 +11,7 @@
 // schedule each island's nodes into barrier-separated stages of wave tasks, allocate LDS slots
 // by liveness, and order islands into launch levels.
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <functional>
 #include <numeric>
@@ -136,10 +137,10 @@ struct PlanBuilder {
         }
     }
 
-    std::shared_ptr<Plan> build(uint32_t maxIslandNodes);
+    std::shared_ptr<Plan> build(uint32_t maxIslandNodes, uint32_t maxCopies);
 };
 
-std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
+std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCopies) {
     auto plan = std::make_shared<Plan>();
     Plan& p = *plan;
     const uint32_t bs = (uint32_t)e.blockSize;
@@ -454,7 +455,13 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
                 if (sc && x.n->op != OP_SVF && x.n->op != OP_SVFSHELF) x.scratch = takeSlots(stage, sc, stage);
             }
         }
-        const uint32_t slotWords = kSlot0 + (uint32_t)slotFreeAt.size() * kSlotWords;
+        const uint32_t slotArea = (uint32_t)slotFreeAt.size() * kSlotWords;      // block-buffer words of one copy
+        bool statelessIsland = true;
+        for (int k : B.nodes) if (ni[k].kind != K_PAR || ni[k].n->op == OP_TAPIN || ni[k].n->op == OP_TAPOUT) statelessIsland = false;
+        // blocks kept in flight by a multi-block launch: as many buffer sets as fit in ~96 KB of LDS
+        uint32_t copies = 1;
+        if (!statelessIsland && slotArea > 0) copies = std::max<uint32_t>(1, std::min<uint32_t>(maxCopies, (30u * 1024u) / slotArea));
+        const uint32_t slotWords = kSlot0 + copies * slotArea;                    // first word after every copy's buffers
 
         // island-local program tables
         std::vector<Task> tasks;
@@ -505,6 +512,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
         // ---- tasks, stage by stage ----
         // A sample-parallel task covers 64*V frames with V in {1,2,4,8} (lane l owns V consecutive
         // frames). The block is cut into 64-frame units handed out as power-of-two runs.
+        uint32_t* loadOut = nullptr;
         auto emitRanges = [&](uint16_t op, int stage, uint32_t first, uint32_t count, const std::vector<int>& waves) {
             const uint32_t units = (bs + 63) / 64;                      // 64-frame units (8 for a 512 block)
             std::vector<std::pair<uint32_t, uint32_t>> runs;            // (first unit, units)
@@ -523,6 +531,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
                     uint32_t take = 1; while (take * 2 <= un && take * 2 <= 8) take *= 2;
                     tasks.push_back(Task{op, (uint8_t)stage, 0, (uint16_t)(u0 * 64), (uint16_t)((u0 + take) * 64), first, count, 0, 0, 0, 0, 0});
                     taskWave.push_back(waves[w % waves.size()]);
+                    if (loadOut) loadOut[waves[w % waves.size()]] += 300u + 150u * take * count;
                     u0 += take; un -= take;
                 }
             }
@@ -537,6 +546,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
             }
             emitRanges(OP_COPY, 0, first, (uint32_t)imports.size(), {0, 1, 2, 3});
         }
+        uint32_t waveLoad[kWaves] = {};   // estimated cycles per block
+        loadOut = waveLoad;
         for (int stage = base; stage <= maxStage; ++stage) {
             std::map<uint32_t, std::vector<int>> chain;   // key: opcode | constMask << 16
             std::map<uint16_t, std::vector<int>> single;
@@ -559,16 +570,27 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
                 else if (x.kind == K_SINGLE) single[x.n->op].push_back(k);
                 else par[{x.sub, x.n->op}].push_back(k);
             }
-            uint32_t load[kWaves] = {0, 0, 0, 0};
-            auto leastLoaded = [&]() { int b = 0; for (int w = 1; w < (int)kWaves; ++w) if (load[w] < load[b]) b = w; return b; };
+            // Wave assignment. Inside one block the tasks of a stage want different waves; across the blocks of
+            // a pipelined multi-block launch each wave's TOTAL work per block bounds the throughput, so the
+            // heavy (serial) tasks go to the wave with the least work so far, idle-in-this-stage waves first.
+            uint32_t busy[kWaves] = {};
+            auto pickWave = [&]() {
+                int b = 0;
+                for (int w = 1; w < (int)kWaves; ++w)
+                    if (busy[w] < busy[b] || (busy[w] == busy[b] && waveLoad[w] < waveLoad[b])) b = w;
+                return b;
+            };
             for (auto& kv : chain) {
+                const uint16_t cop = (uint16_t)(kv.first & 0xFFFFu);
+                const uint32_t cost = (cop == OP_SVF || cop == OP_SVFSHELF || cop == OP_MM1P) ? 8000u
+                                    : (cop == OP_BLEPSAW || cop == OP_BLEPSQUARE || cop == OP_BLEPTRIANGLE) ? 16000u : 12000u;
                 for (size_t off = 0; off < kv.second.size(); off += 64) {
                     const uint32_t cnt = (uint32_t)std::min<size_t>(64, kv.second.size() - off);
                     const uint32_t first = (uint32_t)members.size();
                     for (uint32_t c = 0; c < cnt; ++c) members.push_back(makeMember(ni[kv.second[off + c]]));
-                    const int w = leastLoaded();
-                    load[w] += 1000;
-                    tasks.push_back(Task{(uint16_t)(kv.first & 0xFFFFu), (uint8_t)stage, (uint8_t)(kv.first >> 16), 0, (uint16_t)bs, first, cnt, 0, 0, 0, 0, 0});
+                    const int w = pickWave();
+                    busy[w] += 1; waveLoad[w] += cost;
+                    tasks.push_back(Task{cop, (uint8_t)stage, (uint8_t)(kv.first >> 16), 0, (uint16_t)bs, first, cnt, 0, 0, 0, 0, 0});
                     taskWave.push_back(w);
                 }
             }
@@ -576,19 +598,28 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
                 for (int k : kv.second) {
                     const uint32_t first = (uint32_t)members.size();
                     members.push_back(makeMember(ni[k]));
-                    const int w = leastLoaded();
-                    load[w] += 100;
+                    const int w = pickWave();
+                    busy[w] += 1; waveLoad[w] += 4000u;
                     tasks.push_back(Task{kv.first, (uint8_t)stage, 0, 0, (uint16_t)bs, first, 1, 0, 0, 0, 0, 0});
                     taskWave.push_back(w);
                 }
             }
             std::vector<int> freeWaves;
-            for (int w = 0; w < (int)kWaves; ++w) if (load[w] == 0) freeWaves.push_back(w);
-            if (freeWaves.empty()) freeWaves.push_back(leastLoaded());
+            for (int w = 0; w < (int)kWaves; ++w) if (busy[w] == 0) freeWaves.push_back(w);
+            if (freeWaves.empty()) freeWaves.push_back(pickWave());
+            std::sort(freeWaves.begin(), freeWaves.end(), [&](int a, int b) { return waveLoad[a] < waveLoad[b]; });
+            // Light sample-parallel ops cost mostly per-task overhead. In a pipelined island (blocks overlap, so
+            // there is always other work for the other waves) a stage's ops therefore run unsplit on ONE wave;
+            // stages with a filter-coefficient pre-pass (heavy, and fused with its producers) keep the 4-way split.
+            bool hasCoef = false;
+            for (auto& kv : par) if (kv.first.second == OP_SVF_COEF || kv.first.second == OP_SHELF_COEF) hasCoef = true;
+            std::vector<int> parWaves = freeWaves;
+            if (parWaves.size() > 4) parWaves.resize(4);   // a finer split only multiplies per-task overhead
+            if (copies > 1 && !hasCoef) parWaves = {freeWaves[0]};
             for (auto& kv : par) {
                 const uint32_t first = (uint32_t)members.size();
                 for (int k : kv.second) members.push_back(makeMember(ni[k]));
-                emitRanges(kv.first.second, stage, first, (uint32_t)kv.second.size(), freeWaves);
+                emitRanges(kv.first.second, stage, first, (uint32_t)kv.second.size(), parWaves);
             }
         }
         {   // per-wave task lists: sort by (wave, stage), keep emission order inside a (wave, stage)
@@ -631,25 +662,131 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes) {
             for (uint32_t o : operands) if ((o & kOpKindMask) == kOpHbm) hbmReads++;
             I.split = (pure && imports.empty() && hbmReads >= 8 && bs >= 128) ? std::min<uint32_t>(8, bs / 64) : 1;
         }
-        // pack the blob: [tasks | members | operands | cells]
+        // stage tables: tasks per stage, previous non-empty stage, per-wave first task of each stage
+        const uint32_t S = (uint32_t)maxStage + 1;
+        std::vector<uint32_t> stageTab(2 * S + kWaves * (S + 1) + copies + 1, 0u);
+        uint32_t schedRel = 0;
+        for (const Task& t : tasks) stageTab[t.stage]++;
+        {
+            uint32_t prev = kNone;
+            for (uint32_t st = 0; st < S; ++st) { stageTab[S + st] = prev; if (stageTab[st]) prev = st; }
+            for (uint32_t w = 0; w < kWaves; ++w) {
+                uint32_t* begin = stageTab.data() + 2 * S + w * (S + 1);
+                uint32_t ti = I.waveTask[w];
+                for (uint32_t st = 0; st <= S; ++st) {
+                    while (ti < I.waveTask[w + 1] && tasks[ti].stage < st) ++ti;
+                    begin[st] = ti;
+                }
+            }
+        }
+        {   // phases of the block pipeline: `copies` runs of consecutive stages minimising the costliest run,
+            // a stage costing what its busiest wave spends in it (the stages of one phase run back to back)
+            std::vector<uint32_t> cost(S, 0u);
+            {
+                std::vector<std::array<uint32_t, kWaves>> perWave(S);
+                for (auto& a : perWave) a.fill(0u);
+                for (size_t q = 0; q < tasks.size(); ++q) {
+                    const Task& t = tasks[q];
+                    uint32_t w = 0; while (w + 1 < kWaves && q >= I.waveTask[w + 1]) ++w;
+                    const uint16_t op = t.opcode;
+                    const uint32_t units = ((uint32_t)t.s1 - t.s0 + 63u) / 64u;
+                    uint32_t cst = 300u + 150u * units * t.count;                                  // light sample-parallel op
+                    if (op == OP_SVF_COEF || op == OP_SHELF_COEF) cst = 600u * units * t.count;
+                    else if (op == OP_SVF || op == OP_SVFSHELF || op == OP_MM1P) cst = 9000u * t.count;
+                    else if (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_BLEPTRIANGLE) cst = 19000u;
+                    else if (kindOf(op) == K_CHAIN) cst = 15000u;
+                    else if (kindOf(op) == K_SINGLE) cst = 4000u * t.count;
+                    perWave[t.stage][w] += cst;
+                }
+                for (uint32_t st = 0; st < S; ++st) cost[st] = 2000u + *std::max_element(perWave[st].begin(), perWave[st].end());
+            }
+            const uint32_t P = std::min<uint32_t>(copies, S);
+            // dp[p][j]: best max-run cost covering stages [0, j) with p runs
+            const uint64_t INF = ~0ull;
+            std::vector<std::vector<uint64_t>> dp(P + 1, std::vector<uint64_t>(S + 1, INF));
+            std::vector<std::vector<uint32_t>> cut(P + 1, std::vector<uint32_t>(S + 1, 0u));
+            std::vector<uint64_t> pre(S + 1, 0);
+            for (uint32_t j = 0; j < S; ++j) pre[j + 1] = pre[j] + cost[j];
+            dp[0][0] = 0;
+            for (uint32_t pp = 1; pp <= P; ++pp)
+                for (uint32_t j = pp; j <= S; ++j)
+                    for (uint32_t i0 = pp - 1; i0 < j; ++i0) {
+                        if (dp[pp - 1][i0] == INF) continue;
+                        const uint64_t v = std::max(dp[pp - 1][i0], pre[j] - pre[i0]);
+                        if (v < dp[pp][j]) { dp[pp][j] = v; cut[pp][j] = i0; }
+                    }
+            uint32_t* phase = stageTab.data() + 2 * S + kWaves * (S + 1);
+            for (uint32_t d = 0; d <= copies; ++d) phase[d] = S;     // unused trailing phases are empty
+            uint32_t j = S;
+            for (uint32_t pp = P; pp >= 1; --pp) { phase[pp] = j; j = cut[pp][j]; }
+            phase[0] = 0;
+            for (uint32_t d = P + 1; d <= copies; ++d) phase[d] = S;
+        }
+        {   // per-wave walk of the block pipeline: only the (stage, phase) slots where the wave has tasks, in the
+            // order the kernel visits them inside a macro-step (stage offset inside the phase ascending, oldest
+            // block = highest phase first); 8 dwords each: stage, phase, first task, end task, prev stage, its task count
+            const size_t base = 2 * S + kWaves * (S + 1);
+            std::vector<uint32_t> phaseOf(S, 0u);
+            for (uint32_t d = 0; d < copies; ++d) for (uint32_t st = stageTab[base + d]; st < stageTab[base + d + 1]; ++st) phaseOf[st] = d;
+            std::vector<uint32_t> offs(kWaves + 1, 0u), entries;
+            for (uint32_t w = 0; w < kWaves; ++w) {
+                const uint32_t* begin = stageTab.data() + 2 * S + w * (S + 1);
+                std::vector<uint32_t> mine;
+                for (uint32_t st = 0; st < S; ++st) if (begin[st + 1] > begin[st]) mine.push_back(st);
+                std::stable_sort(mine.begin(), mine.end(), [&](uint32_t a, uint32_t b) {
+                    const uint32_t sla = a - stageTab[base + phaseOf[a]], slb = b - stageTab[base + phaseOf[b]];
+                    return sla != slb ? sla < slb : phaseOf[a] > phaseOf[b]; });
+                for (uint32_t st : mine) {
+                    const uint32_t prev = stageTab[S + st];
+                    const uint32_t e[8] = {st, phaseOf[st], begin[st], begin[st + 1], prev, prev == kNone ? 0u : stageTab[prev], 0u, 0u};
+                    entries.insert(entries.end(), e, e + 8);
+                }
+                offs[w + 1] = (uint32_t)entries.size() / 8u;
+            }
+            while ((stageTab.size() + offs.size()) % 4) stageTab.push_back(0u);   // entries are read with 16-byte LDS loads
+            schedRel = (uint32_t)stageTab.size();
+            stageTab.insert(stageTab.end(), offs.begin(), offs.end());
+            stageTab.insert(stageTab.end(), entries.begin(), entries.end());
+        }
+        // pack the blob: copies x [tasks | members | operands] | cells | stage tables
         static_assert(sizeof(Task) == 32 && sizeof(Member) == 32 && sizeof(ConstCell) == 8, "program layout");
         I.progBegin = (uint32_t)p.prog.size();
         I.numTasks = (uint32_t)tasks.size();
         I.memOff = I.numTasks * 8u;
         I.opndOff = I.memOff + (uint32_t)members.size() * 8u;
-        I.cellOff = I.opndOff + (uint32_t)operands.size();
+        I.copyDwords = (I.opndOff + (uint32_t)operands.size() + 3u) & ~3u;
+        I.copies = copies;
+        I.stateless = statelessIsland ? 1u : 0u;
+        I.cellOff = I.copyDwords * copies;
         I.numCells = (uint32_t)cells.size();
-        I.progDwords = I.cellOff + I.numCells * 2u;
+        I.stageOff = (I.cellOff + I.numCells * 2u + 3u) & ~3u;
+        I.schedOff = I.stageOff + schedRel;
+        I.progDwords = I.stageOff + (uint32_t)stageTab.size();
         p.prog.resize((size_t)I.progBegin + I.progDwords);
-        uint32_t* blob = p.prog.data() + I.progBegin;
-        if (!tasks.empty()) std::memcpy(blob, tasks.data(), tasks.size() * sizeof(Task));
-        if (!members.empty()) std::memcpy(blob + I.memOff, members.data(), members.size() * sizeof(Member));
-        if (!operands.empty()) std::memcpy(blob + I.opndOff, operands.data(), operands.size() * 4);
-        if (!cells.empty()) std::memcpy(blob + I.cellOff, cells.data(), cells.size() * sizeof(ConstCell));
+        for (uint32_t d = 0; d < copies; ++d) {
+            const uint32_t off = d * slotArea;
+            auto adjOp = [&](uint32_t o) { return (o & kOpKindMask) == kOpLds ? o + off : o; };
+            std::vector<Task> tc(tasks);
+            std::vector<Member> mc(members);
+            std::vector<uint32_t> oc(operands);
+            for (Task& t : tc) { t.o0 = adjOp(t.o0); t.o1 = adjOp(t.o1); if (t.outLds16 != 0xFFFFu) t.outLds16 = (uint16_t)(t.outLds16 + off); }
+            for (Member& m : mc) { if (m.outLds != kNone) m.outLds += off; if (m.scratch != kNone) m.scratch += off; }
+            for (uint32_t& o : oc) o = adjOp(o);
+            uint32_t* blob = p.prog.data() + I.progBegin + (size_t)d * I.copyDwords;
+            if (!tc.empty()) std::memcpy(blob, tc.data(), tc.size() * sizeof(Task));
+            if (!mc.empty()) std::memcpy(blob + I.memOff, mc.data(), mc.size() * sizeof(Member));
+            if (!oc.empty()) std::memcpy(blob + I.opndOff, oc.data(), oc.size() * 4);
+        }
+        {
+            uint32_t* blob = p.prog.data() + I.progBegin;
+            if (!cells.empty()) std::memcpy(blob + I.cellOff, cells.data(), cells.size() * sizeof(ConstCell));
+            std::memcpy(blob + I.stageOff, stageTab.data(), stageTab.size() * 4);
+        }
         while (p.prog.size() % 4) p.prog.push_back(0);   // keep every blob 16-byte aligned
-        I.numStages = (uint32_t)maxStage + 1;
+        I.numStages = S;
         I.ldsProg = (slotWords + (uint32_t)cellOf.size() + 3u) & ~3u;
-        I.ldsWords = (I.ldsProg + I.progDwords + 3u) & ~3u;
+        I.ldsCounters = (I.ldsProg + I.progDwords + 3u) & ~3u;
+        I.ldsWords = (I.ldsCounters + S * copies + 3u) & ~3u;
         p.maxLdsBytes = std::max(p.maxLdsBytes, I.ldsWords * 4u);
         p.numTasks += I.numTasks; p.numMembers += (uint32_t)members.size(); p.numOperands += (uint32_t)operands.size();
     }
@@ -692,7 +829,7 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     const uint32_t ldsLimit = 160u * 1024u - 1024u;
     for (uint32_t limit = 56; limit >= 4; limit /= 2) {
         PlanBuilder b(*this);
-        plan = b.build(limit);
+        plan = b.build(limit, (uint32_t)std::max(1, pipelineCopies));
         if (!plan) return nullptr;
         if (plan->maxLdsBytes <= ldsLimit) break;
         plan.reset();
@@ -770,7 +907,8 @@ std::string Engine::describePlan() {
         if (i) s += ",";
         s += "{\"tasks\":" + std::to_string(I.numTasks) + ",\"stages\":" + std::to_string(I.numStages) +
              ",\"lds_bytes\":" + std::to_string(I.ldsWords * 4) + ",\"consts\":" + std::to_string(I.numCells) +
-             ",\"prog_dwords\":" + std::to_string(I.progDwords) + "}";
+             ",\"prog_dwords\":" + std::to_string(I.progDwords) + ",\"copies\":" + std::to_string(I.copies) +
+             ",\"stateless\":" + std::to_string(I.stateless) + "}";
         if (i >= 63) break;
     }
     s += "]}";

@@ -53,7 +53,7 @@ class _Stats(C.Structure):
         ("blocks_rendered", C.c_uint64), ("plans_built", C.c_uint64), ("last_plan_build_ms", C.c_double),
         ("num_islands", C.c_uint32), ("num_levels", C.c_uint32), ("num_tasks", C.c_uint32),
         ("num_nodes_in_plan", C.c_uint32), ("max_lds_bytes", C.c_uint32), ("num_hbm_buffers", C.c_uint32),
-        ("graph_replays", C.c_uint64), ("graph_captures", C.c_uint64),
+        ("graph_replays", C.c_uint64), ("graph_captures", C.c_uint64), ("batch_launches", C.c_uint64),
     ]
 
 
@@ -106,8 +106,9 @@ class Runtime(CRuntime):
         k = self._lib.elemhip_time_launches(self._h, num_outputs, int(num_blocks), buf, 64)
         if k < 0:
             raise ElemHipError(f"elemhip_time_launches failed: {describe(-k)}")
-        self.sample_time += int(num_blocks) * self.block_size
         self.last_event_overhead_ms = float(buf[k])   # empty event pair, already subtracted
+        self.last_time_batch = max(1, int(buf[k + 1]))   # blocks per timed launch (option "time_batch")
+        self.sample_time += int(num_blocks) * self.block_size * self.last_time_batch
         return [float(buf[i]) for i in range(k)]
 
     def describe_plan(self) -> Dict[str, Any]:

@@ -32,6 +32,7 @@ typedef struct elemhip_stats {
     double   last_plan_build_ms;
     uint32_t num_islands, num_levels, num_tasks, num_nodes_in_plan, max_lds_bytes, num_hbm_buffers;
     uint64_t graph_replays, graph_captures;
+    uint64_t batch_launches;      /* multi-block launch groups issued by elemhip_process_blocks */
 } elemhip_stats;
 
 /* Runtime(double sampleRate, int blockSize)                      runtime/elem/Runtime.h:44,157-166

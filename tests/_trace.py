@@ -1,5 +1,5 @@
 import sys, ctypes as C, re
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from elementary_amd import el, graphs
 from elementary_amd.runtime import Runtime, load_library
 lib = load_library()
@@ -8,19 +8,22 @@ src = open('elementary_amd/csrc/device.h').read()
 body = src[src.index('enum Op : uint16_t {'):src.index('OP_COUNT_')]
 names = {i: t[3:].lower() for i, t in enumerate(re.findall(r'OP_[A-Z0-9_]+', body))}
 def trace(rt, nout, level=0):
-    buf = (C.c_ulonglong * (4*192))()
+    buf = (C.c_ulonglong * (8*192))()
     for _ in range(3):
-        rc = lib.elemhip_trace_level(rt._h, nout, level, buf, 4*192); assert rc == 0, rc
-    base = min(buf[w*192+1] for w in range(4) if buf[w*192+1])
-    for w in range(4):
+        rc = lib.elemhip_trace_level(rt._h, nout, level, buf, 8*192); assert rc == 0, rc
+    base = min(buf[w*192+1] for w in range(8) if buf[w*192+1])
+    for w in range(8):
         o = w*192
         nt, ts, tp, te = buf[o], buf[o+1], buf[o+2], buf[o+3]
         print(f" wave{w}: start {ts-base} prologue_end {tp-base} end {te-base} tasks={nt}")
         for k in range(min(nt, 62)):
             d0, t0, t1 = buf[o+3*(k+2)], buf[o+3*(k+2)+1], buf[o+3*(k+2)+2]
-            print(f"    {names.get(d0 & 0xFFFF, d0 & 0xFFFF):12s} stage {(d0>>16)&0xFF:2d}  [{t0-base:7d} .. {t1-base:7d}]  {t1-t0:6d} clk")
+            print(f"    {names.get(d0 & 0xFFFF, d0 & 0xFFFF):12s} stage {(d0>>16)&0xFF:2d} blk {d0>>32:2d}  [{t0-base:7d} .. {t1-base:7d}]  {t1-t0:6d} clk")
 which = sys.argv[1] if len(sys.argv) > 1 else "voice"
-if which == "voice":
+if which == "voicepipe":
+    rt = Runtime(48000.0, 512); assert rt.render(*[graphs.c2_voice(k) for k in range(8)])["result"] == 0
+    rt.process_blocks(8, 8); rt.set_option("time_batch", 8); trace(rt, 8)
+elif which == "voice":
     rt = Runtime(48000.0, 512); assert rt.render(*[graphs.c2_voice(k) for k in range(8)])["result"] == 0; trace(rt, 8)
 elif which == "mul16":
     K = lambda k: el.const({"key": f"k{k}", "value": 100.0 + k})

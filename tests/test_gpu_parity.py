@@ -91,7 +91,50 @@ def test_process_blocks_matches_process(gpu_required):
     a.process_blocks(nb, 2, out_ptr=out.data_ptr())
     ref = np.stack([b.process(None, 2, 512) for _ in range(nb)])
     assert np.array_equal(out.cpu().numpy(), ref)
-    assert a.stats()["graph_replays"] > 0
+    assert a.stats()["batch_launches"] > 0   # multi-block pipelined launches carried the steady-state blocks
+    # the per-block hipGraph path (batching off) renders the same samples
+    c = Runtime(48000.0, 512)
+    c.set_option("batch_blocks", 1)
+    assert c.render(*roots)["result"] == 0
+    c.process_blocks(nb, 2, out_ptr=out.data_ptr())
+    d = Runtime(48000.0, 512)
+    assert d.render(*roots)["result"] == 0
+    ref = np.stack([d.process(None, 2, 512) for _ in range(nb)])
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert c.stats()["graph_replays"] > 0 and c.stats()["batch_launches"] == 0
+
+
+@pytest.mark.parametrize("copies", [1, 2, 3, 4])
+def test_pipelined_batches_match_block_at_a_time(gpu_required, copies):
+    """Multi-block launches (blocks pipelined through `copies` LDS buffer sets) vs process(): every
+    stateful node type in one graph, host inputs, time-dependent nodes, 3 batches + a ragged tail."""
+    import torch
+    from elementary_amd.runtime import Runtime
+    X = el.in_({"channel": 0})
+    def roots():
+        v = el.lowpass(el.add(900, el.mul(700, el.cycle(2.0))), 1.5, el.add(el.blepsaw(110.0), el.mul(0.5, X)))
+        w = el.delay({"size": 3000}, el.add(1000.5, el.mul(300, el.cycle(0.5))), 0.4, el.pole(0.95, X))
+        z = el.mul(el.adsr(0.002, 0.01, 0.5, 0.02, el.train(9.0)), el.pinknoise({"seed": 3}))
+        t = el.add(el.mul(1e-5, el.time()), el.metro({"interval": 7.0}), el.sdelay({"size": 700}, X), el.z(X))
+        s = el.add(el.biquad(0.2, 0.3, 0.2, -0.5, 0.2, X), el.mm1p({"mode": "lowpass"}, el.prewarp(800.0), X),
+                   el.env(el.tau2pole(0.001), el.tau2pole(0.05), X), el.latch(el.train(60.0), X),
+                   el.seq({"seq": [1, 2, 3, 5.5], "hold": True}, el.train(200.0), 0), el.counter(el.train(50.0)),
+                   el.maxhold({"hold": 3.0}, el.abs(X), el.train(9.0)), el.accum(el.abs(X), el.train(20.0)),
+                   el.highshelf(4000, 0.7, -4.5, X), el.syncphasor(440.0, el.train(37.0)), el.bleptriangle(523.25))
+        return [el.tanh(el.add(v, w)), el.add(z, t), s]
+    nb = 53
+    x = np.stack([np.stack([lcg_noise(512, 7 + k, 0.5)]) for k in range(nb)])          # [nb, 1, 512]
+    a, b = Runtime(48000.0, 512), Runtime(48000.0, 512)
+    a.set_option("pipeline_copies", copies)
+    assert a.render(*roots())["result"] == 0 and b.render(*roots())["result"] == 0
+    xin = torch.from_numpy(x).cuda()
+    out = torch.zeros((nb, 3, 512), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    a.process_blocks(nb, 3, out_ptr=out.data_ptr(), in_ptr=xin.data_ptr(), num_inputs=1)
+    ref = np.stack([b.process(x[k], 3, 512) for k in range(nb)])
+    got = out.cpu().numpy()
+    assert a.stats()["batch_launches"] >= 3
+    assert np.array_equal(got, ref), float(np.abs(got - ref).max())
 
 
 def test_property_update_without_rebuild(gpu_required):
