@@ -1626,38 +1626,54 @@ void elemhip_island_kernel(PlanView pv, uint32_t* recs, float* hbm, const Global
     const uint32_t e0 = UNI(ldsu(walkOffs + wave)), e1 = UNI(ldsu(walkOffs + wave + 1u));
     const uint32_t walkBase = walkOffs + kWaves + 1u;            // the planner pads in front of the offsets: entries are 16-byte aligned
     const uint32_t lastT = UNI(ldsu(tabT + lastStage));
-    uint32_t pm = 0, pe = e0;
+    // Inside a macro-step the wave first runs whichever of its slots are ready (pass 0, non-blocking), then blocks on
+    // the rest in order (pass 1): slots of one macro-step belong to different blocks, so their order is free, and a slot
+    // stalled on another wave must not hold back work for a younger block that is already runnable.
+    const uint32_t myEntries = e1 - e0;
+    const bool ooo = pipe && myEntries > 1u && myEntries <= 32u;
+    uint32_t pm = 0, pe = e0, pass = ooo ? 0u : 1u, doneMask = 0u;
+    bool newMs = false;
     uint32_t bbi = 0, bs_ = 0;                  // barrier walk: block of this workgroup, stage
-    const uint32_t steps2 = pipe ? (batch + D - 1u) * (e1 - e0) : steps;
+    const uint32_t steps2 = pipe ? (batch + D - 1u) * myEntries * (ooo ? 2u : 1u) : steps;
     for (uint32_t it = 0; it < steps2; ++it) {
-        uint32_t b, s, tb, te, prev = kNone, prevT = 0;
+        uint32_t b, s, tb, te, use = 0u, copy = 0u;
         if (pipe) {
+            if (newMs) { doneMask = 0u; newMs = false; }
+            const uint32_t idx = pe - e0, curPass = pass, m = pm;
             const v4u ea = lds4u(walkBase + pe * 8u), eb = lds4u(walkBase + pe * 8u + 4u);
-            s = UNI(ea.x); b = pm - UNI(ea.y);                   // wraps when pm < phase: caught by b >= batch
-            tb = UNI(ea.z); te = UNI(ea.w); prev = UNI(eb.x); prevT = UNI(eb.y);
-            if (++pe == e1) { pe = e0; ++pm; }
-            if (b >= batch) continue;
+            if (++pe == e1) { pe = e0; if (ooo && pass == 0u) pass = 1u; else { pass = ooo ? 0u : 1u; ++pm; newMs = true; } }
+            s = UNI(ea.x); b = m - UNI(ea.y);                    // wraps when m < phase: caught by b >= batch
+            tb = UNI(ea.z); te = UNI(ea.w);
+            const uint32_t prev = UNI(eb.x), prevT = UNI(eb.y);
+            if (b >= batch || ((doneMask >> idx) & 1u)) continue;
+            use = D == 3u ? b / 3u : (D == 4u ? b >> 2 : (D == 2u ? b >> 1 : b));
+            copy = b - use * D;
+            // completion counters are per (stage, buffer set): block b is use number b / D of set b % D. (One counter per
+            // stage would let a wave that runs a block ahead satisfy the count meant for a slower wave's task.)
+            const uint32_t wPrev = isl.ldsCounters + prev * D + copy, wLast = isl.ldsCounters + lastStage * D + copy;
+            if (curPass == 0u) {
+                uint32_t* cp = reinterpret_cast<uint32_t*>(lds);
+                const bool ready = (prev == kNone || __hip_atomic_load(cp + wPrev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (use + 1u) * prevT)
+                                && (use == 0u || __hip_atomic_load(cp + wLast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= use * lastT);
+                if (!ready) continue;
+            } else {
+                if (prev != kNone) wait_counter(wPrev, (use + 1u) * prevT);
+                if (use > 0u) wait_counter(wLast, use * lastT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            doneMask |= 1u << idx;
         } else {
             b = blockIdx.y + bbi * gridDim.y;
             s = bs_;
             if (++bs_ == S) { bs_ = 0u; ++bbi; }
             if (it > 0u) __syncthreads();
             tb = UNI(ldsu(tabBegin + s)); te = UNI(ldsu(tabBegin + s + 1u));
+            if (tb == te) continue;
         }
-        if (tb == te) continue;
-        const uint32_t use = !pipe ? 0u : (D == 3u ? b / 3u : (D == 4u ? b >> 2 : (D == 2u ? b >> 1 : b)));
-        const uint32_t copy = pipe ? b - use * D : 0u;
         const uint32_t progBase = isl.ldsProg + copy * isl.copyDwords;
         c.members = progBase + isl.memOff; c.operands = progBase + isl.opndOff;
         c.hbm = (gfp)hbm + (size_t)b * arenaFloats;
         c.sampleTime = sampleTime0 + (int64_t)b * (int64_t)c.n;
-        if (pipe) {
-            // completion counters are per (stage, buffer set): block b is use number b / D of set b % D. (One counter per
-            // stage would let a wave that runs a block ahead satisfy the count meant for a slower wave's task.)
-            if (prev != kNone) wait_counter(isl.ldsCounters + prev * D + copy, (use + 1u) * prevT);
-            if (use > 0u) wait_counter(isl.ldsCounters + lastStage * D + copy, use * lastT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
         for (uint32_t ti = tb; ti < te; ++ti) {
             const v4u h = lds4u(progBase + ti * 8u), h2 = lds4u(progBase + ti * 8u + 4u);
             const uint32_t d0 = UNI(h.x), d1 = UNI(h.y), d6 = UNI(h2.z);

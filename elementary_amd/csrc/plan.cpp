@@ -72,6 +72,19 @@ uint32_t leafArityOfOp(uint16_t op) {
     return leafArity(op);
 }
 
+// estimated shader cycles of one task on a lone wave (measured on the C2 voice island, tests/_trace.py)
+uint32_t taskCost(uint16_t op, uint32_t units, uint32_t count) {
+    if (op == OP_SVF_COEF || op == OP_SHELF_COEF) return 2500u * units * count;           // double tan + divides per frame
+    if (op == OP_SVF || op == OP_SVFSHELF || op == OP_MM1P) return 9500u * count;         // wave scan
+    if (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_BLEPTRIANGLE) return 19000u;
+    if (op == OP_POLE || op == OP_ENV || op == OP_BIQUAD) return 15500u;
+    if (kindOf(op) == K_CHAIN) return 12500u;
+    if (kindOf(op) == K_SINGLE) return 4000u * count;
+    if (op == OP_ROOT) return 2500u + 150u * units * count;
+    if (op >= OP_SIN && op <= OP_EXP) return 700u + 220u * units * count;
+    return 900u + 90u * units * count;
+}
+
 struct NI {                      // per-node planning info
     Node* n = nullptr;
     int seq = 0;                 // owning root sequence
@@ -531,7 +544,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                     uint32_t take = 1; while (take * 2 <= un && take * 2 <= 8) take *= 2;
                     tasks.push_back(Task{op, (uint8_t)stage, 0, (uint16_t)(u0 * 64), (uint16_t)((u0 + take) * 64), first, count, 0, 0, 0, 0, 0});
                     taskWave.push_back(waves[w % waves.size()]);
-                    if (loadOut) loadOut[waves[w % waves.size()]] += 300u + 150u * take * count;
+                    if (loadOut) loadOut[waves[w % waves.size()]] += taskCost(op, take, count);
                     u0 += take; un -= take;
                 }
             }
@@ -582,14 +595,12 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             };
             for (auto& kv : chain) {
                 const uint16_t cop = (uint16_t)(kv.first & 0xFFFFu);
-                const uint32_t cost = (cop == OP_SVF || cop == OP_SVFSHELF || cop == OP_MM1P) ? 8000u
-                                    : (cop == OP_BLEPSAW || cop == OP_BLEPSQUARE || cop == OP_BLEPTRIANGLE) ? 16000u : 12000u;
                 for (size_t off = 0; off < kv.second.size(); off += 64) {
                     const uint32_t cnt = (uint32_t)std::min<size_t>(64, kv.second.size() - off);
                     const uint32_t first = (uint32_t)members.size();
                     for (uint32_t c = 0; c < cnt; ++c) members.push_back(makeMember(ni[kv.second[off + c]]));
                     const int w = pickWave();
-                    busy[w] += 1; waveLoad[w] += cost;
+                    busy[w] += 1; waveLoad[w] += taskCost(cop, 8, (cop == OP_SVF || cop == OP_SVFSHELF || cop == OP_MM1P) ? cnt : 1);
                     tasks.push_back(Task{cop, (uint8_t)stage, (uint8_t)(kv.first >> 16), 0, (uint16_t)bs, first, cnt, 0, 0, 0, 0, 0});
                     taskWave.push_back(w);
                 }
@@ -599,7 +610,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                     const uint32_t first = (uint32_t)members.size();
                     members.push_back(makeMember(ni[k]));
                     const int w = pickWave();
-                    busy[w] += 1; waveLoad[w] += 4000u;
+                    busy[w] += 1; waveLoad[w] += taskCost(kv.first, 8, 1);
                     tasks.push_back(Task{kv.first, (uint8_t)stage, 0, 0, (uint16_t)bs, first, 1, 0, 0, 0, 0, 0});
                     taskWave.push_back(w);
                 }
@@ -690,15 +701,10 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                     uint32_t w = 0; while (w + 1 < kWaves && q >= I.waveTask[w + 1]) ++w;
                     const uint16_t op = t.opcode;
                     const uint32_t units = ((uint32_t)t.s1 - t.s0 + 63u) / 64u;
-                    uint32_t cst = 300u + 150u * units * t.count;                                  // light sample-parallel op
-                    if (op == OP_SVF_COEF || op == OP_SHELF_COEF) cst = 600u * units * t.count;
-                    else if (op == OP_SVF || op == OP_SVFSHELF || op == OP_MM1P) cst = 9000u * t.count;
-                    else if (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_BLEPTRIANGLE) cst = 19000u;
-                    else if (kindOf(op) == K_CHAIN) cst = 15000u;
-                    else if (kindOf(op) == K_SINGLE) cst = 4000u * t.count;
+                    const uint32_t cst = taskCost(op, units, t.count);
                     perWave[t.stage][w] += cst;
                 }
-                for (uint32_t st = 0; st < S; ++st) cost[st] = 2000u + *std::max_element(perWave[st].begin(), perWave[st].end());
+                for (uint32_t st = 0; st < S; ++st) cost[st] = 1500u + *std::max_element(perWave[st].begin(), perWave[st].end());
             }
             const uint32_t P = std::min<uint32_t>(copies, S);
             // dp[p][j]: best max-run cost covering stages [0, j) with p runs
