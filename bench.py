@@ -67,7 +67,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=4096)
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=256, help="blocks per elemhip_process_blocks call")
-    ap.add_argument("--graph-blocks", type=int, default=8, help="blocks per captured hipGraph")
+    ap.add_argument("--graph-blocks", type=int, default=8, help="blocks per captured hipGraph (per-block launch path)")
+    ap.add_argument("--batch-blocks", type=int, default=32, help="blocks per multi-block launch (1 = per-block launches)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--voices", type=int, default=256)
@@ -95,6 +96,7 @@ def main() -> None:
     rt = Runtime(graphs.C2_SAMPLE_RATE, BLOCK, device=local)
     rt.set_option("use_graph", 0 if args.no_graph else 1)
     rt.set_option("graph_blocks", args.graph_blocks)
+    rt.set_option("batch_blocks", args.batch_blocks)
     t0 = time.perf_counter()
     res = rt.render(*graphs.c2_graph(voices=args.voices, channels=2, first_voice=args.voices * rank))
     assert res["result"] == 0, res["result"]
@@ -137,17 +139,23 @@ def main() -> None:
     if rank == 0:
         stats = rt.stats()
         # ---- roofline of the dominant kernel (elemhip_island_kernel), HIP events on the engine's stream ----
-        lv = rt.time_launches(2, 200)
+        # One launch of a level renders `batch` blocks (the same launches the timed region issued).
+        rt.set_option("time_batch", args.batch_blocks)
+        lv = rt.time_launches(2, 50)
+        batch = rt.last_time_batch
         island_ms = sum(lv[:-1])
         alg_bytes = graphs.c2_algorithmic_bytes(args.voices, 2, BLOCK)
-        achieved = alg_bytes / (island_ms * 1e-3) / 1e9
+        achieved = alg_bytes * batch / (island_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("c2_hbm_bytes_per_block")
+                tj = json.load(open(tpath))
+                traffic = tj.get("c2_hbm_bytes_per_launch_set") if batch > 1 else tj.get("c2_hbm_bytes_per_block")
             except Exception:
                 traffic = None
+        rt.set_option("time_batch", 1)
+        lv1 = rt.time_launches(2, 100)
         # ---- synchronous single-block latency through host buffers (cli/Benchmark.cpp style) ----
         for _ in range(20):
             rt.process(None, 2, BLOCK)
@@ -179,7 +187,8 @@ def main() -> None:
                 "mode": "offline elemhip_process_blocks, output bus resident in HBM"
                         + (", RCCL sum-reduce of the bus to rank 0 per chunk" if world > 1 else ""),
                 "blocks_per_call": chunk,
-                "hipgraph_blocks": 0 if args.no_graph else args.graph_blocks,
+                "blocks_per_launch": batch,
+                "pipelined_blocks_in_flight": rt.describe_plan()["islands"][0]["copies"],
                 "islands": stats["num_islands"], "launch_levels": stats["num_levels"], "max_lds_bytes": stats["max_lds_bytes"],
             },
             "realtime_factor_48k": world * BLOCK * args.steps / dt / 48000.0,
@@ -188,12 +197,15 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": "elemhip_island_kernel", "launches_per_block": len(lv) - 1,
+                "kernel": "elemhip_island_kernel", "launches_per_batch": len(lv) - 1, "blocks_per_launch": batch,
                 "kernel_us_per_launch": [1e3 * x for x in lv[:-1]], "epilogue_us": 1e3 * lv[-1],
+                "kernel_us_per_block": [1e3 * x / batch for x in lv[:-1]],
                 "event_pair_overhead_us_subtracted": 1e3 * rt.last_event_overhead_ms,
-                "algorithmic_bytes_per_block": alg_bytes,
-                "note": "achieved = SURVEY §8(d) algorithmic bytes of one block / summed HIP-event duration of that "
-                        "block's island-kernel launches; buffers inside an island live in LDS and never reach HBM",
+                "algorithmic_bytes_per_block": alg_bytes, "algorithmic_bytes_per_launch_set": alg_bytes * batch,
+                "single_block_launch_us": [1e3 * x for x in lv1],
+                "note": "achieved = SURVEY §8(d) algorithmic bytes of the blocks one launch set renders / summed HIP-event "
+                        "duration of that set's island-kernel launches (one per level); `traffic` = PMC HBM bytes of the same "
+                        "launch set; buffers inside an island live in LDS and never reach HBM",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -752,7 +752,7 @@ int Engine::setOption(const std::string& key, double value) {
     std::lock_guard<std::mutex> lock(mu);
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
     if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(64, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
-    if (key == "pipeline_copies") { pipelineCopies = std::max(1, std::min(4, (int)value)); planStale = true; return kOk; }   // next commit re-plans
+    if (key == "pipeline_copies") { pipelineCopies = std::max(1, std::min(6, (int)value)); planStale = true; return kOk; }   // next commit re-plans
     if (key == "time_batch") { timeBatch = std::max(1, std::min(64, (int)value)); return kOk; }
     if (key == "graph_blocks") { graphBlocks = std::max(1, (int)value); if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; } return kOk; }
     return kInvalidPropertyValue;

@@ -1626,42 +1626,56 @@ void elemhip_island_kernel(PlanView pv, uint32_t* recs, float* hbm, const Global
     const uint32_t e0 = UNI(ldsu(walkOffs + wave)), e1 = UNI(ldsu(walkOffs + wave + 1u));
     const uint32_t walkBase = walkOffs + kWaves + 1u;            // the planner pads in front of the offsets: entries are 16-byte aligned
     const uint32_t lastT = UNI(ldsu(tabT + lastStage));
-    // Inside a macro-step the wave first runs whichever of its slots are ready (pass 0, non-blocking), then blocks on
-    // the rest in order (pass 1): slots of one macro-step belong to different blocks, so their order is free, and a slot
-    // stalled on another wave must not hold back work for a younger block that is already runnable.
+    // Inside a macro-step the wave polls its slots and runs whichever is ready: slots of one macro-step belong to
+    // different blocks, so their order is free, and a slot stalled on another wave must not hold back work for a
+    // younger block that is already runnable. The next macro-step starts when every slot of this one has run.
     const uint32_t myEntries = e1 - e0;
     const bool ooo = pipe && myEntries > 1u && myEntries <= 32u;
-    uint32_t pm = 0, pe = e0, pass = ooo ? 0u : 1u, doneMask = 0u;
-    bool newMs = false;
+    const uint32_t fullMask = myEntries >= 32u ? 0xFFFFFFFFu : ((1u << myEntries) - 1u);
+    const uint32_t totalMs = (pipe && myEntries > 0u) ? batch + D - 1u : 0u;
+    uint32_t pm = 0, pe = e0, doneMask = 0u;
+    bool progress = false;
     uint32_t bbi = 0, bs_ = 0;                  // barrier walk: block of this workgroup, stage
-    const uint32_t steps2 = pipe ? (batch + D - 1u) * myEntries * (ooo ? 2u : 1u) : steps;
-    for (uint32_t it = 0; it < steps2; ++it) {
+    for (uint32_t it = 0; pipe ? pm < totalMs : it < steps; ++it) {
         uint32_t b, s, tb, te, use = 0u, copy = 0u;
         if (pipe) {
-            if (newMs) { doneMask = 0u; newMs = false; }
-            const uint32_t idx = pe - e0, curPass = pass, m = pm;
+            const uint32_t idx = pe - e0, m = pm;
             const v4u ea = lds4u(walkBase + pe * 8u), eb = lds4u(walkBase + pe * 8u + 4u);
-            if (++pe == e1) { pe = e0; if (ooo && pass == 0u) pass = 1u; else { pass = ooo ? 0u : 1u; ++pm; newMs = true; } }
+            bool wrapped = false;
+            if (++pe == e1) { pe = e0; wrapped = true; }
             s = UNI(ea.x); b = m - UNI(ea.y);                    // wraps when m < phase: caught by b >= batch
             tb = UNI(ea.z); te = UNI(ea.w);
             const uint32_t prev = UNI(eb.x), prevT = UNI(eb.y);
-            if (b >= batch || ((doneMask >> idx) & 1u)) continue;
-            use = D == 3u ? b / 3u : (D == 4u ? b >> 2 : (D == 2u ? b >> 1 : b));
+            use = D == 4u ? b >> 2 : D == 5u ? b / 5u : D == 3u ? b / 3u : D == 2u ? b >> 1 : D == 6u ? b / 6u : b;
             copy = b - use * D;
             // completion counters are per (stage, buffer set): block b is use number b / D of set b % D. (One counter per
             // stage would let a wave that runs a block ahead satisfy the count meant for a slower wave's task.)
             const uint32_t wPrev = isl.ldsCounters + prev * D + copy, wLast = isl.ldsCounters + lastStage * D + copy;
-            if (curPass == 0u) {
-                uint32_t* cp = reinterpret_cast<uint32_t*>(lds);
-                const bool ready = (prev == kNone || __hip_atomic_load(cp + wPrev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (use + 1u) * prevT)
-                                && (use == 0u || __hip_atomic_load(cp + wLast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= use * lastT);
-                if (!ready) continue;
+            bool run = false;
+            if (ooo) {
+                const uint32_t bit = 1u << idx;
+                if (!(doneMask & bit)) {
+                    if (b >= batch) doneMask |= bit;
+                    else {
+                        uint32_t* cp = reinterpret_cast<uint32_t*>(lds);
+                        const bool ready = (prev == kNone || __hip_atomic_load(cp + wPrev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (use + 1u) * prevT)
+                                        && (use == 0u || __hip_atomic_load(cp + wLast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= use * lastT);
+                        if (ready) { doneMask |= bit; run = true; }
+                    }
+                }
+                if (doneMask == fullMask) { doneMask = 0u; ++pm; pe = e0; progress = false; }
+                else if (run) progress = true;
+                else if (wrapped) { if (!progress) __builtin_amdgcn_s_sleep(2); progress = false; }
             } else {
-                if (prev != kNone) wait_counter(wPrev, (use + 1u) * prevT);
-                if (use > 0u) wait_counter(wLast, use * lastT);
+                if (wrapped) ++pm;
+                if (b < batch) {
+                    if (prev != kNone) wait_counter(wPrev, (use + 1u) * prevT);
+                    if (use > 0u) wait_counter(wLast, use * lastT);
+                    run = true;
+                }
             }
+            if (!run) continue;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            doneMask |= 1u << idx;
         } else {
             b = blockIdx.y + bbi * gridDim.y;
             s = bs_;

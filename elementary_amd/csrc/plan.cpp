@@ -471,9 +471,9 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         const uint32_t slotArea = (uint32_t)slotFreeAt.size() * kSlotWords;      // block-buffer words of one copy
         bool statelessIsland = true;
         for (int k : B.nodes) if (ni[k].kind != K_PAR || ni[k].n->op == OP_TAPIN || ni[k].n->op == OP_TAPOUT) statelessIsland = false;
-        // blocks kept in flight by a multi-block launch: as many buffer sets as fit in ~96 KB of LDS
+        // blocks kept in flight by a multi-block launch: as many buffer sets as fit in ~140 KB of LDS (one such workgroup per CU)
         uint32_t copies = 1;
-        if (!statelessIsland && slotArea > 0) copies = std::max<uint32_t>(1, std::min<uint32_t>(maxCopies, (30u * 1024u) / slotArea));
+        if (!statelessIsland && slotArea > 0) copies = std::max<uint32_t>(1, std::min<uint32_t>(maxCopies, (35u * 1024u) / slotArea));
         const uint32_t slotWords = kSlot0 + copies * slotArea;                    // first word after every copy's buffers
 
         // island-local program tables

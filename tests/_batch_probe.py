@@ -3,12 +3,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(
 import torch
 from elementary_amd import graphs
 from elementary_amd.runtime import Runtime
-for copies in (1, 2, 3, 4):
+for copies in (3, 4, 5):
     rt = Runtime(48000.0, 512, device=0)
     rt.set_option("pipeline_copies", copies)
     assert rt.render(*graphs.c2_graph())["result"] == 0
     rt.process_blocks(64, 2)
-    for batch in (8, 16, 32):
+    for batch in (16, 32, 64):
         rt.set_option("batch_blocks", batch); rt.set_option("time_batch", batch)
         rt.process_blocks(2 * batch, 2)
         torch.cuda.synchronize(); t = time.time(); rt.process_blocks(1024, 2); dt = (time.time() - t) / 1024
