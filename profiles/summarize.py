@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 CSV output (profiles/collect.sh) into the per-round summary files under profiles/.
+
+usage: python profiles/summarize.py <gpurun_out dir> <round tag>
+Writes gpurun_out/<tag>_summary/ (copied into profiles/<tag>/ and committed from the authoring container).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(src, f"{tag}_summary")
+os.makedirs(dst, exist_ok=True)
+
+
+def first(pattern):
+    g = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    return g[0] if g else None
+
+
+# 1. kernel stats (--kernel-trace --stats)
+ks = first("prof_stats/**/*kernel_stats.csv")
+if ks:
+    rows = list(csv.DictReader(open(ks)))
+    with open(os.path.join(dst, "c2_n1_kernel_stats.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(rows)
+    print("kernel stats:", [(r.get("Name", "")[:40], r.get("Calls"), r.get("AverageNs")) for r in rows[:6]])
+# per-dispatch durations by grid size (a level = one grid size) from the kernel trace
+kt = first("prof_stats/**/*kernel_trace.csv")
+per_grid = defaultdict(list)
+if kt:
+    for r in csv.DictReader(open(kt)):
+        name = r.get("Kernel_Name", "")
+        g = (r.get("Grid_Size_X") or r.get("Grid_Size") or "?", r.get("Grid_Size_Y") or "1")
+        try:
+            per_grid[(name.split("(")[0][:48], g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        except Exception:
+            pass
+trace_summary = {f"{k[0]}|grid={k[1][0]}x{k[1][1]}": {"dispatches": len(v), "mean_us": sum(v) / len(v) / 1e3,
+                                                        "min_us": min(v) / 1e3, "max_us": max(v) / 1e3} for k, v in per_grid.items()}
+
+# 2. PMC passes
+pmc = {}
+for ctr, d in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
+    cc = first(f"{d}/**/*counter_collection.csv")
+    if not cc:
+        continue
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(cc)):
+        if r.get("Counter_Name") != ctr:
+            continue
+        name = r.get("Kernel_Name", "").split("(")[0][:48]
+        g = (r.get("Grid_Size_X") or r.get("Grid_Size") or "?", r.get("Grid_Size_Y") or "1")
+        acc[(name, g)].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        pmc[f"{k[0]}|grid={k[1][0]}x{k[1][1]}|{ctr}_KB_mean"] = sum(v) / len(v)
+        pmc[f"{k[0]}|grid={k[1][0]}x{k[1][1]}|{ctr}_dispatches"] = len(v)
+
+out = {"command": "rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE} --output-format csv -- "
+                  "python bench.py --no-cpu-baseline --steps 1024 --warmup 128",
+       "kernel_trace_per_dispatch": trace_summary, "pmc_per_dispatch": pmc}
+json.dump(out, open(os.path.join(dst, "c2_n1_rocprof_summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:3000])
