@@ -11,6 +11,9 @@ void launch_level(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm,
 void launch_epilogue_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, const float* hbm, Globals* g, float* outRing,
                            uint32_t batch, uint32_t arenaFloats);
 void launch_epilogue(hipStream_t s, const PlanView& pv, uint32_t* recs, const float* hbm, Globals* g, float* outRing);
+hipError_t configure_kernels_rt(uint32_t maxLdsBytes);
+void launch_level_rt(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, const uint32_t* lcg,
+                     uint32_t levelBegin, uint32_t numIslands, uint32_t ldsBytes);
 void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g,
                      uint32_t workBegin, uint32_t numWorkgroups);
 hipError_t upload_convolve_tables(const float* twiddleReIm);

@@ -104,7 +104,7 @@ def test_process_blocks_matches_process(gpu_required):
     assert c.stats()["graph_replays"] > 0 and c.stats()["batch_launches"] == 0
 
 
-@pytest.mark.parametrize("copies", [1, 2, 3, 4])
+@pytest.mark.parametrize("copies", [1, 2, 3, 4, 5])
 def test_pipelined_batches_match_block_at_a_time(gpu_required, copies):
     """Multi-block launches (blocks pipelined through `copies` LDS buffer sets) vs process(): every
     stateful node type in one graph, host inputs, time-dependent nodes, 3 batches + a ragged tail."""
@@ -126,6 +126,7 @@ def test_pipelined_batches_match_block_at_a_time(gpu_required, copies):
     x = np.stack([np.stack([lcg_noise(512, 7 + k, 0.5)]) for k in range(nb)])          # [nb, 1, 512]
     a, b = Runtime(48000.0, 512), Runtime(48000.0, 512)
     a.set_option("pipeline_copies", copies)
+    a.set_option("batch_blocks", 12)
     assert a.render(*roots())["result"] == 0 and b.render(*roots())["result"] == 0
     xin = torch.from_numpy(x).cuda()
     out = torch.zeros((nb, 3, 512), dtype=torch.float32, device="cuda")
