@@ -55,6 +55,7 @@ enum Op : uint16_t {
     OP_DELAY, OP_SDELAY, OP_Z, OP_POLE, OP_ENV, OP_BIQUAD, OP_PREWARP, OP_MM1P, OP_SVF, OP_SVFSHELF,
     OP_TAPIN, OP_TAPOUT, OP_SAMPLESEQ, OP_BLEPSAW, OP_BLEPSQUARE, OP_BLEPTRIANGLE,
     OP_TIME, OP_METRO, OP_CONVOLVE,
+    OP_TABLE, OP_SEQ2, OP_SPARSEQ2,
     // plan pseudo-ops
     OP_COPY,          // out = in0 (import HBM->LDS, export LDS->HBM)
     OP_SVF_COEF,      // SVF coefficient pre-pass (a1,a2,a3 as double into the member's scratch), sample-parallel
@@ -218,6 +219,11 @@ enum : uint32_t {
     SEQ_INDEX = S0, SEQ_HOLDVAL = S1, SEQ_FIRST = S2, SEQ_CHANGE = S3, SEQ_RCHANGE = S4, SEQ_HAVE = S5,
     // taps (Feedback.h)
     TAP_SHARED = P0, TAP_PRIVATE = P2,
+    // table (Table.h:17-76): sample buffer pointer + true length
+    TBL_BUF = P0, TBL_LEN = P2,
+    // sparseq2 (SparSeq2.h:17-141): interpolate flag, event table [len doubles | len floats]
+    SPS_INTERP = P0, SPS_SEQ = P4, SPS_LEN = P6,
+    // seq2 (Seq2.h:35-166) shares seq's parameter layout; state: S0 edge count, S3/S4 change detectors, S5 have-sequence
     // convolve: device pointer to the conv:: state
     CONV_STATE = P0,
     // sampleseq (SampleSeq.h:169-404): sample buffer, event table [len doubles | len floats], k-rate state, two readers

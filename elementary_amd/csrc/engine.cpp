@@ -56,7 +56,7 @@ static const std::unordered_map<std::string, uint16_t>& opTable() {
         {"pole", OP_POLE}, {"env", OP_ENV}, {"biquad", OP_BIQUAD}, {"prewarp", OP_PREWARP}, {"mm1p", OP_MM1P}, {"svf", OP_SVF}, {"svfshelf", OP_SVFSHELF},
         {"tapIn", OP_TAPIN}, {"tapOut", OP_TAPOUT},
         {"blepsaw", OP_BLEPSAW}, {"blepsquare", OP_BLEPSQUARE}, {"bleptriangle", OP_BLEPTRIANGLE},
-        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE},
+        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2},
     };
     return t;
 }
@@ -352,6 +352,7 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
         }
         case OP_MAXHOLD: r[rec::P0] = 0xFFFFFFFFu; break;                         // Core.h:336
         case OP_SEQ:     r[rec::SEQ_HOLD] = 0; r[rec::SEQ_LOOP] = 1; break;       // Core.h:566-568
+        case OP_SEQ2:    r[rec::SEQ_HOLD] = 0; r[rec::SEQ_LOOP] = 1; break;       // Seq2.h:157-159
         case OP_RAND:    r[rec::S0] = (uint32_t)std::rand(); break;               // Noise.h:42
         case OP_SAMPLESEQ:                                                        // SampleSeq.h:66-68: fade step 0.02
             r[rec::SSQ_PREV] = r[rec::SSQ_NEXT] = 0xFFFFFFFFu;
@@ -443,6 +444,7 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
                 }
             }
             break;
+        case OP_SEQ2:                                              // Seq2.h:38-84 (same properties as seq)
         case OP_SEQ:                                               // Core.h:411-458
             if (key == "hold") { if (!v.isBool()) return kInvalidPropertyType; writeParam(n, rec::SEQ_HOLD, v.b ? 1u : 0u); }
             if (key == "loop") { if (!v.isBool()) return kInvalidPropertyType; writeParam(n, rec::SEQ_LOOP, v.b ? 1u : 0u); }
@@ -533,6 +535,44 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
                 if (rc != kOk) return rc;
                 n.res = r;
                 writeParamPtr(n, rec::TAP_SHARED, r->dev.ptr);
+            }
+            break;
+        case OP_TABLE:                                             // Table.h:20-33
+            if (key == "path") {
+                if (!v.isString()) return kInvalidPropertyType;
+                auto rit = resources.find(v.str);
+                if (rit == resources.end()) return kInvalidPropertyValue;
+                int rc = ensureResourceOnDevice(rit->second);
+                if (rc != kOk) return rc;
+                n.res = rit->second;
+                writeParamPtr(n, rec::TBL_BUF, n.res->dev.ptr);
+                writeParam(n, rec::TBL_LEN, (uint32_t)(n.res->channels.empty() ? 0 : n.res->channels[0].size()));
+            }
+            break;
+        case OP_SPARSEQ2:                                          // SparSeq2.h:20-54
+            if (key == "seq") {
+                if (!v.isArray()) return kInvalidPropertyType;
+                std::map<double, float> events;
+                for (const Value& e : v.arr) {
+                    if (!e.isObject()) return kInvalidPropertyType;
+                    const Value* val = e.find("value"); const Value* tm = e.find("time");
+                    if (!val || !tm || !val->isNumber() || !tm->isNumber()) return kInvalidPropertyType;
+                    events.insert({tm->num, (float)val->num});
+                }
+                const size_t len = events.size();
+                std::vector<uint32_t> blob(len * 3 + 2, 0u);        // [len doubles][len floats]
+                size_t k = 0;
+                for (auto& kv : events) { std::memcpy(&blob[2 * k], &kv.first, 8); std::memcpy(&blob[2 * len + k], &kv.second, 4); ++k; }
+                int rc = allocRing(n, blob.size());
+                if (rc != kOk) return rc;
+                if (dry) std::memcpy(n.ring.ptr, blob.data(), blob.size() * 4);
+                else HIP_OK(hipMemcpy(n.ring.ptr, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+                writeParamPtr(n, rec::SPS_SEQ, n.ring.ptr);
+                writeParam(n, rec::SPS_LEN, (uint32_t)len);
+            }
+            if (key == "interpolate") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                writeParam(n, rec::SPS_INTERP, (uint32_t)(int32_t)v.num);
             }
             break;
         case OP_CONVOLVE:                                          // wasm/Convolve.h:34-56

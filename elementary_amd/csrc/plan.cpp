@@ -33,7 +33,7 @@ Kind kindOf(uint16_t op) {
         case OP_RAND: case OP_Z: case OP_SDELAY: case OP_DELAY: case OP_SAMPLESEQ: return K_SINGLE;
         case OP_CONVOLVE: return K_CONV;   // always an island of its own, rendered by conv.hip
         case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD:
-        case OP_ONCE: case OP_SEQ: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
+        case OP_ONCE: case OP_SEQ: case OP_SEQ2: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
         case OP_SVFSHELF: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
             return K_CHAIN;
         default: return K_PAR;
@@ -55,7 +55,7 @@ uint32_t leafArity(uint16_t op) {
     switch (op) {
         case OP_PHASOR: case OP_COUNTER: case OP_ONCE: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
         case OP_Z: case OP_SDELAY: case OP_PREWARP: case OP_ROOT: case OP_TAPOUT: case OP_SAMPLESEQ: return 1;
-        case OP_SPHASOR: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_SEQ: case OP_POLE: case OP_MM1P: return 2;
+        case OP_SPHASOR: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_SEQ: case OP_SEQ2: case OP_POLE: case OP_MM1P: return 2;
         case OP_ENV: case OP_SVF: case OP_DELAY: return 3;
         case OP_SVFSHELF: return 4;
         case OP_BIQUAD: return 6;
@@ -587,9 +587,13 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             // a pipelined multi-block launch each wave's TOTAL work per block bounds the throughput, so the
             // heavy (serial) tasks go to the wave with the least work so far, idle-in-this-stage waves first.
             uint32_t busy[kWaves] = {};
+            // In a pipelined island the long serial tasks get waves 0..3 to themselves and the sample-parallel work
+            // runs on waves 4..7: a light task on the critical path of an older block never queues behind a
+            // 15-20 k-cycle recurrence of a younger one.
+            const int serialWaves = copies > 1 ? (int)kWaves / 2 : (int)kWaves;
             auto pickWave = [&]() {
                 int b = 0;
-                for (int w = 1; w < (int)kWaves; ++w)
+                for (int w = 1; w < serialWaves; ++w)
                     if (busy[w] < busy[b] || (busy[w] == busy[b] && waveLoad[w] < waveLoad[b])) b = w;
                 return b;
             };
@@ -616,7 +620,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 }
             }
             std::vector<int> freeWaves;
-            for (int w = 0; w < (int)kWaves; ++w) if (busy[w] == 0) freeWaves.push_back(w);
+            for (int w = copies > 1 ? serialWaves : 0; w < (int)kWaves; ++w) if (busy[w] == 0) freeWaves.push_back(w);
             if (freeWaves.empty()) freeWaves.push_back(pickWave());
             std::sort(freeWaves.begin(), freeWaves.end(), [&](int a, int b) { return waveLoad[a] < waveLoad[b]; });
             // Light sample-parallel ops cost mostly per-task overhead. In a pipelined island (blocks overlap, so

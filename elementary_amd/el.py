@@ -79,6 +79,18 @@ def seq(props: Dict[str, Any], trigger: ElemNode, reset: ElemNode) -> NodeRepr:
     return _n("seq", props, trigger, reset)
 
 
+def table(props: Dict[str, Any], t: ElemNode) -> NodeRepr:
+    return _n("table", props, t)
+
+
+def seq2(props: Dict[str, Any], trigger: ElemNode, reset: ElemNode) -> NodeRepr:
+    return _n("seq2", props, trigger, reset)
+
+
+def sparseq2(props: Dict[str, Any], t: ElemNode) -> NodeRepr:
+    return _n("sparseq2", props, t)
+
+
 def sampleseq(props: Dict[str, Any], t: ElemNode) -> NodeRepr:
     return _n("sampleseq", props, t)
 

@@ -120,7 +120,7 @@ enum Kind {
     K_ADD, K_SUB, K_MUL, K_DIV, K_MOD, K_MIN, K_MAX,
     K_ROOT, K_CONST, K_PHASOR, K_SPHASOR, K_SR, K_SEQ, K_COUNTER, K_ACCUM, K_LATCH, K_MAXHOLD, K_ONCE, K_RAND,
     K_DELAY, K_SDELAY, K_Z, K_POLE, K_ENV, K_BIQUAD, K_PREWARP, K_MM1P, K_SVF, K_SVFSHELF, K_TAPIN, K_TAPOUT,
-    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ, K_CONVOLVE,
+    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ, K_CONVOLVE, K_TABLE, K_SEQ2, K_SPARSEQ2,
 };
 
 // registry names: runtime/elem/DefaultNodeTypes.h:49-144 (hot-path subset) + wasm/Main.cpp:47-61
@@ -136,7 +136,7 @@ const std::unordered_map<std::string, Kind>& registry() {
         {"sdelay", K_SDELAY}, {"z", K_Z}, {"pole", K_POLE}, {"env", K_ENV}, {"biquad", K_BIQUAD}, {"prewarp", K_PREWARP},
         {"mm1p", K_MM1P}, {"svf", K_SVF}, {"svfshelf", K_SVFSHELF}, {"tapIn", K_TAPIN}, {"tapOut", K_TAPOUT},
         {"blepsaw", K_BLEPSAW}, {"blepsquare", K_BLEPSQUARE}, {"bleptriangle", K_BLEPTRIANGLE}, {"time", K_TIME},
-        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ}, {"convolve", K_CONVOLVE},
+        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ}, {"convolve", K_CONVOLVE}, {"table", K_TABLE}, {"seq2", K_SEQ2}, {"sparseq2", K_SPARSEQ2},
     };
     return r;
 }
@@ -198,6 +198,7 @@ struct Node {
     Buf sampleBuf, pendingSampleBuf; bool samplePending = false;
     SeqReader readers[2]; size_t activeReader = 0; size_t sampleLen = 0, pendingSampleLen = 0;
     size_t sampleBufSize() const { return sampleLen; }
+    int32_t interp = 0;          // sparseq2
     // convolve (wasm/Convolve.h:23-92)
     std::shared_ptr<fftconv_oracle::TwoStageConvolver> convolver, pendingConvolver;
     std::vector<float> out;      // this node's block buffer (one per node, never aliased)
@@ -278,6 +279,7 @@ struct Oracle {
                 break;
             case K_MAXHOLD: if (key == "hold") { if (!num) return 5; n.holdSamples = (uint32_t)(sr * 0.001 * v.n); } break;   // Core.h:292-303
             case K_ONCE: if (key == "arm") { if (!boo) return 5; if (n.armed == 0.0f) n.armed = v.b ? 1.0f : 0.0f; } break;   // Core.h:352-366
+            case K_SEQ2:                                                                                  // Seq2.h:38-84 (same properties)
             case K_SEQ:                                                                                   // Core.h:411-458
                 if (key == "hold") { if (!boo) return 5; n.hold = v.b; }
                 if (key == "loop") { if (!boo) return 5; n.loop = v.b; }
@@ -337,6 +339,29 @@ struct Oracle {
                     }
                     n.newSeqEvents.assign(m.begin(), m.end()); n.pendingEvents = true;
                 }
+                break;
+            case K_TABLE:                                                                                 // Table.h:20-33
+                if (key == "path") {
+                    if (!str) return 5;
+                    auto r = resources.find(v.s);
+                    if (r == resources.end()) return 6;
+                    n.pendingSampleBuf = r->second; n.samplePending = true; n.pendingSampleLen = resourceLen[v.s];
+                }
+                break;
+            case K_SPARSEQ2:                                                                              // SparSeq2.h:20-54
+                if (key == "seq") {
+                    if (v.t != JV::Arr) return 5;
+                    std::map<double, float> m;
+                    for (const JV& e : v.a) {
+                        if (e.t != JV::Obj) return 5;
+                        const JV* val = nullptr; const JV* tm = nullptr;
+                        for (auto& kv : e.o) { if (kv.first == "value") val = &kv.second; if (kv.first == "time") tm = &kv.second; }
+                        if (!val || !tm || val->t != JV::Num || tm->t != JV::Num) return 5;
+                        m.insert({tm->n, (float)val->n});
+                    }
+                    n.newSeqEvents.assign(m.begin(), m.end()); n.pendingEvents = true;
+                }
+                if (key == "interpolate") { if (!num) return 5; n.interp = (int32_t)v.n; }
                 break;
             case K_CONVOLVE:                                                                              // wasm/Convolve.h:34-56
                 if (key == "path") {
@@ -789,6 +814,60 @@ struct Oracle {
                 zero();
                 n.readers[0].readAdding(out, N);
                 n.readers[1].readAdding(out, N);
+                break;
+            }
+            case K_TABLE: {                                                                               // Table.h:35-71
+                if (n.samplePending) { n.sampleBuf = n.pendingSampleBuf; n.sampleLen = n.pendingSampleLen; n.samplePending = false; }
+                const int size = (int)n.sampleLen;
+                if (nIn == 0 || !n.sampleBuf || size == 0) { zero(); break; }
+                const float* buf = n.sampleBuf->data();
+                for (size_t i = 0; i < N; ++i) {
+                    const float readPos = clampf(in[0][i], 0.0f, 1.0f) * (float)(size - 1);
+                    const int readLeft = (int)readPos, readRight = readLeft + 1;
+                    const float frac = readPos - std::floor(readPos);
+                    const float left = buf[readLeft % size], right = buf[readRight % size];
+                    out[i] = left + frac * (right - left);
+                }
+                break;
+            }
+            case K_SEQ2: {                                                                                // Seq2.h:87-147
+                if (n.pendingSeq) { n.seq.swap(n.newSeq); n.pendingSeq = false; n.haveSeq = true; }
+                if (nIn < 1 || !n.haveSeq) { zero(); break; }
+                const bool hasReset = nIn > 1;
+                const size_t len = n.seq.size();
+                for (size_t i = 0; i < N; ++i) {
+                    const float x = in[0][i], reset = hasReset ? in[1][i] : 0.0f;
+                    if (changeTick(n.f1, x) > 0.5f) n.seqIndex++;          // seqIndex holds edgeCount here
+                    if (changeTick(n.f2, reset) > 0.5f) n.seqIndex = 0;
+                    const size_t idx = n.seqOffset + n.seqIndex;
+                    // an empty sequence is UB in the reference (% 0, at(size - 1)); it emits 0 here
+                    const float next = len == 0 ? 0.0f : (idx < len) ? n.seq[idx] : (n.loop ? n.seq[idx % len] : (n.hold ? n.seq[len - 1] : 0.0f));
+                    out[i] = n.hold ? next : next * x;
+                }
+                break;
+            }
+            case K_SPARSEQ2: {                                                                            // SparSeq2.h:68-127
+                if (n.pendingEvents) { n.seqEvents.swap(n.newSeqEvents); n.pendingEvents = false; n.haveEvents = true; n.prevEvent = n.nextEvent = -1; }
+                if (nIn < 1 || !n.haveEvents || n.seqEvents.empty()) { zero(); break; }
+                const auto& ev = n.seqEvents;
+                const bool interp = n.interp == 1;
+                for (size_t i = 0; i < N; ++i) {
+                    const double t = (double)in[0][i];
+                    const bool update = (n.prevEvent < 0 && n.nextEvent < 0)
+                        || (n.prevEvent >= 0 && t <= ev[(size_t)n.prevEvent].first + 1e-9)
+                        || (n.nextEvent >= 0 && t >= ev[(size_t)n.nextEvent].first - 1e-9);
+                    if (update) {                                                                         // :56-66
+                        size_t ub = 0;
+                        while (ub < ev.size() && !(ev[ub].first > t)) ++ub;
+                        n.nextEvent = ub < ev.size() ? (int)ub : -1;
+                        n.prevEvent = ub == 0 ? -1 : (int)ub - 1;
+                    }
+                    if (n.prevEvent < 0) { out[i] = 0.0f; continue; }
+                    if (n.nextEvent < 0) { out[i] = ev[(size_t)n.prevEvent].second; continue; }
+                    const auto& p = ev[(size_t)n.prevEvent]; const auto& q = ev[(size_t)n.nextEvent];
+                    const double alpha = interp ? ((t - p.first) / (q.first - p.first)) : 0.0;
+                    out[i] = p.second + (float)alpha * (q.second - p.second);
+                }
                 break;
             }
             case K_CONVOLVE:                                                                              // wasm/Convolve.h:58-84

@@ -69,7 +69,25 @@ NODE_CASES = {
     "adsr": (lambda: [el.adsr(0.002, 0.01, 0.5, 0.02, el.train(10.0))], 0),
     "compress": (lambda: [el.compress(5, 50, -20, 4, X(), X())], 1),
     "shared_between_roots": (lambda: (lambda s: [el.mul(0.5, s), el.tanh(s), s])(el.cycle(330.0)), 0),
+    # SURVEY 8(f) rank 2
+    "table": (lambda: [el.table({"path": "/t/ramp"}, el.add(0.5, X())), el.table({"path": "/t/five"}, el.phasor(3.0)),
+                       el.table({"path": "/t/one"}, X())], 1),
+    "seq2": (lambda: [el.seq2({"seq": [1, 2, 3, 5.5], "hold": True}, el.train(200.0), 0),
+                      el.seq2({"seq": [0.5, 0.25, 4], "loop": False}, el.train(150.0), el.train(7.0)),
+                      el.seq2({"seq": [3, 4, 5], "offset": 1, "hold": False, "loop": True}, el.train(90.0), el.train(11.0)),
+                      el.seq2({"seq": [7, 8], "loop": False, "hold": True}, el.train(400.0), el.train(5.0))], 0),
+    "sparseq2": (lambda: [el.sparseq2({"seq": [{"time": 100, "value": 1}, {"time": 700, "value": 2.5}, {"time": 2000, "value": -1},
+                                               {"time": 100, "value": 9}]}, el.time()),
+                          el.sparseq2({"interpolate": 1, "seq": [{"time": 0, "value": 0}, {"time": 1000, "value": 1}, {"time": 3000, "value": -2}]},
+                                      el.add(500, el.mod(el.time(), 2800))),
+                          el.sparseq2({"interpolate": 1, "seq": [{"time": 0.25, "value": 1}, {"time": 0.5, "value": 3}]}, el.add(0.4, el.mul(0.8, X())))], 1),
 }
+
+# shared resources the cases above load (name -> channel-0 samples)
+def node_case_resources():
+    import numpy as np
+    return {"/t/ramp": (np.arange(300, dtype=np.float32) / 300.0 + 0.25).astype(np.float32),
+            "/t/five": np.asarray([1, 2, 3, 4, 5], np.float32), "/t/one": np.asarray([0.75], np.float32)}
 
 
 

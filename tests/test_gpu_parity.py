@@ -30,14 +30,14 @@ def _engines():
     return hip, chk
 
 
-from cases import NODE_CASES, sampleseq_scenario
+from cases import NODE_CASES, node_case_resources, sampleseq_scenario
 
 
 @pytest.mark.parametrize("name", sorted(NODE_CASES))
 def test_node_parity(gpu_required, name):
     roots_fn, n_in = NODE_CASES[name]
     hip, chk = _engines()
-    a, b = render_pair(hip, chk, roots_fn, sample_rate=44100.0, blocks=14, n_in=n_in)
+    a, b = render_pair(hip, chk, roots_fn, sample_rate=44100.0, blocks=14, n_in=n_in, resources=node_case_resources())
     assert np.isfinite(a).all()
     scale = max(1.0, float(np.abs(b).max()))
     err = float(np.abs(a - b).max())

@@ -183,3 +183,47 @@ def test_maxhold_snapshots(core_factory):
         out = [f32(len(x))]
         core.process([np.asarray(x, np.float32)], out)
         core_factory.same(out[0], GOLD[key])
+
+
+_SPARSE = [{"time": 5120 + 0, "value": 1}, {"time": 5120 + 4, "value": 2}, {"time": 5120 + 8, "value": 3}, {"time": 5120 + 12, "value": 4}]
+
+
+def test_sparseq2_snapshots(core_factory):
+    """sparseq2.test.js:5-36 (basics), :38-72 (interp), :74-108 (looping), :110-148 (skip ahead)."""
+    core = core_factory(num_input_channels=0, num_output_channels=1)
+    core.render(el.sparseq2({"seq": [{"time": 5120 + 4 * (k + 1), "value": k + 1} for k in range(4)]}, el.time()))
+    core.process([], [f32(5120)])
+    out = [f32(32)]
+    core.process([], out)
+    core_factory.same(out[0], GOLD["sparseq2:sparseq2 basics 1"])
+
+    core = core_factory(num_input_channels=0, num_output_channels=1)
+    core.render(el.sparseq2({"interpolate": 1, "seq": _SPARSE}, el.time()))
+    core.process([], [f32(5120)])
+    core.process([], out)
+    core_factory.same(out[0], GOLD["sparseq2:sparseq2 interp 1"])
+
+    core = core_factory(num_input_channels=0, num_output_channels=1)
+    loop = lambda start, end, t: el.add(start, el.mod(t, el.sub(end, start)))  # noqa: E731
+    core.render(el.sparseq2({"seq": _SPARSE}, loop(5120, 5120 + 16, el.time())))
+    core.process([], [f32(5120)])
+    core.process([], out)
+    core_factory.same(out[0], GOLD["sparseq2:sparseq2 looping 1"])
+
+    core = core_factory(num_input_channels=1, num_output_channels=1)
+    core.render(el.sparseq2({"seq": _SPARSE}, el.in_({"channel": 0})))
+    core.process([f32(5120)], [f32(5120)])
+    out = [f32(16)]
+    core.process([np.asarray([5120] * 8 + [5128] * 8, np.float32)], out)
+    core_factory.same(out[0], GOLD["sparseq2:sparseq2 skip ahead 1"])
+
+
+def test_vfs_table_snapshot(core_factory):
+    """vfs.test.js:5-35: el.table over a virtual-file-system buffer."""
+    core = core_factory(num_input_channels=1, num_output_channels=1,
+                        virtual_file_system={"/v/increment": np.asarray([1, 2, 3, 4, 5], np.float32)})
+    core.render(el.table({"path": "/v/increment"}, el.in_({"channel": 0})))
+    core.process([f32(5120)], [f32(5120)])
+    out = [f32(5)]
+    core.process([np.asarray([0, 0.25, 0.5, 0.75, 1], np.float32)], out)
+    core_factory.same(out[0], GOLD["vfs:vfs sample 1"])
