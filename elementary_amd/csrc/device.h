@@ -55,7 +55,7 @@ enum Op : uint16_t {
     OP_DELAY, OP_SDELAY, OP_Z, OP_POLE, OP_ENV, OP_BIQUAD, OP_PREWARP, OP_MM1P, OP_SVF, OP_SVFSHELF,
     OP_TAPIN, OP_TAPOUT, OP_SAMPLESEQ, OP_BLEPSAW, OP_BLEPSQUARE, OP_BLEPTRIANGLE,
     OP_TIME, OP_METRO, OP_CONVOLVE,
-    OP_TABLE, OP_SEQ2, OP_SPARSEQ2,
+    OP_TABLE, OP_SEQ2, OP_SPARSEQ2, OP_SAMPLE,
     // plan pseudo-ops
     OP_COPY,          // out = in0 (import HBM->LDS, export LDS->HBM)
     OP_SVF_COEF,      // SVF coefficient pre-pass (a1,a2,a3 as double into the member's scratch), sample-parallel
@@ -223,6 +223,10 @@ enum : uint32_t {
     TBL_BUF = P0, TBL_LEN = P2,
     // sparseq2 (SparSeq2.h:17-141): interpolate flag, event table [len doubles | len floats]
     SPS_INTERP = P0, SPS_SEQ = P4, SPS_LEN = P6,
+    // sample (Sample.h:22-231): buffer, length, new-buffer flag, mode (0 trigger, 1 gate, 2 loop), offsets, gain smoothing alpha;
+    // state: change detector, current reader, two readers {target gain, gain, pos (double)}
+    SMP_BUF = P0, SMP_LEN = P2, SMP_PENDING = P3, SMP_MODE = P4, SMP_START = P5, SMP_STOP = P6, SMP_ALPHA = P7,
+    SMP_CHANGE = 8, SMP_CURRENT = 9, SMP_HAVE = 10, SMP_READER0 = 12, SMP_READER_DWORDS = 4,   // target, gain, pos lo, pos hi
     // seq2 (Seq2.h:35-166) shares seq's parameter layout; state: S0 edge count, S3/S4 change detectors, S5 have-sequence
     // convolve: device pointer to the conv:: state
     CONV_STATE = P0,

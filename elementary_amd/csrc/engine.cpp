@@ -56,7 +56,7 @@ static const std::unordered_map<std::string, uint16_t>& opTable() {
         {"pole", OP_POLE}, {"env", OP_ENV}, {"biquad", OP_BIQUAD}, {"prewarp", OP_PREWARP}, {"mm1p", OP_MM1P}, {"svf", OP_SVF}, {"svfshelf", OP_SVFSHELF},
         {"tapIn", OP_TAPIN}, {"tapOut", OP_TAPOUT},
         {"blepsaw", OP_BLEPSAW}, {"blepsquare", OP_BLEPSQUARE}, {"bleptriangle", OP_BLEPTRIANGLE},
-        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2},
+        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2}, {"sample", OP_SAMPLE},
     };
     return t;
 }
@@ -353,6 +353,8 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
         case OP_MAXHOLD: r[rec::P0] = 0xFFFFFFFFu; break;                         // Core.h:336
         case OP_SEQ:     r[rec::SEQ_HOLD] = 0; r[rec::SEQ_LOOP] = 1; break;       // Core.h:566-568
         case OP_SEQ2:    r[rec::SEQ_HOLD] = 0; r[rec::SEQ_LOOP] = 1; break;       // Seq2.h:157-159
+        case OP_SAMPLE:  // VariablePitchLerpReader(float sampleRate, ...): gainSmoothAlpha(1.0 - exp(-1.0 / (0.01 * sampleRate))), Sample.h:163
+            r[rec::SMP_ALPHA] = fbits((float)(1.0 - std::exp(-1.0 / (0.01 * (double)(float)sampleRate)))); break;
         case OP_RAND:    r[rec::S0] = (uint32_t)std::rand(); break;               // Noise.h:42
         case OP_SAMPLESEQ:                                                        // SampleSeq.h:66-68: fade step 0.02
             r[rec::SSQ_PREV] = r[rec::SSQ_NEXT] = 0xFFFFFFFFu;
@@ -535,6 +537,31 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
                 if (rc != kOk) return rc;
                 n.res = r;
                 writeParamPtr(n, rec::TAP_SHARED, r->dev.ptr);
+            }
+            break;
+        case OP_SAMPLE:                                            // Sample.h:25-75
+            if (key == "path") {
+                if (!v.isString()) return kInvalidPropertyType;
+                auto rit = resources.find(v.str);
+                if (rit == resources.end()) return kInvalidPropertyValue;
+                int rc = ensureResourceOnDevice(rit->second);
+                if (rc != kOk) return rc;
+                n.res = rit->second;
+                writeParamPtr(n, rec::SMP_BUF, n.res->dev.ptr);
+                writeParam(n, rec::SMP_LEN, (uint32_t)(n.res->channels.empty() ? 0 : n.res->channels[0].size()));
+                writeParam(n, rec::SMP_PENDING, 1u);
+            }
+            if (key == "mode") {
+                if (!v.isString()) return kInvalidPropertyType;
+                if (v.str == "trigger") writeParam(n, rec::SMP_MODE, 0u);
+                if (v.str == "gate") writeParam(n, rec::SMP_MODE, 1u);
+                if (v.str == "loop") writeParam(n, rec::SMP_MODE, 2u);
+            }
+            if (key == "startOffset" || key == "stopOffset") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                const int vi = (int)v.num;
+                if (vi < 0) return kInvalidPropertyValue;
+                writeParam(n, key == "startOffset" ? rec::SMP_START : rec::SMP_STOP, (uint32_t)vi);
             }
             break;
         case OP_TABLE:                                             // Table.h:20-33

@@ -33,7 +33,7 @@ Kind kindOf(uint16_t op) {
         case OP_RAND: case OP_Z: case OP_SDELAY: case OP_DELAY: case OP_SAMPLESEQ: return K_SINGLE;
         case OP_CONVOLVE: return K_CONV;   // always an island of its own, rendered by conv.hip
         case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD:
-        case OP_ONCE: case OP_SEQ: case OP_SEQ2: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
+        case OP_ONCE: case OP_SEQ: case OP_SEQ2: case OP_SAMPLE: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
         case OP_SVFSHELF: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
             return K_CHAIN;
         default: return K_PAR;
@@ -46,6 +46,7 @@ uint32_t scratchSlots(uint16_t op) {
         case OP_SVFSHELF: return 10;  // a1,a2,a3,k,A
         case OP_DELAY: return 1;
         case OP_SAMPLESEQ: return 2;  // per-reader fade gains
+        case OP_SAMPLE: return 6;     // per reader: read index, fraction, gain (serial pass -> gather pass)
         default: return 0;
     }
 }
@@ -55,7 +56,7 @@ uint32_t leafArity(uint16_t op) {
     switch (op) {
         case OP_PHASOR: case OP_COUNTER: case OP_ONCE: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
         case OP_Z: case OP_SDELAY: case OP_PREWARP: case OP_ROOT: case OP_TAPOUT: case OP_SAMPLESEQ: return 1;
-        case OP_SPHASOR: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_SEQ: case OP_SEQ2: case OP_POLE: case OP_MM1P: return 2;
+        case OP_SPHASOR: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_SEQ: case OP_SEQ2: case OP_SAMPLE: case OP_POLE: case OP_MM1P: return 2;
         case OP_ENV: case OP_SVF: case OP_DELAY: return 3;
         case OP_SVFSHELF: return 4;
         case OP_BIQUAD: return 6;

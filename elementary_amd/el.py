@@ -79,6 +79,10 @@ def seq(props: Dict[str, Any], trigger: ElemNode, reset: ElemNode) -> NodeRepr:
     return _n("seq", props, trigger, reset)
 
 
+def sample(props: Dict[str, Any], trigger: ElemNode, rate: ElemNode) -> NodeRepr:
+    return _n("sample", props, trigger, rate)
+
+
 def table(props: Dict[str, Any], t: ElemNode) -> NodeRepr:
     return _n("table", props, t)
 

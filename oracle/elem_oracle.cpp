@@ -120,7 +120,7 @@ enum Kind {
     K_ADD, K_SUB, K_MUL, K_DIV, K_MOD, K_MIN, K_MAX,
     K_ROOT, K_CONST, K_PHASOR, K_SPHASOR, K_SR, K_SEQ, K_COUNTER, K_ACCUM, K_LATCH, K_MAXHOLD, K_ONCE, K_RAND,
     K_DELAY, K_SDELAY, K_Z, K_POLE, K_ENV, K_BIQUAD, K_PREWARP, K_MM1P, K_SVF, K_SVFSHELF, K_TAPIN, K_TAPOUT,
-    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ, K_CONVOLVE, K_TABLE, K_SEQ2, K_SPARSEQ2,
+    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ, K_CONVOLVE, K_TABLE, K_SEQ2, K_SPARSEQ2, K_SAMPLE,
 };
 
 // registry names: runtime/elem/DefaultNodeTypes.h:49-144 (hot-path subset) + wasm/Main.cpp:47-61
@@ -136,7 +136,7 @@ const std::unordered_map<std::string, Kind>& registry() {
         {"sdelay", K_SDELAY}, {"z", K_Z}, {"pole", K_POLE}, {"env", K_ENV}, {"biquad", K_BIQUAD}, {"prewarp", K_PREWARP},
         {"mm1p", K_MM1P}, {"svf", K_SVF}, {"svfshelf", K_SVFSHELF}, {"tapIn", K_TAPIN}, {"tapOut", K_TAPOUT},
         {"blepsaw", K_BLEPSAW}, {"blepsquare", K_BLEPSQUARE}, {"bleptriangle", K_BLEPTRIANGLE}, {"time", K_TIME},
-        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ}, {"convolve", K_CONVOLVE}, {"table", K_TABLE}, {"seq2", K_SEQ2}, {"sparseq2", K_SPARSEQ2},
+        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ}, {"convolve", K_CONVOLVE}, {"table", K_TABLE}, {"seq2", K_SEQ2}, {"sparseq2", K_SPARSEQ2}, {"sample", K_SAMPLE},
     };
     return r;
 }
@@ -199,6 +199,9 @@ struct Node {
     SeqReader readers[2]; size_t activeReader = 0; size_t sampleLen = 0, pendingSampleLen = 0;
     size_t sampleBufSize() const { return sampleLen; }
     int32_t interp = 0;          // sparseq2
+    // sample (Sample.h:22-231): two VariablePitchLerpReader<float>
+    struct LerpReader { float targetGain = 0, gain = 0; double pos = 0; bool hasBuffer = false; } lerp[2];
+    size_t currentReader = 0, startOffset = 0, stopOffset = 0; int sampleMode = 0;
     // convolve (wasm/Convolve.h:23-92)
     std::shared_ptr<fftconv_oracle::TwoStageConvolver> convolver, pendingConvolver;
     std::vector<float> out;      // this node's block buffer (one per node, never aliased)
@@ -339,6 +342,17 @@ struct Oracle {
                     }
                     n.newSeqEvents.assign(m.begin(), m.end()); n.pendingEvents = true;
                 }
+                break;
+            case K_SAMPLE:                                                                                // Sample.h:25-75
+                if (key == "path") {
+                    if (!str) return 5;
+                    auto r = resources.find(v.s);
+                    if (r == resources.end()) return 6;
+                    n.pendingSampleBuf = r->second; n.samplePending = true; n.pendingSampleLen = resourceLen[v.s];
+                }
+                if (key == "mode") { if (!str) return 5; if (v.s == "trigger") n.sampleMode = 0; if (v.s == "gate") n.sampleMode = 1; if (v.s == "loop") n.sampleMode = 2; }
+                if (key == "startOffset") { if (!num) return 5; const int vi = (int)v.n; if (vi < 0) return 6; n.startOffset = (size_t)vi; }
+                if (key == "stopOffset") { if (!num) return 5; const int vi = (int)v.n; if (vi < 0) return 6; n.stopOffset = (size_t)vi; }
                 break;
             case K_TABLE:                                                                                 // Table.h:20-33
                 if (key == "path") {
@@ -814,6 +828,46 @@ struct Oracle {
                 zero();
                 n.readers[0].readAdding(out, N);
                 n.readers[1].readAdding(out, N);
+                break;
+            }
+            case K_SAMPLE: {                                                                              // Sample.h:82-139, 178-221
+                if (n.samplePending) {
+                    n.sampleBuf = n.pendingSampleBuf; n.sampleLen = n.pendingSampleLen; n.samplePending = false;
+                    for (auto& rd : n.lerp) { rd = Node::LerpReader(); rd.hasBuffer = true; }
+                }
+                if (nIn < 1 || !n.sampleBuf) { zero(); break; }
+                const float alpha = (float)(1.0 - std::exp(-1.0 / (0.01 * (double)(float)sr)));           // :163, sampleRate is FloatType
+                const bool loop = n.sampleMode == 2;
+                const size_t len = n.sampleLen, ostart = n.startOffset, ostop = n.stopOffset;
+                const float* data = n.sampleBuf->data();
+                auto tick = [&](Node::LerpReader& rd, float step) -> float {
+                    if (!rd.hasBuffer || rd.pos < 0.0 || (rd.gain == 0.0f && rd.targetGain == 0.0f)) return 0.0f;
+                    if (rd.pos >= (double)(len - ostop)) { if (!loop) return 0.0f; rd.pos = (double)ostart; }
+                    size_t left = (size_t)rd.pos, right = left + 1;
+                    const float frac = (float)(rd.pos - (double)left);
+                    if (left >= len) left -= len;
+                    if (right >= len) right -= len;
+                    if (len) { left %= len; right %= len; }   // out-of-bounds reads in the reference (start offset beyond the buffer)
+                    const float out = rd.gain * (data[left] + frac * (data[right] - data[left]));
+                    const bool settled = std::abs(rd.targetGain - rd.gain) <= std::numeric_limits<float>::epsilon();
+                    rd.pos = rd.pos + (double)step;
+                    rd.gain = settled ? rd.targetGain : rd.gain + alpha * (rd.targetGain - rd.gain);
+                    rd.gain = clampf(rd.gain, 0.0f, 1.0f);
+                    return out;
+                };
+                const bool hasRate = nIn >= 2;
+                for (size_t i = 0; i < N; ++i) {
+                    const float cv = changeTick(n.f1, in[0][i]);
+                    const float rate = hasRate ? in[1][i] : 1.0f;
+                    if (cv > 0.5f) {
+                        n.lerp[n.currentReader & 1].targetGain = 0.0f;
+                        auto& nr = n.lerp[++n.currentReader & 1];
+                        nr.targetGain = 1.0f; nr.pos = (double)(float)ostart;                              // pos = FloatType(startOffset) with ReaderType's float
+                    }
+                    if (cv < -0.5f && n.sampleMode != 0) n.lerp[n.currentReader & 1].targetGain = 0.0f;
+                    const float a = tick(n.lerp[0], rate);
+                    out[i] = a + tick(n.lerp[1], rate);
+                }
                 break;
             }
             case K_TABLE: {                                                                               // Table.h:35-71

@@ -81,6 +81,11 @@ NODE_CASES = {
                           el.sparseq2({"interpolate": 1, "seq": [{"time": 0, "value": 0}, {"time": 1000, "value": 1}, {"time": 3000, "value": -2}]},
                                       el.add(500, el.mod(el.time(), 2800))),
                           el.sparseq2({"interpolate": 1, "seq": [{"time": 0.25, "value": 1}, {"time": 0.5, "value": 3}]}, el.add(0.4, el.mul(0.8, X())))], 1),
+    "sample": (lambda: [el.sample({"path": "/t/ramp"}, el.train(90.0), 1.0),
+                        el.sample({"path": "/t/ramp", "mode": "gate"}, el.train(40.0), el.add(1.5, X())),
+                        el.sample({"path": "/t/ramp", "mode": "loop", "startOffset": 20, "stopOffset": 50}, el.train(5.0), 0.37),
+                        el.sample({"path": "/t/five", "mode": "loop"}, el.train(300.0), 0.25),
+                        el.sample({"path": "/t/ramp", "mode": "trigger", "startOffset": 10}, el.train(700.0), 2.0)], 1),
 }
 
 # shared resources the cases above load (name -> channel-0 samples)
