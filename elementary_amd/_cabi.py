@@ -31,6 +31,9 @@ RETURN_CODES = {
 _FPP = C.POINTER(C.POINTER(C.c_float))
 
 
+_EVENT_CB = C.CFUNCTYPE(None, C.c_char_p, C.c_char_p, C.c_void_p)
+
+
 def _ptr_array(rows: Sequence[np.ndarray]):
     arr = (C.POINTER(C.c_float) * max(1, len(rows)))()
     for i, r in enumerate(rows):
@@ -72,6 +75,9 @@ class CRuntime:
         self._fn("destroy").restype = None
         self._fn("reset").argtypes = [C.c_void_p]
         self._fn("prune_shared_resources").argtypes = [C.c_void_p]
+        f = self._fn("process_queued_events")
+        f.argtypes = [C.c_void_p, _EVENT_CB, C.c_void_p]
+        f.restype = C.c_int
 
     # -- Runtime API -----------------------------------------------------------------
     def apply_instructions(self, batch: List[list]) -> int:
@@ -131,6 +137,18 @@ class CRuntime:
 
     def reset(self) -> None:
         self._fn("reset")(self._h)
+
+    def process_queued_events(self) -> List[tuple]:
+        """Runtime::processQueuedEvents (Runtime.h:64, 437-446): [(type, payload dict), ...] in relay order."""
+        import json
+        got: List[tuple] = []
+
+        def cb(kind, payload, _user):
+            got.append((kind.decode(), json.loads(payload.decode())))
+        rc = self._fn("process_queued_events")(self._h, _EVENT_CB(cb), None)
+        if rc != 0:
+            raise RuntimeError(f"process_queued_events failed with code {rc}")
+        return got
 
     # -- frontend convenience (offline-renderer/index.ts:60-85) ------------------------
     @property

@@ -116,6 +116,11 @@ size_t elemhip_gc(elemhip_t* h, int32_t* out, size_t cap) { return h ? h->engine
 void elemhip_reset(elemhip_t* h) { if (h) h->engine.reset(); }
 const char* elemhip_describe(int code) { return elemhip::describe(code); }
 
+int elemhip_process_queued_events(elemhip_t* h, elemhip_event_cb cb, void* user) {
+    if (!h) return elemhip::kInvalidInstructionFormat;
+    return h->engine.processQueuedEvents(cb, user);
+}
+
 int elemhip_get_stats(elemhip_t* h, elemhip_stats* out) {
     if (!h || !out) return elemhip::kInvalidInstructionFormat;
     const elemhip::Stats& s = h->engine.stats();

@@ -56,7 +56,7 @@ static const std::unordered_map<std::string, uint16_t>& opTable() {
         {"pole", OP_POLE}, {"env", OP_ENV}, {"biquad", OP_BIQUAD}, {"prewarp", OP_PREWARP}, {"mm1p", OP_MM1P}, {"svf", OP_SVF}, {"svfshelf", OP_SVFSHELF},
         {"tapIn", OP_TAPIN}, {"tapOut", OP_TAPOUT},
         {"blepsaw", OP_BLEPSAW}, {"blepsquare", OP_BLEPSQUARE}, {"bleptriangle", OP_BLEPTRIANGLE},
-        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2}, {"sample", OP_SAMPLE},
+        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2}, {"sample", OP_SAMPLE}, {"meter", OP_METER}, {"snapshot", OP_SNAPSHOT},
     };
     return t;
 }
@@ -753,6 +753,42 @@ int Engine::apply(const Value& batch) {   // Runtime.h:170-218
             default: break;
         }
         if (res != kOk) return res;
+    }
+    return kOk;
+}
+
+// ---- event relay ------------------------------------------------------------------------------------
+int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), void* user) {   // Runtime.h:437-446
+    std::lock_guard<std::mutex> lock(mu);
+    if (dry || !current || !cb) return kOk;
+    if (hipSetDevice(device) != hipSuccess) return kHipError;
+    HIP_OK(hipStreamSynchronize(stream));
+    auto numStr = [](float v) { char b[64]; std::snprintf(b, sizeof b, "%.17g", (double)v); return std::string(b); };
+    for (auto& en : current->eventNodes) {
+        auto nit = nodes.find(en.first), rit = nodes.find(en.second);
+        if (nit == nodes.end() || rit == nodes.end()) continue;
+        auto a = rit->second.props.find("active");                       // GraphRenderSequence.h:192
+        if (a == rit->second.props.end() || !a->second.isBool() || !a->second.b) continue;
+        Node& n = nit->second;
+        uint32_t st[3] = {0, 0, 0};
+        HIP_OK(hipMemcpy(st, dRecs + (size_t)n.rec * kRecDwords + rec::EVT_A, sizeof st, hipMemcpyDeviceToHost));
+        if (st[2] == n.eventCount) continue;                             // nothing new since the last relay
+        n.eventCount = st[2];
+        std::string src = "null";
+        auto nm = n.props.find("name");
+        if (nm != n.props.end() && nm->second.isString()) {
+            src = "\"";
+            for (char ch : nm->second.str) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; }
+            src += "\"";
+        }
+        float fa, fb; std::memcpy(&fa, &st[0], 4); std::memcpy(&fb, &st[1], 4);
+        if (n.op == OP_METER) {                                           // Analyzers.h:43-62
+            const std::string j = "{\"min\": " + numStr(fa) + ", \"max\": " + numStr(fb) + ", \"source\": " + src + "}";
+            cb("meter", j.c_str(), user);
+        } else {                                                          // Analyzers.h:112-131
+            const std::string j = "{\"source\": " + src + ", \"data\": " + numStr(fb) + "}";
+            cb("snapshot", j.c_str(), user);
+        }
     }
     return kOk;
 }

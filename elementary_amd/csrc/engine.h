@@ -65,6 +65,7 @@ struct Node {
     // device-side resources owned by the node
     DevBuf ring;                // delay / sdelay ring, tapOut private buffer, seq data
     ResourcePtr res;            // tap buffer / sample data held by the node
+    uint32_t eventCount = 0;    // meter / snapshot: readouts already relayed by processQueuedEvents
     uint32_t convSlices = 1;    // convolve: helper slices its current impulse response wants (conv.hip)
 };
 
@@ -106,6 +107,9 @@ public:
     void pruneSharedResources();
     size_t gc(int32_t* out, size_t cap);
     void reset();
+    // Runtime::processQueuedEvents (Runtime.h:64, 437-446): relays the newest meter / snapshot readout of every such node
+    // of the current render sequence whose root is active. cb(type, json payload, user).
+    int processQueuedEvents(void (*cb)(const char*, const char*, void*), void* user);
     void setStream(hipStream_t s);
     const Stats& stats() const { return st; }
     // dry-engine introspection for host-logic tests: adopt the pending plan and describe it as JSON
@@ -198,6 +202,7 @@ struct Plan {
     uint32_t numTasks = 0, numMembers = 0, numOperands = 0;
     std::vector<RootEntry> roots;
     std::vector<TapEntry> taps;
+    std::vector<std::pair<int32_t, int32_t>> eventNodes;   // (node id, owning root id) of meter / snapshot nodes, render order
     std::vector<ConvDesc> convs;           // convolve nodes (conv.hip)
     std::vector<uint32_t> convWork;        // conv workgroups, level-major
     std::vector<uint32_t> convLevelOffsets; // numLevels + 1

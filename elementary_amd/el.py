@@ -83,6 +83,14 @@ def sample(props: Dict[str, Any], trigger: ElemNode, rate: ElemNode) -> NodeRepr
     return _n("sample", props, trigger, rate)
 
 
+def meter(props: Dict[str, Any], x: ElemNode) -> NodeRepr:
+    return _n("meter", props, x)
+
+
+def snapshot(props: Dict[str, Any], trigger: ElemNode, x: ElemNode) -> NodeRepr:
+    return _n("snapshot", props, trigger, x)
+
+
 def table(props: Dict[str, Any], t: ElemNode) -> NodeRepr:
     return _n("table", props, t)
 

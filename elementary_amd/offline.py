@@ -17,6 +17,7 @@ class OfflineRenderer:
     def __init__(self, engine_factory: Callable[[float, int], Any]):
         self._factory = engine_factory
         self._rt: Any = None
+        self._listeners: Dict[str, list] = {}
 
     def initialize(self, num_input_channels: int = 0, num_output_channels: int = 2, sample_rate: float = 44100,
                    block_size: int = 512, virtual_file_system: Optional[Dict[str, np.ndarray]] = None) -> None:
@@ -32,6 +33,10 @@ class OfflineRenderer:
     @property
     def runtime(self) -> Any:
         return self._rt
+
+    def on(self, kind: str, callback) -> None:
+        """EventEmitter.on of the reference renderer (index.ts:14): 'meter', 'snapshot', ..."""
+        self._listeners.setdefault(kind, []).append(callback)
 
     def render(self, *roots: Any) -> Dict[str, Any]:
         stats = self._rt.render(*roots)
@@ -60,6 +65,9 @@ class OfflineRenderer:
                     block_in[i, :len(seg)] = seg
             out = self._rt.process(block_in, self.num_out, bs, sample_time=self._time)
             self._time += bs
+            for kind, payload in self._rt.process_queued_events():     # index.ts:118-122: relay events after every block
+                for cb in self._listeners.get(kind, []):
+                    cb(payload)
             for i, buf in enumerate(outputs):
                 m = min(bs, len(buf) - k)
                 if m > 0:

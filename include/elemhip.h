@@ -87,6 +87,12 @@ int  elemhip_time_launches(elemhip_t*, size_t nOut, size_t numBlocks, float* msO
 /* Tracing hook: render one block while workgroup 0 of launch level `level` logs shader-clock
  * timestamps per task. out[wave*192 + 0..3] = {tasks, kernel start, prologue end, kernel end};
  * out[wave*192 + 3*(k+2) + 0..2] = {opcode | stage<<16 | flags<<24, start, end} for the wave's k-th task. */
+/* void processQueuedEvents(std::function<void(std::string const&, js::Value)>&&)   runtime/elem/Runtime.h:64, 437-446
+ * Non-render thread. Relays the newest readout of every `meter` / `snapshot` node (builtins/Analyzers.h) of the current
+ * render sequence whose root is active: cb(type, JSON payload, user), e.g. ("meter", {"min":..,"max":..,"source":name|null}). */
+typedef void (*elemhip_event_cb)(const char* type, const char* json_payload, void* user);
+int  elemhip_process_queued_events(elemhip_t*, elemhip_event_cb cb, void* user);
+
 int  elemhip_trace_level(elemhip_t*, size_t nOut, uint32_t level, unsigned long long* out, size_t cap);
 /* Debug/test hook: JSON description of the current render plan (islands, launch levels, LDS).
  * deviceOrdinal == -1 at create time gives a "dry" handle that runs all host logic (instruction

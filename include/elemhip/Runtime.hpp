@@ -3,6 +3,7 @@
 // cli/Benchmark.cpp switches engines by changing the class it instantiates.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -44,6 +45,13 @@ public:
         return elemhip_add_shared_resource(h, name.c_str(), channels, nCh, nSamples) != 0;
     }
     void pruneSharedResources() { elemhip_prune_shared_resources(h); }                    // Runtime.h:89
+    // processQueuedEvents: the payload arrives as JSON text (parse with elem::js::parseJSON to get the js::Value back)
+    void processQueuedEvents(std::function<void(std::string const&, std::string const&)>&& cb) {   // Runtime.h:64
+        auto tramp = [](const char* type, const char* json, void* user) {
+            (*static_cast<std::function<void(std::string const&, std::string const&)>*>(user))(type, json);
+        };
+        elemhip_process_queued_events(h, tramp, &cb);
+    }
     void reset() { elemhip_reset(h); }                                                    // Runtime.h:70
     std::set<int32_t> gc() {                                                              // Runtime.h:76
         std::vector<int32_t> buf(1 << 16);

@@ -120,7 +120,7 @@ enum Kind {
     K_ADD, K_SUB, K_MUL, K_DIV, K_MOD, K_MIN, K_MAX,
     K_ROOT, K_CONST, K_PHASOR, K_SPHASOR, K_SR, K_SEQ, K_COUNTER, K_ACCUM, K_LATCH, K_MAXHOLD, K_ONCE, K_RAND,
     K_DELAY, K_SDELAY, K_Z, K_POLE, K_ENV, K_BIQUAD, K_PREWARP, K_MM1P, K_SVF, K_SVFSHELF, K_TAPIN, K_TAPOUT,
-    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ, K_CONVOLVE, K_TABLE, K_SEQ2, K_SPARSEQ2, K_SAMPLE,
+    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ, K_CONVOLVE, K_TABLE, K_SEQ2, K_SPARSEQ2, K_SAMPLE, K_METER, K_SNAPSHOT,
 };
 
 // registry names: runtime/elem/DefaultNodeTypes.h:49-144 (hot-path subset) + wasm/Main.cpp:47-61
@@ -136,7 +136,7 @@ const std::unordered_map<std::string, Kind>& registry() {
         {"sdelay", K_SDELAY}, {"z", K_Z}, {"pole", K_POLE}, {"env", K_ENV}, {"biquad", K_BIQUAD}, {"prewarp", K_PREWARP},
         {"mm1p", K_MM1P}, {"svf", K_SVF}, {"svfshelf", K_SVFSHELF}, {"tapIn", K_TAPIN}, {"tapOut", K_TAPOUT},
         {"blepsaw", K_BLEPSAW}, {"blepsquare", K_BLEPSQUARE}, {"bleptriangle", K_BLEPTRIANGLE}, {"time", K_TIME},
-        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ}, {"convolve", K_CONVOLVE}, {"table", K_TABLE}, {"seq2", K_SEQ2}, {"sparseq2", K_SPARSEQ2}, {"sample", K_SAMPLE},
+        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ}, {"convolve", K_CONVOLVE}, {"table", K_TABLE}, {"seq2", K_SEQ2}, {"sparseq2", K_SPARSEQ2}, {"sample", K_SAMPLE}, {"meter", K_METER}, {"snapshot", K_SNAPSHOT},
     };
     return r;
 }
@@ -199,6 +199,8 @@ struct Node {
     SeqReader readers[2]; size_t activeReader = 0; size_t sampleLen = 0, pendingSampleLen = 0;
     size_t sampleBufSize() const { return sampleLen; }
     int32_t interp = 0;          // sparseq2
+    // meter / snapshot readouts (Analyzers.h): the relay reports the newest one and clears the queue
+    bool haveReadout = false; float roMin = 0, roMax = 0, roVal = 0;
     // sample (Sample.h:22-231): two VariablePitchLerpReader<float>
     struct LerpReader { float targetGain = 0, gain = 0; double pos = 0; bool hasBuffer = false; } lerp[2];
     size_t currentReader = 0, startOffset = 0, stopOffset = 0; int sampleMode = 0;
@@ -830,6 +832,24 @@ struct Oracle {
                 n.readers[1].readAdding(out, N);
                 break;
             }
+            case K_METER: {                                                                               // Analyzers.h:23-41
+                if (nIn < 1) { zero(); break; }
+                std::copy_n(in[0], N, out);
+                const auto mm = std::minmax_element(in[0], in[0] + N);
+                n.roMin = *mm.first; n.roMax = *mm.second; n.haveReadout = true;
+                break;
+            }
+            case K_SNAPSHOT: {                                                                            // Analyzers.h:83-110
+                if (nIn < 2) { zero(); break; }
+                const float eps = std::numeric_limits<float>::epsilon();
+                for (size_t i = 0; i < N; ++i) {
+                    const float l = in[0][i], x = in[1][i];
+                    if (std::abs(n.f0) <= eps && l > eps) { n.roVal = x; n.haveReadout = true; }
+                    n.f0 = l;
+                    out[i] = x;
+                }
+                break;
+            }
             case K_SAMPLE: {                                                                              // Sample.h:82-139, 178-221
                 if (n.samplePending) {
                     n.sampleBuf = n.pendingSampleBuf; n.sampleLen = n.pendingSampleLen; n.samplePending = false;
@@ -943,6 +963,36 @@ struct Oracle {
         }
     }
 
+    // ---- Runtime::processQueuedEvents -> RootRenderSequence::processQueuedEvents (Runtime.h:437-446, GraphRenderSequence.h:189-198)
+    void events(void (*cb)(const char*, const char*, void*), void* user) {
+        if (!current) return;
+        auto numStr = [](float v) { char b[64]; std::snprintf(b, sizeof b, "%.17g", (double)v); return std::string(b); };
+        for (RootSeq& rs : current->roots) {
+            Node& root = nodes.at(rs.root);
+            auto a = root.props.find("active");
+            if (a == root.props.end() || a->second.t != JV::Bool || !a->second.b) continue;
+            for (int32_t id : rs.order) {
+                Node& n = nodes.at(id);
+                if ((n.kind != K_METER && n.kind != K_SNAPSHOT) || !n.haveReadout) continue;
+                n.haveReadout = false;
+                std::string src = "null";
+                auto nm = n.props.find("name");
+                if (nm != n.props.end() && nm->second.t == JV::Str) {
+                    src = "\"";
+                    for (char ch : nm->second.s) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; }
+                    src += "\"";
+                }
+                if (n.kind == K_METER) {                                                                  // Analyzers.h:43-62
+                    const std::string j = "{\"min\": " + numStr(n.roMin) + ", \"max\": " + numStr(n.roMax) + ", \"source\": " + src + "}";
+                    cb("meter", j.c_str(), user);
+                } else {                                                                                  // Analyzers.h:112-131
+                    const std::string j = "{\"source\": " + src + ", \"data\": " + numStr(n.roVal) + "}";
+                    cb("snapshot", j.c_str(), user);
+                }
+            }
+        }
+    }
+
     // ---- Runtime::process -> GraphRenderSequence::process (Runtime.h:274-290, GraphRenderSequence.h:212-309)
     int process(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t N, int64_t sampleTime) {
         if (pending) { current = pending; pending.reset(); }
@@ -1030,6 +1080,9 @@ void elemoracle_prune_shared_resources(void* h) {   // SharedResource.h:94-102
     for (auto it = o->resources.begin(); it != o->resources.end();) { if (it->second.use_count() == 1) it = o->resources.erase(it); else ++it; }
 }
 size_t elemoracle_gc(void* h, int32_t* out, size_t cap) { return static_cast<Oracle*>(h)->gc(out, cap); }
+int elemoracle_process_queued_events(void* h, void (*cb)(const char*, const char*, void*), void* user) {
+    static_cast<Oracle*>(h)->events(cb, user); return 0;
+}
 void elemoracle_reset(void*) {}   // Runtime.h:448-458: only SampleNode (out of scope) reacts
 
 } // extern "C"

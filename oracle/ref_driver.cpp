@@ -38,6 +38,7 @@ struct RefBase {
     virtual void prune() = 0;
     virtual size_t gc(int32_t* out, size_t cap) = 0;
     virtual void reset() = 0;
+    virtual void events(void (*cb)(const char*, const char*, void*), void* user) = 0;
 };
 
 template <typename F>
@@ -109,6 +110,13 @@ struct Ref final : RefBase {
     }
 
     void reset() override { rt.reset(); }
+
+    void events(void (*cb)(const char*, const char*, void*), void* user) override {   // Runtime.h:437-446
+        rt.processQueuedEvents([&](std::string const& type, elem::js::Value evt) {
+            const std::string json = elem::js::serialize(evt);
+            cb(type.c_str(), json.c_str(), user);
+        });
+    }
 };
 
 } // namespace
@@ -132,5 +140,8 @@ int elemref_add_shared_resource(void* h, const char* name, const float* const* c
 void elemref_prune_shared_resources(void* h) { static_cast<RefBase*>(h)->prune(); }
 size_t elemref_gc(void* h, int32_t* out, size_t cap) { return static_cast<RefBase*>(h)->gc(out, cap); }
 void elemref_reset(void* h) { static_cast<RefBase*>(h)->reset(); }
+int elemref_process_queued_events(void* h, void (*cb)(const char*, const char*, void*), void* user) {
+    static_cast<RefBase*>(h)->events(cb, user); return 0;
+}
 
 } // extern "C"

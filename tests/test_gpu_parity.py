@@ -178,3 +178,27 @@ def test_sampleseq_scenario(gpu_required, block):
     a, b = sampleseq_scenario(hip, block=block), sampleseq_scenario(chk, block=block)
     assert np.abs(b).max() > 0.5
     assert float(np.abs(a - b).max()) <= TOL
+
+
+def test_event_relay(gpu_required):
+    """Runtime::processQueuedEvents (Runtime.h:437-446): meter / snapshot readouts of the HIP engine vs the checker."""
+    hip, chk = _engines()
+    logs = []
+    for mk in (hip, chk):
+        rt = mk(44100.0, 128)
+        x = el.in_({"channel": 0})
+        assert rt.render(el.meter({"name": "in"}, x), el.snapshot({"name": "snap"}, el.train(500.0), el.mul(2, x)),
+                         el.meter({}, el.cycle(100.0)))["result"] == 0
+        log = []
+        for k in range(12):
+            rt.process(lcg_noise(128, 5 + k, 0.5)[None, :], 3, 128)
+            if k % 3 != 1:
+                log.append(rt.process_queued_events())
+        logs.append(log)
+    assert len(logs[0]) == len(logs[1])
+    for a, b in zip(*logs):
+        assert [(t, p.get("source")) for t, p in a] == [(t, p.get("source")) for t, p in b]
+        for (_, pa), (_, pb) in zip(a, b):
+            for key in ("min", "max", "data"):
+                if key in pb:
+                    assert abs(pa[key] - pb[key]) <= TOL, (key, pa, pb)

@@ -227,3 +227,35 @@ def test_vfs_table_snapshot(core_factory):
     out = [f32(5)]
     core.process([np.asarray([0, 0.25, 0.5, 0.75, 1], np.float32)], out)
     core_factory.same(out[0], GOLD["vfs:vfs sample 1"])
+
+
+def test_event_propagation(core_factory):
+    """events.test.js:5-46: a meter fires once per block; payloads {min, max, source}."""
+    core = core_factory(num_input_channels=0, num_output_channels=1, block_size=512)
+    calls = []
+    core.on("meter", calls.append)
+    core.render(el.meter({}, 0))
+    core.process([], [f32(512 * 4)])
+    assert calls == [{"min": 0, "max": 0, "source": None}] * 4       # events.test.js.snap "event propagation 1"
+    calls.clear()
+    core.render(el.meter({}, 1))
+    core.process([], [f32(512 * 4)])
+    assert calls == [{"min": 1, "max": 1, "source": None}] * 4       # "event propagation 2"
+
+
+def test_snapshot_and_named_meter_events(core_factory):
+    """Analyzers.h:83-131: snapshot latches x on a zero -> non-zero trigger transition; `name` becomes `source`."""
+    core = core_factory(num_input_channels=1, num_output_channels=2, block_size=64)
+    snaps, meters = [], []
+    core.on("snapshot", snaps.append)
+    core.on("meter", meters.append)
+    x = el.in_({"channel": 0})
+    core.render(el.snapshot({"name": "s"}, el.train(44100.0 / 128.0), x), el.meter({"name": "m"}, x))
+    ramp = (np.arange(64 * 6, dtype=np.float32) / 1000.0).astype(np.float32)
+    out = [f32(64 * 6), f32(64 * 6)]
+    core.process([ramp], out)
+    assert [m["source"] for m in meters] == ["m"] * 6
+    assert [round(m["max"] - m["min"], 6) for m in meters] == [0.063] * 6
+    assert len(snaps) == 3 and all(s["source"] == "s" for s in snaps)            # one rising edge every 128 frames
+    make_vals = [s["data"] for s in snaps]
+    assert make_vals == sorted(make_vals) and make_vals[0] >= 0.0

@@ -69,3 +69,23 @@ def test_sampleseq_scenario_bit_exact():
     assert np.abs(b).max() > 0.5
     a, b = sampleseq_scenario(port, block=512), sampleseq_scenario(ref, block=512)
     assert np.array_equal(a, b)
+
+
+def test_event_relay_matches_reference():
+    """Runtime::processQueuedEvents: same (type, payload) sequence from the restatement and the reference."""
+    from elementary_amd import el
+    from helpers import lcg_noise
+    logs = []
+    for mk in (port, ref):
+        rt = mk(44100.0, 128)
+        x = el.in_({"channel": 0})
+        assert rt.render(el.meter({"name": "in"}, x), el.snapshot({"name": "snap"}, el.train(500.0), el.mul(2, x)),
+                         el.meter({}, el.cycle(100.0)))["result"] == 0
+        log = []
+        for k in range(12):
+            rt.process(lcg_noise(128, 5 + k, 0.5)[None, :], 3, 128)
+            if k % 3 != 1:                      # skipped relays: only the newest readout survives
+                log.append(rt.process_queued_events())
+        logs.append(log)
+    assert logs[0] == logs[1]
+    assert sum(len(e) for e in logs[0]) > 16
