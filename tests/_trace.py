@@ -20,7 +20,22 @@ def trace(rt, nout, level=0):
             d0, t0, t1 = buf[o+3*(k+2)], buf[o+3*(k+2)+1], buf[o+3*(k+2)+2]
             print(f"    {names.get(d0 & 0xFFFF, d0 & 0xFFFF):12s} stage {(d0>>16)&0xFF:2d} blk {d0>>32:2d}  [{t0-base:7d} .. {t1-base:7d}]  {t1-t0:6d} clk")
 which = sys.argv[1] if len(sys.argv) > 1 else "voice"
-if which == "voicepipe":
+if which == "pipe32":
+    rt = Runtime(48000.0, 512); assert rt.render(*[graphs.c2_voice(k) for k in range(8)])["result"] == 0
+    rt.process_blocks(8, 8); rt.set_option("time_batch", 32)
+    buf = (C.c_ulonglong * (8*192))()
+    for _ in range(3):
+        rc = lib.elemhip_trace_level(rt._h, 8, 0, buf, 8*192); assert rc == 0, rc
+    base = min(buf[w*192+1] for w in range(8) if buf[w*192+1])
+    for w in range(8):
+        o = w*192; nt = buf[o]
+        rows = []
+        for k in range(min(nt, 62)):
+            d0, t0, t1 = buf[o+3*(k+2)], buf[o+3*(k+2)+1], buf[o+3*(k+2)+2]
+            rows.append((names.get(d0 & 0xFFFF, "?"), (d0 >> 16) & 0xFF, d0 >> 32, t0 - base, t1 - t0))
+        print(f"wave{w} tasks={nt} end={buf[o+3]-base}")
+        print("   " + " ".join(f"{n[:4]}{st}b{b}@{t0//1000}k+{d//100/10:g}k" for n, st, b, t0, d in rows))
+elif which == "voicepipe":
     rt = Runtime(48000.0, 512); assert rt.render(*[graphs.c2_voice(k) for k in range(8)])["result"] == 0
     rt.process_blocks(8, 8); rt.set_option("time_batch", 8); trace(rt, 8)
 elif which == "voice":
