@@ -68,7 +68,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=256, help="blocks per elemhip_process_blocks call")
     ap.add_argument("--graph-blocks", type=int, default=8, help="blocks per captured hipGraph (per-block launch path)")
-    ap.add_argument("--batch-blocks", type=int, default=32, help="blocks per multi-block launch (1 = per-block launches)")
+    ap.add_argument("--batch-blocks", type=int, default=64, help="blocks per multi-block launch (1 = per-block launches)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--voices", type=int, default=256)

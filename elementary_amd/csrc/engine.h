@@ -164,7 +164,7 @@ private:
     uint32_t maxLdsConfigured = 0;
     bool useGraph = true;
     int  graphBlocks = 8;
-    int  batchBlocks = 32;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)
+    int  batchBlocks = 64;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)
     int  pipelineCopies = 6;               // blocks a stateful island keeps in flight inside a multi-block launch
     int  timeBatch = 1;
     uint32_t lastTimeBatch = 1;            // blocks per launch the last timeLaunches actually used                    // timeLaunches: blocks per timed launch

@@ -75,15 +75,16 @@ uint32_t leafArityOfOp(uint16_t op) {
 
 // estimated shader cycles of one task on a lone wave (measured on the C2 voice island, tests/_trace.py)
 uint32_t taskCost(uint16_t op, uint32_t units, uint32_t count) {
-    if (op == OP_SVF_COEF || op == OP_SHELF_COEF) return 2500u * units * count;           // double tan + divides per frame
-    if (op == OP_SVF || op == OP_SVFSHELF || op == OP_MM1P) return 9500u * count;         // wave scan
-    if (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_BLEPTRIANGLE) return 19000u;
-    if (op == OP_POLE || op == OP_ENV || op == OP_BIQUAD) return 15500u;
-    if (kindOf(op) == K_CHAIN) return 12500u;
-    if (kindOf(op) == K_SINGLE) return 4000u * count;
-    if (op == OP_ROOT) return 2500u + 150u * units * count;
-    if (op >= OP_SIN && op <= OP_EXP) return 700u + 220u * units * count;
-    return 900u + 90u * units * count;
+    const uint32_t gap = 800u;                                                              // walk + decode + signal around every task
+    if (op == OP_SVF_COEF || op == OP_SHELF_COEF) return gap + 3000u * units * count;      // double tan + divides per frame
+    if (op == OP_SVF || op == OP_SVFSHELF || op == OP_MM1P) return gap + 9500u * count;    // wave scan
+    if (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_BLEPTRIANGLE) return gap + 19000u;
+    if (op == OP_POLE || op == OP_ENV || op == OP_BIQUAD) return gap + 16000u;
+    if (kindOf(op) == K_CHAIN) return gap + 13000u;
+    if (kindOf(op) == K_SINGLE) return gap + 4000u * count;
+    if (op == OP_ROOT) return gap + 2800u + 130u * units * count;
+    if (op >= OP_SIN && op <= OP_EXP) return gap + 900u + 380u * units * count;            // tanh: 1.7 k (2 units) .. 4 k (8 units)
+    return gap + 1100u + 100u * units * count;                                              // light op: 1.3 k (2 units) .. 1.9 k (8 units)
 }
 
 struct NI {                      // per-node planning info
@@ -591,7 +592,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             // In a pipelined island the long serial tasks get waves 0..3 to themselves and the sample-parallel work
             // runs on waves 4..7: a light task on the critical path of an older block never queues behind a
             // 15-20 k-cycle recurrence of a younger one.
-            const int serialWaves = copies > 1 ? (int)kWaves / 2 : (int)kWaves;
+            const int serialWaves = (int)kWaves;   // (dedicating waves 0..3 to the serial tasks was measured: no gain, worse balance)
             auto pickWave = [&]() {
                 int b = 0;
                 for (int w = 1; w < serialWaves; ++w)
@@ -621,7 +622,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 }
             }
             std::vector<int> freeWaves;
-            for (int w = copies > 1 ? serialWaves : 0; w < (int)kWaves; ++w) if (busy[w] == 0) freeWaves.push_back(w);
+            for (int w = 0; w < (int)kWaves; ++w) if (busy[w] == 0) freeWaves.push_back(w);
             if (freeWaves.empty()) freeWaves.push_back(pickWave());
             std::sort(freeWaves.begin(), freeWaves.end(), [&](int a, int b) { return waveLoad[a] < waveLoad[b]; });
             // Light sample-parallel ops cost mostly per-task overhead. In a pipelined island (blocks overlap, so

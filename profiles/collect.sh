@@ -6,7 +6,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 REPO=$PWD
-CMD="python $REPO/bench.py --no-cpu-baseline --steps 1024 --warmup 128"
+CMD="python $REPO/bench.py --no-cpu-baseline --steps 2048 --warmup 256"
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $CMD > $OUT/prof_stats.log 2>&1)
