@@ -1,0 +1,93 @@
+"""Randomised graphs (seeded): planner clustering / staging / pipelining edge cases that the hand-written
+cases do not reach. Every graph is rendered three ways — reference CPU engine, HIP process(), HIP
+process_blocks() (multi-block pipelined launches) — and must agree (1e-6 abs, x max|ref| when > 1)."""
+import random
+
+import numpy as np
+import pytest
+
+from elementary_amd import el
+from helpers import lcg_noise
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def random_graph(seed, n_nodes=28, n_roots=3):
+    """Nodes are drawn from two pools. `exact` holds signals every IEEE engine computes bit-identically (no libm
+    transcendental, no double-precision filter upstream); only those may drive inputs that integrate or threshold
+    their argument (oscillator frequencies, comparisons, triggers) — a 1-ulp libm difference there grows without
+    bound and says nothing about the engine. Everything else reads from `anyp`."""
+    rnd = random.Random(seed)
+    X = [el.in_({"channel": 0}), el.in_({"channel": 1})]
+    exact = list(X) + [el.const({"value": rnd.uniform(-1, 1)}) for _ in range(3)]
+    anyp = list(exact)
+
+    def ex():
+        return rnd.choice(exact)
+
+    def pick():
+        return rnd.choice(anyp)
+
+    def clip(x):                         # exact limiter
+        return el.max(-1.0, el.min(1.0, x))
+
+    E, A = True, False                   # result is exact iff the maker says so (its inputs then all came from `exact`)
+    makers = [
+        (E, lambda: el.add(ex(), ex())), (E, lambda: el.mul(ex(), ex())), (E, lambda: el.sub(ex(), ex())),
+        (A, lambda: el.add(pick(), pick(), pick(), pick())), (A, lambda: el.mul(pick(), pick())),
+        (E, lambda: el.min(ex(), ex())), (A, lambda: el.max(pick(), pick())),
+        (A, lambda: el.tanh(pick())), (A, lambda: el.sin(el.mul(3.0, pick()))), (E, lambda: el.abs(ex())), (E, lambda: el.sqrt(el.abs(ex()))),
+        (E, lambda: el.le(ex(), ex())), (E, lambda: el.geq(ex(), 0.1)),
+        (E, lambda: el.phasor(rnd.uniform(1, 2000))), (E, lambda: el.phasor(el.add(300.0, el.mul(200.0, clip(ex()))))),
+        (A, lambda: el.blepsaw(rnd.uniform(50, 3000))), (A, lambda: el.blepsquare(el.add(500.0, el.mul(300.0, clip(ex()))))),
+        (E, lambda: el.pole(rnd.uniform(0.5, 0.999), clip(ex()))), (A, lambda: el.pole(el.mul(0.9, el.abs(clip(ex()))), pick())),
+        (A, lambda: el.env(el.tau2pole(0.001), el.tau2pole(0.02), pick())),
+        (A, lambda: el.lowpass(el.add(900.0, el.mul(700.0, clip(pick()))), rnd.uniform(0.5, 4.0), clip(pick()))),
+        (A, lambda: el.highpass(rnd.uniform(100, 5000), 1.0, clip(pick()))),
+        (A, lambda: el.mm1p({"mode": "lowpass"}, el.prewarp(rnd.uniform(100, 4000)), clip(pick()))),
+        (A, lambda: el.biquad(0.2, 0.3, 0.2, -0.5, 0.2, clip(pick()))),
+        (E, lambda: el.z(ex())), (E, lambda: el.sdelay({"size": rnd.randint(1, 900)}, ex())),
+        (A, lambda: el.delay({"size": rnd.choice([16, 400, 3000])}, rnd.uniform(1, 300), rnd.uniform(-0.5, 0.5), clip(pick()))),
+        (A, lambda: el.latch(el.train(rnd.uniform(5, 300)), pick())), (E, lambda: el.counter(el.train(rnd.uniform(5, 100)))),
+        (A, lambda: el.accum(el.abs(clip(pick())), el.train(rnd.uniform(5, 50)))),
+        (E, lambda: el.seq({"seq": [rnd.uniform(-1, 1) for _ in range(rnd.randint(1, 6))], "hold": rnd.random() < 0.5},
+                           el.train(rnd.uniform(20, 400)), el.train(rnd.uniform(1, 20)))),
+        (E, lambda: el.seq2({"seq": [rnd.uniform(-1, 1) for _ in range(rnd.randint(1, 6))]}, el.train(rnd.uniform(20, 400)), 0)),
+        (E, lambda: el.rand({"seed": rnd.randint(1, 1 << 30)})), (E, lambda: el.mul(1e-5, el.time())), (E, lambda: el.metro({"interval": rnd.uniform(1, 20)})),
+        (A, lambda: el.maxhold({"hold": rnd.uniform(0.5, 5.0)}, el.abs(pick()), el.train(rnd.uniform(2, 40)))),
+        (E, lambda: el.sparseq2({"interpolate": rnd.randint(0, 1), "seq": [{"time": 512.0 * k, "value": rnd.uniform(-1, 1)} for k in range(1, 9)]}, el.time())),
+    ]
+    for _ in range(n_nodes):
+        is_exact, mk = rnd.choice(makers)
+        node = mk()
+        anyp.append(node)
+        if is_exact:
+            exact.append(node)
+    return [el.tanh(el.add(*rnd.sample(anyp[5:], 4))) for _ in range(n_roots)]
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_graph(gpu_required, seed):
+    import torch
+    import oracle
+    from elementary_amd.runtime import Runtime
+    nb, n_out = 22, min(3, 1 + seed % 5)
+    x = np.stack([np.stack([lcg_noise(512, 11 + 7 * k + c, 0.5) for c in range(2)]) for k in range(nb)])   # [nb, 2, 512]
+    chk = oracle.RefRuntime(48000.0, 512) if oracle.have_ref() else oracle.PortRuntime(48000.0, 512)
+    a, b = Runtime(48000.0, 512), Runtime(48000.0, 512)
+    b.set_option("batch_blocks", 5 + seed % 7)
+    for rt in (chk, a, b):
+        assert rt.render(*random_graph(seed, n_nodes=24 + 22 * (seed % 4), n_roots=1 + seed % 5)[:n_out])["result"] == 0
+    ref = np.stack([chk.process(x[k], n_out, 512) for k in range(nb)])
+    got = np.stack([a.process(x[k], n_out, 512) for k in range(nb)])
+    xin = torch.from_numpy(x).cuda()
+    out = torch.zeros((nb, n_out, 512), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    b.process_blocks(nb, n_out, out_ptr=out.data_ptr(), in_ptr=xin.data_ptr(), num_inputs=2)
+    batched = out.cpu().numpy()
+    assert np.isfinite(ref).all()
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(got - ref).max()) <= TOL * scale, f"seed {seed}: process() max err {np.abs(got - ref).max():.3e}"
+    assert np.array_equal(batched, got), f"seed {seed}: process_blocks differs from process by {np.abs(batched - got).max():.3e}"
+    assert b.stats()["batch_launches"] > 0
