@@ -97,7 +97,7 @@ def c3(args):
     assert cpu.render(*graphs.c3_graph(ch))["result"] == 0
     c, m = _time_cpu(cpu, ch, ch, x[:, :BLOCK].copy())
     alg = graphs.c3_algorithmic_bytes(ch)
-    conv_us = 1e3 * lv[1] if len(lv) > 2 else None
+    conv_us = 1e3 * (lv[1] if len(lv) > 2 else lv[0])    # the convolve launch (level 0 once `in` / root are folded into it)
     return {"config": "C3 8-channel convolution reverb, 96 000-tap IRs, sr 48000", "gpu_us_per_block": 1e6 * g,
             "gpu_samples_per_s": BLOCK / g, "cpu_us_per_block": 1e6 * c, "cpu_kind": kind + " (plain radix-2 FFT, not Ooura)",
             "cpu_blocks_timed": m, "speedup": c / g, "launch_us": [1e3 * v for v in lv],

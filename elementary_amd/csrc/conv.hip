@@ -119,8 +119,24 @@ __device__ void conv_main(const ConvDesc d, gup recs, gfp hbm, const Globals* g,
     gfp out = hbm + (size_t)d.outHbm * stride;
     gcup r = (gcup)(recs + d.rec * kRecDwords);
     const uint64_t sp = (uint64_t)r[rec::CONV_STATE] | ((uint64_t)r[rec::CONV_STATE + 1] << 32);
-    uint32_t inKind = d.inKind;
-    if (inKind == 3u) inKind = g->numIn > 0 ? 1u : 0u;                 // leaf: host channel 0 (arena buffer 0)
+    uint32_t inKind = d.inKind, inBuf = d.inIdx;
+    if (inKind == 3u) { inKind = g->numIn > 0 ? 1u : 0u; inBuf = 0u; }   // leaf: host channel 0 (arena buffer 0)
+    if (inKind == 5u) {                                                  // folded `in` node (Math.h:92-126): its channel, or silence
+        const uint32_t ch = ((gcup)recs)[d.inIdx * kRecDwords + rec::P0];
+        if (ch < g->numIn) { inKind = 1u; inBuf = ch; } else inKind = 4u;
+    }
+    // folded root (Core.h:66-78 / GainFade.h:56-72): gain ramp of this block
+    float rootG = 1.0f, rootT = 1.0f, rootStep = 0.0f;
+    if (d.fuseRootRec != kNone) {
+        gcup rr = (gcup)(recs + d.fuseRootRec * kRecDwords);
+        rootG = __uint_as_float(rr[rec::ROOT_GAIN]); rootT = __uint_as_float(rr[rec::ROOT_TARGET]); rootStep = __uint_as_float(rr[rec::ROOT_STEP]);
+    }
+    auto rootGain = [&](uint32_t frame) {
+        if (d.fuseRootRec == kNone) return 1.0f;
+        if (rootG == rootT) return rootT;
+        const float v = rootG + rootStep * (float)(int)frame;
+        return (v < 0.0f) ? 0.0f : ((1.0f < v) ? 1.0f : v);
+    };
     if (sp == 0ull || inKind == 0u) {                                 // Convolve.h:70-71
         for (uint32_t i = tid; i < n; i += 256u) out[i] = 0.0f;
         return;
@@ -130,7 +146,7 @@ __device__ void conv_main(const ConvDesc d, gup recs, gfp hbm, const Globals* g,
         for (uint32_t i = tid; i < n; i += 256u) out[i] = 0.0f;
         return;
     }
-    gcfp in = (gcfp)(hbm + (size_t)(inKind == 1u ? (d.inKind == 3u ? 0u : d.inIdx) : 0u) * stride);
+    gcfp in = (gcfp)(hbm + (size_t)(inKind == 1u ? inBuf : 0u) * stride);
     const float cval = inKind == 2u ? __uint_as_float(((gcup)recs)[d.inIdx * kRecDwords + rec::P0]) : 0.0f;
     for (uint32_t i = tid; i < conv::kFft; i += 256u) W[i] = kTwiddle[i];
 
@@ -188,7 +204,10 @@ __device__ void conv_main(const ConvDesc d, gup recs, gfp hbm, const Globals* g,
         __syncthreads();
         fft1024(A, B, W, tid);                                        // -> B; y[i] = Re B[i] (H carries the 1/1024)
         // 3. overlap-add and emit
-        for (uint32_t i = tid; i < chunk; i += 256u) out[processed + i] = B[fill + i].x + st.overlap[fill + i];
+        for (uint32_t i = tid; i < chunk; i += 256u) {
+            const float y = B[fill + i].x + st.overlap[fill + i];
+            out[processed + i] = d.fuseRootRec == kNone ? y : y * rootGain(processed + i);
+        }
         __syncthreads();
         fill += chunk;
         if (fill == 512u) {
@@ -213,7 +232,7 @@ __device__ void conv_helper(const ConvDesc d, uint32_t h, gup recs, const Global
     const uint64_t sp = (uint64_t)r[rec::CONV_STATE] | ((uint64_t)r[rec::CONV_STATE + 1] << 32);
     uint32_t inKind = d.inKind;
     if (inKind == 3u) inKind = g->numIn > 0 ? 1u : 0u;
-    if (sp == 0ull || inKind == 0u) return;
+    if (sp == 0ull || inKind == 0u) return;                           // (kind 5 always convolves: its channel or silence)
     const State st = state_of((gup)reinterpret_cast<uint32_t*>(sp));
     if (st.P <= 2u) return;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;

@@ -136,12 +136,14 @@ struct RootEntry {
 struct ConvDesc {
     uint32_t rec;        // node record: p0/p1 = device pointer to the node's convolver state (conv:: layout)
     uint32_t inKind;     // 0 no input channel: zero output, state untouched; 1 HBM arena buffer; 2 const (record);
-                         // 3 leaf: host input 0 when the block has host inputs, else as 0; 4 silent input
+                         // 3 leaf: host input 0 when the block has host inputs, else as 0; 4 silent input;
+                         // 5 the host channel named by an `in` record (inIdx) that the planner folded into this launch
     uint32_t inIdx;
     uint32_t outHbm;     // HBM arena buffer receiving the output
     uint32_t rootRec;    // owning root (the node renders only while that root runs)
     uint32_t slices;     // helper workgroups per bin group the plan launches for this node
-    uint32_t pad_[2];
+    uint32_t fuseRootRec; // kNone, or the record of a root folded into this node: its fade is applied here (Core.h:66-78)
+    uint32_t pad_;
 };
 
 // Convolver state: one device allocation per `path` assignment, zero-initialised except H.

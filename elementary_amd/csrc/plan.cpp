@@ -101,6 +101,8 @@ struct NI {                      // per-node planning info
     uint32_t hbm = kNone;        // HBM arena index
     uint32_t scratch = kNone;
     int lastUse = 0;             // last in-island consumer stage
+    int fusedRoot = -1;          // convolve: NI index of the root whose gain this node applies itself (the root has no task)
+    bool elided = false;         // `in` leaf read directly by convolvers / root folded into its convolver: never a task
 };
 
 struct IslandBuild {
@@ -192,6 +194,37 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             ni.push_back(x);
             p.nodeIds.insert(id);
         }
+    }
+
+    // ---- 1b. nodes folded into the convolve launch ------------------------------------------------------
+    // `root(convolve(in))` is the whole graph of a convolution reverb channel: three launch levels for one
+    // kernel's worth of work. An `in` leaf whose only in-plan consumers are convolvers is read by them straight
+    // from the host-input arena, and a root whose only input is a convolver owned by the same sequence (and
+    // consumed by nothing else) has its fade applied by that convolver, which writes the root's buffer.
+    for (NI& x : ni) {
+        if (x.n->op != OP_IN || !x.n->inlets.empty()) continue;
+        bool any = false, all = true;
+        for (auto& o : x.n->outlets) {
+            auto it = idx.find(o.dest);
+            if (it == idx.end()) continue;
+            any = true;
+            if (ni[it->second].n->op != OP_CONVOLVE) all = false;
+        }
+        if (any && all) { x.kind = K_CONST; x.elided = true; }
+    }
+    for (size_t sq = 0; sq < seqRoots.size(); ++sq) {
+        Node* r = seqRoots[sq];
+        if (r->inlets.size() != 1 || r->inlets[0].channel != 0) continue;
+        auto it = idx.find(r->inlets[0].source);
+        if (it == idx.end()) continue;
+        NI& c = ni[it->second];
+        if (c.kind != K_CONV || c.seq != (int)sq) continue;
+        size_t consumers = 0;
+        for (auto& o : c.n->outlets) if (idx.count(o.dest)) ++consumers;
+        if (consumers != 1) continue;
+        NI& rn = ni[idx.at(r->id)];
+        rn.kind = K_CONST; rn.elided = true;
+        c.fusedRoot = idx.at(r->id);
     }
 
     // ---- 2. islands ---------------------------------------------------------------------------------
@@ -345,6 +378,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ib[a].level < ib[b].level; });
         uint32_t next = kMaxHostIn;
         for (int i : order) for (int k : ib[i].nodes) if (ni[k].exported) ni[k].hbm = next++;
+        for (NI& x : ni) if (x.elided && x.n->op == OP_ROOT) x.hbm = next++;   // written by the root's convolver
         p.numHbmBuffers = next;
     }
 
@@ -359,11 +393,14 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             NI& x = ni[B.nodes[0]];
             ConvDesc d{};
             d.rec = x.n->rec; d.outHbm = x.hbm; d.rootRec = I.rootRec; d.slices = std::max<uint32_t>(1, x.n->convSlices);
+            d.fuseRootRec = kNone;
+            if (x.fusedRoot >= 0) { d.outHbm = ni[x.fusedRoot].hbm; d.fuseRootRec = ni[x.fusedRoot].n->rec; }
             if (x.n->inlets.empty()) d.inKind = 3;                                      // leaf: host input 0
             else {
                 const Inlet& in = x.n->inlets[0];
                 auto it = idx.find(in.source);
                 if (it == idx.end() || in.channel != 0) d.inKind = 4;
+                else if (ni[it->second].elided) { d.inKind = 5; d.inIdx = ni[it->second].n->rec; }   // host channel named by the `in` record
                 else if (ni[it->second].kind == K_CONST) { d.inKind = 2; d.inIdx = ni[it->second].n->rec; }
                 else { d.inKind = 1; d.inIdx = ni[it->second].hbm; }
             }
