@@ -56,7 +56,7 @@ enum Op : uint16_t {
     OP_TAPIN, OP_TAPOUT, OP_SAMPLESEQ, OP_BLEPSAW, OP_BLEPSQUARE, OP_BLEPTRIANGLE,
     OP_TIME, OP_METRO, OP_CONVOLVE,
     OP_TABLE, OP_SEQ2, OP_SPARSEQ2, OP_SAMPLE,
-    OP_METER, OP_SNAPSHOT,                        // event side-channel (Analyzers.h)
+    OP_METER, OP_SNAPSHOT, OP_SCOPE,              // event side-channel (Analyzers.h)
     // plan pseudo-ops
     OP_COPY,          // out = in0 (import HBM->LDS, export LDS->HBM)
     OP_SVF_COEF,      // SVF coefficient pre-pass (a1,a2,a3 as double into the member's scratch), sample-parallel
@@ -228,6 +228,8 @@ enum : uint32_t {
     SPS_INTERP = P0, SPS_SEQ = P4, SPS_LEN = P6,
     // meter: S0 min, S1 max, S2 readout count; snapshot: S0 previous trigger sample, S1 captured value, S2 capture count
     EVT_A = 8, EVT_B = 9, EVT_COUNT = 10,
+    // scope: device ring [4 channels][8192] (MultiChannelRingBuffer.h), write / read positions shared with the host relay
+    SCP_RING = P0, SCP_WRITE = 8, SCP_READ = 9,
     // sample (Sample.h:22-231): buffer, length, new-buffer flag, mode (0 trigger, 1 gate, 2 loop), offsets, gain smoothing alpha;
     // state: change detector, current reader, two readers {target gain, gain, pos (double)}
     SMP_BUF = P0, SMP_LEN = P2, SMP_PENDING = P3, SMP_MODE = P4, SMP_START = P5, SMP_STOP = P6, SMP_ALPHA = P7,

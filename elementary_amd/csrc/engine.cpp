@@ -56,7 +56,7 @@ static const std::unordered_map<std::string, uint16_t>& opTable() {
         {"pole", OP_POLE}, {"env", OP_ENV}, {"biquad", OP_BIQUAD}, {"prewarp", OP_PREWARP}, {"mm1p", OP_MM1P}, {"svf", OP_SVF}, {"svfshelf", OP_SVFSHELF},
         {"tapIn", OP_TAPIN}, {"tapOut", OP_TAPOUT},
         {"blepsaw", OP_BLEPSAW}, {"blepsquare", OP_BLEPSQUARE}, {"bleptriangle", OP_BLEPTRIANGLE},
-        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2}, {"sample", OP_SAMPLE}, {"meter", OP_METER}, {"snapshot", OP_SNAPSHOT},
+        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2}, {"sample", OP_SAMPLE}, {"meter", OP_METER}, {"snapshot", OP_SNAPSHOT}, {"scope", OP_SCOPE},
     };
     return t;
 }
@@ -353,6 +353,9 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
         case OP_MAXHOLD: r[rec::P0] = 0xFFFFFFFFu; break;                         // Core.h:336
         case OP_SEQ:     r[rec::SEQ_HOLD] = 0; r[rec::SEQ_LOOP] = 1; break;       // Core.h:566-568
         case OP_SEQ2:    r[rec::SEQ_HOLD] = 0; r[rec::SEQ_LOOP] = 1; break;       // Seq2.h:157-159
+        case OP_SCOPE:   // Analyzers.h:142-149: ringBuffer(4) of 8192 frames, channels = 1, size = 512
+            n.props["channels"] = Value::number(1.0); n.props["size"] = Value::number(512.0);
+            break;
         case OP_SAMPLE:  // VariablePitchLerpReader(float sampleRate, ...): gainSmoothAlpha(1.0 - exp(-1.0 / (0.01 * sampleRate))), Sample.h:163
             r[rec::SMP_ALPHA] = fbits((float)(1.0 - std::exp(-1.0 / (0.01 * (double)(float)sampleRate)))); break;
         case OP_RAND:    r[rec::S0] = (uint32_t)std::rand(); break;               // Noise.h:42
@@ -376,6 +379,9 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
     } else if (nn.op == OP_TAPOUT) {                                              // Feedback.h:66-67
         rc = allocRing(nn, (size_t)blockSize);
         if (rc == kOk) writeParamPtr(nn, rec::TAP_PRIVATE, nn.ring.ptr);
+    } else if (nn.op == OP_SCOPE) {                                               // Analyzers.h:145: MultiChannelRingBuffer(4) x 8192
+        rc = allocRing(nn, 4u * 8192u);
+        if (rc == kOk) writeParamPtr(nn, rec::SCP_RING, nn.ring.ptr);
     }
     return rc;
 }
@@ -563,6 +569,11 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
                 if (vi < 0) return kInvalidPropertyValue;
                 writeParam(n, key == "startOffset" ? rec::SMP_START : rec::SMP_STOP, (uint32_t)vi);
             }
+            break;
+        case OP_SCOPE:                                             // Analyzers.h:151-173
+            if (key == "size") { if (!v.isNumber()) return kInvalidPropertyType; if (v.num < 256 || v.num > 8192) return kInvalidPropertyValue; }
+            if (key == "channels") { if (!v.isNumber()) return kInvalidPropertyType; if (v.num < 0 || v.num > 4) return kInvalidPropertyValue; }
+            if (key == "name") { if (!v.isString()) return kInvalidPropertyType; }
             break;
         case OP_TABLE:                                             // Table.h:20-33
             if (key == "path") {
@@ -770,6 +781,33 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
         auto a = rit->second.props.find("active");                       // GraphRenderSequence.h:192
         if (a == rit->second.props.end() || !a->second.isBool() || !a->second.b) continue;
         Node& n = nit->second;
+        if (n.op == OP_SCOPE) {                                           // Analyzers.h:192-245, MultiChannelRingBuffer.h:61-86
+            auto numOr = [&](const char* k, double dflt) { auto q = n.props.find(k); return (q != n.props.end() && q->second.isNumber()) ? q->second.num : dflt; };
+            const size_t size = (size_t)numOr("size", 512.0), channels = (size_t)numOr("channels", 1.0);
+            const uint32_t cap = 8192u, mask = cap - 1u;
+            uint32_t pos[2] = {0, 0};                                     // write, read
+            HIP_OK(hipMemcpy(pos, dRecs + (size_t)n.rec * kRecDwords + rec::SCP_WRITE, sizeof pos, hipMemcpyDeviceToHost));
+            const uint32_t w = pos[0], r = pos[1];
+            const uint32_t full = w > r ? w - r : ((cap - (r - w)) & mask);
+            if (!(full > size) || !n.ring.ptr) continue;
+            std::vector<float> host(4u * cap);
+            HIP_OK(hipMemcpy(host.data(), n.ring.ptr, host.size() * 4, hipMemcpyDeviceToHost));
+            std::string src = "null";
+            auto nm = n.props.find("name");
+            if (nm != n.props.end() && nm->second.isString()) { src = "\""; for (char ch : nm->second.str) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; } src += "\""; }
+            std::string j = "{\"source\": " + src + ", \"data\": [";
+            for (size_t ch = 0; ch < channels; ++ch) {
+                j += ch ? ", [" : "[";
+                for (size_t i = 0; i < size; ++i) { if (i) j += ", "; j += numStr(host[ch * cap + ((r + i) & mask)]); }
+                j += "]";
+            }
+            j += "]}";
+            const uint32_t nr = (uint32_t)((r + size) & mask);
+            HIP_OK(hipMemcpy(dRecs + (size_t)n.rec * kRecDwords + rec::SCP_READ, &nr, 4, hipMemcpyHostToDevice));
+            shadow[(size_t)n.rec * kRecDwords + rec::SCP_READ] = nr;
+            cb("scope", j.c_str(), user);
+            continue;
+        }
         uint32_t st[3] = {0, 0, 0};
         HIP_OK(hipMemcpy(st, dRecs + (size_t)n.rec * kRecDwords + rec::EVT_A, sizeof st, hipMemcpyDeviceToHost));
         if (st[2] == n.eventCount) continue;                             // nothing new since the last relay

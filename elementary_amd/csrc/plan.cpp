@@ -30,7 +30,7 @@ enum Kind : uint8_t { K_CONST, K_PAR, K_SINGLE, K_CHAIN, K_CONV };
 Kind kindOf(uint16_t op) {
     switch (op) {
         case OP_CONST: case OP_SR: return K_CONST;
-        case OP_RAND: case OP_Z: case OP_SDELAY: case OP_DELAY: case OP_SAMPLESEQ: case OP_METER: case OP_SNAPSHOT: return K_SINGLE;
+        case OP_RAND: case OP_Z: case OP_SDELAY: case OP_DELAY: case OP_SAMPLESEQ: case OP_METER: case OP_SNAPSHOT: case OP_SCOPE: return K_SINGLE;
         case OP_CONVOLVE: return K_CONV;   // always an island of its own, rendered by conv.hip
         case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD:
         case OP_ONCE: case OP_SEQ: case OP_SEQ2: case OP_SAMPLE: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
@@ -58,6 +58,7 @@ uint32_t leafArity(uint16_t op) {
         case OP_Z: case OP_SDELAY: case OP_PREWARP: case OP_ROOT: case OP_TAPOUT: case OP_SAMPLESEQ: return 1;
         case OP_SPHASOR: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_SEQ: case OP_SEQ2: case OP_SAMPLE: case OP_POLE: case OP_MM1P: case OP_SNAPSHOT: return 2;
         case OP_ENV: case OP_SVF: case OP_DELAY: return 3;
+        case OP_SCOPE: return 4;
         case OP_SVFSHELF: return 4;
         case OP_BIQUAD: return 6;
         case OP_LE: case OP_LEQ: case OP_GE: case OP_GEQ: case OP_POW: case OP_EQ: case OP_AND: case OP_OR: return 2;
@@ -867,7 +868,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         p.roots.push_back(RootEntry{r->rec, x.hbm});
         p.rootIds.push_back(r->id);
         for (int k : seqNodes[s]) if (ni[k].n->op == OP_TAPOUT) p.taps.push_back(TapEntry{ni[k].n->rec, r->rec});
-        for (int k : seqNodes[s]) if (ni[k].n->op == OP_METER || ni[k].n->op == OP_SNAPSHOT) p.eventNodes.push_back({ni[k].n->id, r->id});
+        for (int k : seqNodes[s]) if (ni[k].n->op == OP_METER || ni[k].n->op == OP_SNAPSHOT || ni[k].n->op == OP_SCOPE) p.eventNodes.push_back({ni[k].n->id, r->id});
     }
     return plan;
 }

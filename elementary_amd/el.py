@@ -87,6 +87,10 @@ def meter(props: Dict[str, Any], x: ElemNode) -> NodeRepr:
     return _n("meter", props, x)
 
 
+def scope(props: Dict[str, Any], *args: ElemNode) -> NodeRepr:
+    return _n("scope", props, *args)
+
+
 def snapshot(props: Dict[str, Any], trigger: ElemNode, x: ElemNode) -> NodeRepr:
     return _n("snapshot", props, trigger, x)
 

@@ -120,7 +120,7 @@ enum Kind {
     K_ADD, K_SUB, K_MUL, K_DIV, K_MOD, K_MIN, K_MAX,
     K_ROOT, K_CONST, K_PHASOR, K_SPHASOR, K_SR, K_SEQ, K_COUNTER, K_ACCUM, K_LATCH, K_MAXHOLD, K_ONCE, K_RAND,
     K_DELAY, K_SDELAY, K_Z, K_POLE, K_ENV, K_BIQUAD, K_PREWARP, K_MM1P, K_SVF, K_SVFSHELF, K_TAPIN, K_TAPOUT,
-    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ, K_CONVOLVE, K_TABLE, K_SEQ2, K_SPARSEQ2, K_SAMPLE, K_METER, K_SNAPSHOT,
+    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ, K_CONVOLVE, K_TABLE, K_SEQ2, K_SPARSEQ2, K_SAMPLE, K_METER, K_SNAPSHOT, K_SCOPE,
 };
 
 // registry names: runtime/elem/DefaultNodeTypes.h:49-144 (hot-path subset) + wasm/Main.cpp:47-61
@@ -136,7 +136,7 @@ const std::unordered_map<std::string, Kind>& registry() {
         {"sdelay", K_SDELAY}, {"z", K_Z}, {"pole", K_POLE}, {"env", K_ENV}, {"biquad", K_BIQUAD}, {"prewarp", K_PREWARP},
         {"mm1p", K_MM1P}, {"svf", K_SVF}, {"svfshelf", K_SVFSHELF}, {"tapIn", K_TAPIN}, {"tapOut", K_TAPOUT},
         {"blepsaw", K_BLEPSAW}, {"blepsquare", K_BLEPSQUARE}, {"bleptriangle", K_BLEPTRIANGLE}, {"time", K_TIME},
-        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ}, {"convolve", K_CONVOLVE}, {"table", K_TABLE}, {"seq2", K_SEQ2}, {"sparseq2", K_SPARSEQ2}, {"sample", K_SAMPLE}, {"meter", K_METER}, {"snapshot", K_SNAPSHOT},
+        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ}, {"convolve", K_CONVOLVE}, {"table", K_TABLE}, {"seq2", K_SEQ2}, {"sparseq2", K_SPARSEQ2}, {"sample", K_SAMPLE}, {"meter", K_METER}, {"snapshot", K_SNAPSHOT}, {"scope", K_SCOPE},
     };
     return r;
 }
@@ -201,6 +201,8 @@ struct Node {
     int32_t interp = 0;          // sparseq2
     // meter / snapshot readouts (Analyzers.h): the relay reports the newest one and clears the queue
     bool haveReadout = false; float roMin = 0, roMax = 0, roVal = 0;
+    // scope (Analyzers.h:137-250): MultiChannelRingBuffer(4) of 8192 frames
+    std::vector<float> scopeRing; size_t scopeW = 0, scopeR = 0;
     // sample (Sample.h:22-231): two VariablePitchLerpReader<float>
     struct LerpReader { float targetGain = 0, gain = 0; double pos = 0; bool hasBuffer = false; } lerp[2];
     size_t currentReader = 0, startOffset = 0, stopOffset = 0; int sampleMode = 0;
@@ -355,6 +357,11 @@ struct Oracle {
                 if (key == "mode") { if (!str) return 5; if (v.s == "trigger") n.sampleMode = 0; if (v.s == "gate") n.sampleMode = 1; if (v.s == "loop") n.sampleMode = 2; }
                 if (key == "startOffset") { if (!num) return 5; const int vi = (int)v.n; if (vi < 0) return 6; n.startOffset = (size_t)vi; }
                 if (key == "stopOffset") { if (!num) return 5; const int vi = (int)v.n; if (vi < 0) return 6; n.stopOffset = (size_t)vi; }
+                break;
+            case K_SCOPE:                                                                                 // Analyzers.h:151-173
+                if (key == "size") { if (!num) return 5; if (v.n < 256 || v.n > 8192) return 6; }
+                if (key == "channels") { if (!num) return 5; if (v.n < 0 || v.n > 4) return 6; }
+                if (key == "name") { if (!str) return 5; }
                 break;
             case K_TABLE:                                                                                 // Table.h:20-33
                 if (key == "path") {
@@ -832,6 +839,20 @@ struct Oracle {
                 n.readers[1].readAdding(out, N);
                 break;
             }
+            case K_SCOPE: {                                                                               // Analyzers.h:175-190, MultiChannelRingBuffer.h:34-59
+                if (nIn < 1) { zero(); break; }
+                std::copy_n(in[0], N, out);
+                const size_t cap = 8192, mask = cap - 1;
+                if (n.scopeRing.empty()) n.scopeRing.assign(4 * cap, 0.0f);
+                const size_t w = n.scopeW, r = n.scopeR;
+                const size_t freeSlots = r > w ? r - w : cap - (w - r);
+                const size_t nw = (w + N) & mask;
+                for (size_t ch = 0; ch < std::min<size_t>(4, nIn); ++ch)
+                    for (size_t i = 0; i < N; ++i) n.scopeRing[ch * cap + ((w + i) & mask)] = in[ch][i];
+                n.scopeW = nw;
+                n.scopeR = N >= freeSlots ? ((nw + 1) & mask) : r;
+                break;
+            }
             case K_METER: {                                                                               // Analyzers.h:23-41
                 if (nIn < 1) { zero(); break; }
                 std::copy_n(in[0], N, out);
@@ -973,6 +994,26 @@ struct Oracle {
             if (a == root.props.end() || a->second.t != JV::Bool || !a->second.b) continue;
             for (int32_t id : rs.order) {
                 Node& n = nodes.at(id);
+                if (n.kind == K_SCOPE) {                                                                  // Analyzers.h:192-245
+                    auto numOr = [&](const char* k, double d) { auto q = n.props.find(k); return (q != n.props.end() && q->second.t == JV::Num) ? q->second.n : d; };
+                    const size_t size = (size_t)numOr("size", 512.0), channels = (size_t)numOr("channels", 1.0), cap = 8192, mask = cap - 1;
+                    const size_t w = n.scopeW, r = n.scopeR;
+                    const size_t full = w > r ? w - r : ((cap - (r - w)) & mask);
+                    if (!(full > size) || n.scopeRing.empty()) continue;
+                    std::string src = "null";
+                    auto nm = n.props.find("name");
+                    if (nm != n.props.end() && nm->second.t == JV::Str) { src = "\""; for (char ch : nm->second.s) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; } src += "\""; }
+                    std::string j = "{\"source\": " + src + ", \"data\": [";
+                    for (size_t ch = 0; ch < channels; ++ch) {
+                        j += ch ? ", [" : "[";
+                        for (size_t i = 0; i < size; ++i) { if (i) j += ", "; j += numStr(n.scopeRing[ch * cap + ((r + i) & mask)]); }
+                        j += "]";
+                    }
+                    j += "]}";
+                    n.scopeR = (r + size) & mask;
+                    cb("scope", j.c_str(), user);
+                    continue;
+                }
                 if ((n.kind != K_METER && n.kind != K_SNAPSHOT) || !n.haveReadout) continue;
                 n.haveReadout = false;
                 std::string src = "null";

@@ -61,6 +61,8 @@ def test_return_codes_match_reference():
         [[0, 1, "sparseq2"], [3, 1, "interpolate", "x"]],   # 5 (SparSeq2.h:46-50)
         [[0, 1, "sample"], [3, 1, "startOffset", -3]],      # 6 (Sample.h:50-61)
         [[0, 1, "sample"], [3, 1, "mode", 2]],              # 5 (:37-47)
+        [[0, 1, "scope"], [3, 1, "size", 100]],             # 6 (Analyzers.h:153-159)
+        [[0, 1, "scope"], [3, 1, "name", 3]],               # 5 (:169-172)
         [[2, 1, 2, 0]],                                     # 2
         [[0, 1, "root"], [4, [1, 2]], [5]],                 # 2 (activateRoots on a missing node)
         ["x"],                                              # 8 invalid instruction format
@@ -69,7 +71,7 @@ def test_return_codes_match_reference():
         [[0, 1, "root"], [0, 2, "const"], [2, 1, 2, 0], [3, 1, "channel", 0], [4, [1]], [5]],   # 0
     ]
     have_ref = oracle.have_ref()
-    expect = [1, 3, 2, 5, 6, 6, 5, 6, 5, 6, 5, 6, 6, 5, 6, 5, 2, 2, 8, 8, 0, 0]
+    expect = [1, 3, 2, 5, 6, 6, 5, 6, 5, 6, 5, 6, 6, 5, 6, 5, 6, 5, 2, 2, 8, 8, 0, 0]
     for b, want in zip(batches, expect):
         got = dry().apply_instructions(b)
         assert got == want, (b, got)

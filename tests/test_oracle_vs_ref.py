@@ -80,10 +80,11 @@ def test_event_relay_matches_reference():
         rt = mk(44100.0, 128)
         x = el.in_({"channel": 0})
         assert rt.render(el.meter({"name": "in"}, x), el.snapshot({"name": "snap"}, el.train(500.0), el.mul(2, x)),
-                         el.meter({}, el.cycle(100.0)))["result"] == 0
+                         el.meter({}, el.cycle(100.0)),
+                         el.scope({"name": "sc", "size": 256, "channels": 2}, x, el.mul(0.5, x), el.mul(0.25, x)))["result"] == 0
         log = []
         for k in range(12):
-            rt.process(lcg_noise(128, 5 + k, 0.5)[None, :], 3, 128)
+            rt.process(lcg_noise(128, 5 + k, 0.5)[None, :], 4, 128)
             if k % 3 != 1:                      # skipped relays: only the newest readout survives
                 log.append(rt.process_queued_events())
         logs.append(log)
