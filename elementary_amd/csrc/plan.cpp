@@ -155,6 +155,7 @@ struct PlanBuilder {
         }
     }
 
+    bool splitCoefStage = true;
     std::shared_ptr<Plan> build(uint32_t maxIslandNodes, uint32_t maxCopies);
 };
 
@@ -447,7 +448,9 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 // its slice), so a sample-parallel consumer of a sample-parallel producer can run in
                 // the SAME stage on the same wave, right after it, with no barrier in between.
                 const bool xsvf = x.n->op == OP_SVF || x.n->op == OP_SVFSHELF;   // its coefficient pre-pass is such an op too
-                const bool fuse = (x.kind == K_PAR || xsvf) && s.kind == K_PAR;
+                // (xsvf && splitCoefStage: the pre-pass gets a stage of its own, so its light producers run unsplit on one
+                // wave instead of four times with four times the per-task overhead)
+                const bool fuse = (x.kind == K_PAR || (xsvf && !splitCoefStage)) && s.kind == K_PAR;
                 const int need = fuse ? s.level : s.level + 1;
                 if (need > lv) { lv = need; sub = 0; }
                 if (fuse && s.level == lv) sub = std::max(sub, s.sub + 1);
@@ -670,7 +673,16 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             for (auto& kv : par) if (kv.first.second == OP_SVF_COEF || kv.first.second == OP_SHELF_COEF) hasCoef = true;
             std::vector<int> parWaves = freeWaves;
             if (parWaves.size() > 4) parWaves.resize(4);   // a finer split only multiplies per-task overhead
-            if (copies > 1 && !hasCoef) parWaves = {freeWaves[0]};
+            if (copies > 1) {
+                // split a stage's sample-parallel work so that one part is about as long as a serial recurrence
+                // (~12 k cycles): light stages run unsplit, a filter-coefficient pre-pass on two waves. A finer split
+                // shortens the stage but makes its completion wait for the slowest of more, unrelated wave queues.
+                uint32_t total = 0;
+                for (auto& kv : par) total += taskCost(kv.first.second, 8, (uint32_t)kv.second.size());
+                size_t f = total >= 36000u ? 4 : (total >= 18000u ? 2 : 1);
+                f = std::min(f, parWaves.size());
+                parWaves.resize(f);
+            }
             for (auto& kv : par) {
                 const uint32_t first = (uint32_t)members.size();
                 for (int k : kv.second) members.push_back(makeMember(ni[k]));
