@@ -798,6 +798,19 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 std::stable_sort(mine.begin(), mine.end(), [&](uint32_t a, uint32_t b) {
                     const uint32_t sla = a - stageTab[base + phaseOf[a]], slb = b - stageTab[base + phaseOf[b]];
                     return sla != slb ? sla < slb : phaseOf[a] > phaseOf[b]; });
+                if (mine.size() > 1 && mine.size() <= 32) {
+                    // the kernel polls a wave's slots in table order and runs the first ready one (any order is correct,
+                    // the completion counters carry the dependencies): shortest slot first keeps a 2-4 k-cycle slot of a
+                    // young block from queueing behind a 10 k-cycle slot of an old one — block latency, and with it the
+                    // pipeline period (latency / blocks in flight), is what the short slots sit on.
+                    auto slotCost = [&](uint32_t st) {
+                        uint32_t cst = 0;
+                        for (uint32_t q = begin[st]; q < begin[st + 1]; ++q)
+                            cst += taskCost(tasks[q].opcode, ((uint32_t)tasks[q].s1 - tasks[q].s0 + 63u) / 64u, tasks[q].count);
+                        return cst;
+                    };
+                    std::stable_sort(mine.begin(), mine.end(), [&](uint32_t a, uint32_t b) { return slotCost(a) < slotCost(b); });
+                }
                 for (uint32_t st : mine) {
                     const uint32_t prev = stageTab[S + st];
                     const uint32_t e[8] = {st, phaseOf[st], begin[st], begin[st + 1], prev, prev == kNone ? 0u : stageTab[prev], 0u, 0u};
