@@ -118,6 +118,7 @@ struct Island {
     uint32_t stateless;            // 1: only stateless sample-parallel nodes: blocks of a batch may run in any order / in parallel
     uint32_t ldsCounters;          // LDS word of the completion counters [numStages][copies]
     uint32_t schedOff;             // dword offset (whole blob): walkOffsets[kWaves+1] | walk entries (8 dwords each), 16-byte aligned
+    uint32_t ldsNext;              // LDS word of the per-wave next-block counters [kWaves][numStages] of the dataflow walk
 };
 
 struct ConstCell {

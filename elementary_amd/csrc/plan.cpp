@@ -76,7 +76,7 @@ uint32_t leafArityOfOp(uint16_t op) {
 
 // estimated shader cycles of one task on a lone wave (measured on the C2 voice island, tests/_trace.py)
 uint32_t taskCost(uint16_t op, uint32_t units, uint32_t count) {
-    const uint32_t gap = 800u;                                                              // walk + decode + signal around every task
+    const uint32_t gap = 1600u;                                                             // walk + decode + signal around every task
     if (op == OP_SVF_COEF || op == OP_SHELF_COEF) return gap + 3000u * units * count;      // double tan + divides per frame
     if (op == OP_SVF || op == OP_SVFSHELF || op == OP_MM1P) return gap + 9500u * count;    // wave scan
     if (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_BLEPTRIANGLE) return gap + 19000u;
@@ -480,21 +480,29 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         }
 
         // LDS slots by liveness. Words 0..3 = zero cell; slots start at word kSlot0.
-        std::vector<int> slotFreeAt;   // stage from which the slot is free again
+        // Two regions keep the allocation dense: buffers that live for one stage (and the multi-slot scratch areas, which
+        // need consecutive slots) recycle the low region; buffers that stay live across several stages go to their own
+        // region, so they never leave holes in front of a scratch request. (C2 voice: 13 slots -> 10, i.e. one more block in
+        // flight in the same LDS.)
+        std::vector<int> slotFreeAt[2];   // per region: stage from which the slot is free again
+        const uint32_t kLongBit = 1u << 31;
         auto takeSlots = [&](int stage, uint32_t count, int lastUse) -> uint32_t {
+            const int region = (count == 1 && lastUse - stage >= 2) ? 1 : 0;
+            std::vector<int>& fr = slotFreeAt[region];
+            const uint32_t tag = region ? kLongBit : 0u;
             // `count` consecutive slots free at `stage`
-            const size_t S = slotFreeAt.size();
+            const size_t S = fr.size();
             for (size_t s0 = 0; s0 + count <= S; ++s0) {
                 bool ok = true;
-                for (uint32_t c = 0; c < count; ++c) if (slotFreeAt[s0 + c] > stage) { ok = false; break; }
-                if (ok) { for (uint32_t c = 0; c < count; ++c) slotFreeAt[s0 + c] = lastUse + 1; return kSlot0 + (uint32_t)s0 * kSlotWords; }
+                for (uint32_t c = 0; c < count; ++c) if (fr[s0 + c] > stage) { ok = false; break; }
+                if (ok) { for (uint32_t c = 0; c < count; ++c) fr[s0 + c] = lastUse + 1; return tag | (uint32_t)s0; }
             }
             // extend (reuse a free tail if there is one)
             size_t s0 = S;
-            while (s0 > 0 && slotFreeAt[s0 - 1] <= stage && S - (s0 - 1) <= count) --s0;
-            slotFreeAt.resize(s0 + count, 0);
-            for (uint32_t c = 0; c < count; ++c) slotFreeAt[s0 + c] = lastUse + 1;
-            return kSlot0 + (uint32_t)s0 * kSlotWords;
+            while (s0 > 0 && fr[s0 - 1] <= stage && S - (s0 - 1) <= count) --s0;
+            fr.resize(s0 + count, 0);
+            for (uint32_t c = 0; c < count; ++c) fr[s0 + c] = lastUse + 1;
+            return tag | (uint32_t)s0;
         };
         for (auto& im : imports) im.lds = takeSlots(0, 1, im.lastUse);
         for (int stage = base; stage <= maxStage; ++stage) {
@@ -511,7 +519,13 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 if (sc && x.n->op != OP_SVF && x.n->op != OP_SVFSHELF) x.scratch = takeSlots(stage, sc, stage);
             }
         }
-        const uint32_t slotArea = (uint32_t)slotFreeAt.size() * kSlotWords;      // block-buffer words of one copy
+        {   // slot index -> LDS word: short-lived region first, long-lived region behind it
+            const uint32_t nShort = (uint32_t)slotFreeAt[0].size();
+            auto resolve = [&](uint32_t v) { return v == kNone ? v : kSlot0 + ((v & kLongBit) ? nShort + (v & ~kLongBit) : v) * kSlotWords; };
+            for (auto& im : imports) im.lds = resolve(im.lds);
+            for (int k : B.nodes) { ni[k].lds = resolve(ni[k].lds); ni[k].scratch = resolve(ni[k].scratch); }
+        }
+        const uint32_t slotArea = (uint32_t)(slotFreeAt[0].size() + slotFreeAt[1].size()) * kSlotWords;      // block-buffer words of one copy
         bool statelessIsland = true;
         for (int k : B.nodes) if (ni[k].kind != K_PAR || ni[k].n->op == OP_TAPIN || ni[k].n->op == OP_TAPOUT) statelessIsland = false;
         // blocks kept in flight by a multi-block launch: as many buffer sets as fit in ~140 KB of LDS (one such workgroup per CU)
@@ -689,6 +703,35 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 emitRanges(kv.first.second, stage, first, (uint32_t)kv.second.size(), parWaves);
             }
         }
+        if (copies > 1) {
+            // Pipelined island: re-assign whole (stage, wave) slots to waves, longest first (LPT), now that every slot's cost is
+            // known — the stage-by-stage choice above cannot see that, e.g., the long final stage is still to come and
+            // parks it on the wave that already carries the coefficient stage. Slots of one stage keep distinct waves.
+            struct Slot { int stage, wave; uint32_t cost; };
+            std::vector<Slot> slots;
+            for (size_t q = 0; q < tasks.size(); ++q) {
+                const uint32_t cst = taskCost(tasks[q].opcode, ((uint32_t)tasks[q].s1 - tasks[q].s0 + 63u) / 64u, tasks[q].count);
+                bool found = false;
+                for (Slot& sl : slots) if (sl.stage == tasks[q].stage && sl.wave == taskWave[q]) { sl.cost += cst; found = true; break; }
+                if (!found) slots.push_back(Slot{tasks[q].stage, taskWave[q], cst});
+            }
+            std::vector<size_t> order(slots.size());
+            std::iota(order.begin(), order.end(), (size_t)0);
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return slots[a].cost > slots[b].cost; });
+            uint32_t load[kWaves] = {};
+            std::map<int, uint32_t> usedInStage;                       // stage -> mask of waves taken
+            std::map<std::pair<int, int>, int> remap;                  // (stage, old wave) -> new wave
+            for (size_t o : order) {
+                const Slot& sl = slots[o];
+                uint32_t& used = usedInStage[sl.stage];
+                int best = -1;
+                for (int w = 0; w < (int)kWaves; ++w) if (!((used >> w) & 1u) && (best < 0 || load[w] < load[best])) best = w;
+                if (best < 0) for (int w = 0; w < (int)kWaves; ++w) if (best < 0 || load[w] < load[best]) best = w;
+                used |= 1u << best; load[best] += sl.cost;
+                remap[{sl.stage, sl.wave}] = best;
+            }
+            for (size_t q = 0; q < tasks.size(); ++q) taskWave[q] = remap.at({(int)tasks[q].stage, taskWave[q]});
+        }
         {   // per-wave task lists: sort by (wave, stage), keep emission order inside a (wave, stage)
             std::vector<size_t> order(tasks.size());
             std::iota(order.begin(), order.end(), (size_t)0);
@@ -798,19 +841,9 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 std::stable_sort(mine.begin(), mine.end(), [&](uint32_t a, uint32_t b) {
                     const uint32_t sla = a - stageTab[base + phaseOf[a]], slb = b - stageTab[base + phaseOf[b]];
                     return sla != slb ? sla < slb : phaseOf[a] > phaseOf[b]; });
-                if (mine.size() > 1 && mine.size() <= 32) {
-                    // the kernel polls a wave's slots in table order and runs the first ready one (any order is correct,
-                    // the completion counters carry the dependencies): shortest slot first keeps a 2-4 k-cycle slot of a
-                    // young block from queueing behind a 10 k-cycle slot of an old one — block latency, and with it the
-                    // pipeline period (latency / blocks in flight), is what the short slots sit on.
-                    auto slotCost = [&](uint32_t st) {
-                        uint32_t cst = 0;
-                        for (uint32_t q = begin[st]; q < begin[st + 1]; ++q)
-                            cst += taskCost(tasks[q].opcode, ((uint32_t)tasks[q].s1 - tasks[q].s0 + 63u) / 64u, tasks[q].count);
-                        return cst;
-                    };
-                    std::stable_sort(mine.begin(), mine.end(), [&](uint32_t a, uint32_t b) { return slotCost(a) < slotCost(b); });
-                }
+                // the kernel polls a wave's slots in table order and runs the first ready one: later stages first, so the
+                // oldest blocks drain (and release their buffer sets) before younger ones are started
+                std::sort(mine.begin(), mine.end(), [](uint32_t a, uint32_t b) { return a > b; });
                 for (uint32_t st : mine) {
                     const uint32_t prev = stageTab[S + st];
                     const uint32_t e[8] = {st, phaseOf[st], begin[st], begin[st + 1], prev, prev == kNone ? 0u : stageTab[prev], 0u, 0u};
@@ -861,7 +894,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         I.numStages = S;
         I.ldsProg = (slotWords + (uint32_t)cellOf.size() + 3u) & ~3u;
         I.ldsCounters = (I.ldsProg + I.progDwords + 3u) & ~3u;
-        I.ldsWords = (I.ldsCounters + S * copies + 3u) & ~3u;
+        I.ldsNext = (I.ldsCounters + S * copies + 3u) & ~3u;
+        I.ldsWords = (I.ldsNext + S * kWaves + 3u) & ~3u;
         p.maxLdsBytes = std::max(p.maxLdsBytes, I.ldsWords * 4u);
         p.numTasks += I.numTasks; p.numMembers += (uint32_t)members.size(); p.numOperands += (uint32_t)operands.size();
     }
@@ -984,7 +1018,12 @@ std::string Engine::describePlan() {
         s += "{\"tasks\":" + std::to_string(I.numTasks) + ",\"stages\":" + std::to_string(I.numStages) +
              ",\"lds_bytes\":" + std::to_string(I.ldsWords * 4) + ",\"consts\":" + std::to_string(I.numCells) +
              ",\"prog_dwords\":" + std::to_string(I.progDwords) + ",\"copies\":" + std::to_string(I.copies) +
-             ",\"stateless\":" + std::to_string(I.stateless) + "}";
+             ",\"stateless\":" + std::to_string(I.stateless) + ",\"phases\":[";
+        {   // first stage of each pipeline phase (stage tables of the island's program blob)
+            const uint32_t* tab = p.prog.data() + I.progBegin + I.stageOff + 2 * I.numStages + kWaves * (I.numStages + 1);
+            for (uint32_t d = 0; d <= I.copies; ++d) { if (d) s += ","; s += std::to_string(tab[d]); }
+        }
+        s += "]}";
         if (i >= 63) break;
     }
     s += "]}";
