@@ -66,7 +66,7 @@ enum Op : uint16_t {
 
 // One node of a task (8 dwords in the island program, 16-byte aligned).
 struct Member {
-    uint32_t rec;        // node record index
+    uint32_t rec;        // node record: local index into the island's staged record table (Island::recOff)
     uint32_t opnd;       // first operand (index into the island's operand array)
     uint32_t nin;        // operand count; kNone => leaf: operands are host inputs 0..nIn-1
     uint32_t outLds;     // LDS word offset of the output slot, or kNone
@@ -119,6 +119,9 @@ struct Island {
     uint32_t ldsCounters;          // LDS word of the completion counters [numStages][copies]
     uint32_t schedOff;             // dword offset (whole blob): walkOffsets[kWaves+1] | walk entries (8 dwords each), 16-byte aligned
     uint32_t ldsNext;              // LDS word of the per-wave next-block counters [kWaves][numStages] of the dataflow walk
+    uint32_t recOff;               // dword offset (whole blob) of the island's record table: global record index per local index
+    uint32_t numRecs;              // Member.rec is a LOCAL index into that table: the records are staged in LDS for the launch
+    uint32_t ldsRecs;              // LDS word of the staged records [numRecs][kRecDwords]
 };
 
 struct ConstCell {

@@ -550,9 +550,18 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             return word;
         };
 
+        std::vector<uint32_t> recTable;                  // local record index -> global record
+        std::unordered_map<uint32_t, uint32_t> localRec;
+        auto localOf = [&](uint32_t rec) {
+            auto it = localRec.find(rec);
+            if (it != localRec.end()) return it->second;
+            localRec.emplace(rec, (uint32_t)recTable.size());
+            recTable.push_back(rec);
+            return (uint32_t)recTable.size() - 1u;
+        };
         auto makeMember = [&](NI& x) -> Member {
             Member m{};
-            m.rec = x.n->rec;
+            m.rec = localOf(x.n->rec);
             m.opnd = (uint32_t)operands.size();
             m.outLds = x.needLds ? x.lds : kNone;
             m.outHbm = x.exported ? x.hbm : kNone;
@@ -869,7 +878,9 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         I.numCells = (uint32_t)cells.size();
         I.stageOff = (I.cellOff + I.numCells * 2u + 3u) & ~3u;
         I.schedOff = I.stageOff + schedRel;
-        I.progDwords = I.stageOff + (uint32_t)stageTab.size();
+        I.recOff = I.stageOff + (uint32_t)stageTab.size();
+        I.numRecs = (uint32_t)recTable.size();
+        I.progDwords = I.recOff + I.numRecs;
         p.prog.resize((size_t)I.progBegin + I.progDwords);
         for (uint32_t d = 0; d < copies; ++d) {
             const uint32_t off = d * slotArea;
@@ -889,13 +900,15 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             uint32_t* blob = p.prog.data() + I.progBegin;
             if (!cells.empty()) std::memcpy(blob + I.cellOff, cells.data(), cells.size() * sizeof(ConstCell));
             std::memcpy(blob + I.stageOff, stageTab.data(), stageTab.size() * 4);
+            if (!recTable.empty()) std::memcpy(blob + I.recOff, recTable.data(), recTable.size() * 4);
         }
         while (p.prog.size() % 4) p.prog.push_back(0);   // keep every blob 16-byte aligned
         I.numStages = S;
         I.ldsProg = (slotWords + (uint32_t)cellOf.size() + 3u) & ~3u;
         I.ldsCounters = (I.ldsProg + I.progDwords + 3u) & ~3u;
         I.ldsNext = (I.ldsCounters + S * copies + 3u) & ~3u;
-        I.ldsWords = (I.ldsNext + S * kWaves + 3u) & ~3u;
+        I.ldsRecs = (I.ldsNext + S * kWaves + 3u) & ~3u;
+        I.ldsWords = (I.ldsRecs + I.numRecs * kRecDwords + 3u) & ~3u;
         p.maxLdsBytes = std::max(p.maxLdsBytes, I.ldsWords * 4u);
         p.numTasks += I.numTasks; p.numMembers += (uint32_t)members.size(); p.numOperands += (uint32_t)operands.size();
     }
