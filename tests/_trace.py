@@ -18,7 +18,7 @@ def trace(rt, nout, level=0):
         print(f" wave{w}: start {ts-base} prologue_end {tp-base} end {te-base} tasks={nt}")
         for k in range(min(nt, 62)):
             d0, t0, t1 = buf[o+3*(k+2)], buf[o+3*(k+2)+1], buf[o+3*(k+2)+2]
-            print(f"    {names.get(d0 & 0xFFFF, d0 & 0xFFFF):12s} stage {(d0>>16)&0xFF:2d} blk {d0>>32:2d}  [{t0-base:7d} .. {t1-base:7d}]  {t1-t0:6d} clk")
+            print(f"    {names.get(d0 & 0xFFFF, d0 & 0xFFFF):12s} stage {(d0>>16)&0xFF:2d} blk {(d0>>32)&0xFFFF:2d}  [{t0-base:7d} .. {t1-base:7d}]  {t1-t0:6d} clk")
 which = sys.argv[1] if len(sys.argv) > 1 else "voice"
 if which == "pipe32":
     rt = Runtime(48000.0, 512); assert rt.render(*[graphs.c2_voice(k) for k in range(8)])["result"] == 0
@@ -32,9 +32,9 @@ if which == "pipe32":
         rows = []
         for k in range(min(nt, 62)):
             d0, t0, t1 = buf[o+3*(k+2)], buf[o+3*(k+2)+1], buf[o+3*(k+2)+2]
-            rows.append((names.get(d0 & 0xFFFF, "?"), (d0 >> 16) & 0xFF, d0 >> 32, t0 - base, t1 - t0))
+            rows.append((names.get(d0 & 0xFFFF, "?"), (d0 >> 16) & 0xFF, (d0 >> 32) & 0xFFFF, t0 - base, t1 - t0, ((d0 >> 48) & 0xFF) * 64, ((d0 >> 56) & 0xFF) * 64))
         print(f"wave{w} tasks={nt} end={buf[o+3]-base}")
-        print("   " + " ".join(f"{n[:4]}{st}b{b}@{t0//1000}k+{d//100/10:g}k" for n, st, b, t0, d in rows))
+        print("   " + " ".join(f"{n[:4]}{st}b{b}@{t0//1000}k+{d//100/10:g}k[{ga}/{gb}]" for n, st, b, t0, d, ga, gb in rows))
 elif which == "voicepipe":
     rt = Runtime(48000.0, 512); assert rt.render(*[graphs.c2_voice(k) for k in range(8)])["result"] == 0
     rt.process_blocks(8, 8); rt.set_option("time_batch", 8); trace(rt, 8)
