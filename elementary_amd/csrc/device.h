@@ -61,6 +61,8 @@ enum Op : uint16_t {
     OP_COPY,          // out = in0 (import HBM->LDS, export LDS->HBM)
     OP_SVF_COEF,      // SVF coefficient pre-pass (a1,a2,a3 as double into the member's scratch), sample-parallel
     OP_SHELF_COEF,    // shelf variant (a1,a2,a3,k,A)
+    OP_SAW_SHAPE,     // blepsaw waveform from (phase, frequency), sample-parallel, one stage after the phase recurrence
+    OP_SQUARE_SHAPE,  // blepsquare variant
     OP_COUNT_
 };
 

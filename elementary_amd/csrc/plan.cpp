@@ -68,24 +68,33 @@ uint32_t leafArity(uint16_t op) {
     }
 }
 
+// blepsaw / blepsquare take two stages: the phase recurrence (one lane, serial), then the waveform as a sample-parallel
+// task (OP_SAW_SHAPE / OP_SQUARE_SHAPE) that any wave can run — the recurrence is the longest serial item of a synth voice
+// and bounds a pipelined island's block rate, so nothing else rides on its wave.
+bool blepSplit(uint16_t op) { return op == OP_BLEPSAW || op == OP_BLEPSQUARE; }
+
 uint32_t leafArityOfOp(uint16_t op) {
+    if (op == OP_SAW_SHAPE || op == OP_SQUARE_SHAPE) return 1;
     if (op == OP_SVF_COEF) return leafArity(OP_SVF);
     if (op == OP_SHELF_COEF) return leafArity(OP_SVFSHELF);
     return leafArity(op);
 }
 
-// estimated shader cycles of one task on a lone wave (measured on the C2 voice island, tests/_trace.py)
+// estimated shader cycles of one task on a lone wave (measured on the pipelined C2 voice island, tests/_trace.py pipe32)
+constexpr uint32_t kSlotGap = 2500u;   // hand-over into a (stage, wave) slot: publish, poll, acquire
 uint32_t taskCost(uint16_t op, uint32_t units, uint32_t count) {
-    const uint32_t gap = 1600u;                                                             // walk + decode + signal around every task
-    if (op == OP_SVF_COEF || op == OP_SHELF_COEF) return gap + 3000u * units * count;      // double tan + divides per frame
+    const uint32_t gap = 900u;                                                              // header decode + dispatch around every task
+    if (op == OP_SVF_COEF || op == OP_SHELF_COEF) return gap + 2300u * units * count;      // double tan + divides per frame
     if (op == OP_SVF || op == OP_SVFSHELF || op == OP_MM1P) return gap + 9500u * count;    // wave scan
-    if (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_BLEPTRIANGLE) return gap + 19000u;
-    if (op == OP_POLE || op == OP_ENV || op == OP_BIQUAD) return gap + 16000u;
-    if (kindOf(op) == K_CHAIN) return gap + 13000u;
+    if (op == OP_SAW_SHAPE || op == OP_SQUARE_SHAPE) return gap + 500u * units * count;
+    if (op == OP_BLEPSAW || op == OP_BLEPSQUARE) return gap + 12500u;                       // phase recurrence only
+    if (op == OP_BLEPTRIANGLE) return gap + 30000u;
+    if (op == OP_POLE || op == OP_ENV || op == OP_BIQUAD) return gap + 15300u;
+    if (kindOf(op) == K_CHAIN) return gap + 12000u;
     if (kindOf(op) == K_SINGLE) return gap + 4000u * count;
-    if (op == OP_ROOT) return gap + 2800u + 130u * units * count;
-    if (op >= OP_SIN && op <= OP_EXP) return gap + 900u + 380u * units * count;            // tanh: 1.7 k (2 units) .. 4 k (8 units)
-    return gap + 1100u + 100u * units * count;                                              // light op: 1.3 k (2 units) .. 1.9 k (8 units)
+    if (op == OP_ROOT) return gap + 1000u + 250u * units * count;
+    if (op >= OP_SIN && op <= OP_EXP) return gap + 900u + 280u * units * count;            // tanh: 3.1 k for a whole block
+    return gap + 900u + 80u * units * count;                                                // light op: 1.5 k for a whole block
 }
 
 struct NI {                      // per-node planning info
@@ -155,7 +164,7 @@ struct PlanBuilder {
         }
     }
 
-    bool splitCoefStage = true;
+    bool splitCoefStage = false;
     std::shared_ptr<Plan> build(uint32_t maxIslandNodes, uint32_t maxCopies);
 };
 
@@ -450,7 +459,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 const bool xsvf = x.n->op == OP_SVF || x.n->op == OP_SVFSHELF;   // its coefficient pre-pass is such an op too
                 // (xsvf && splitCoefStage: the pre-pass gets a stage of its own, so its light producers run unsplit on one
                 // wave instead of four times with four times the per-task overhead)
-                const bool fuse = (x.kind == K_PAR || (xsvf && !splitCoefStage)) && s.kind == K_PAR;
+                // (a split oscillator's waveform task is sample-parallel as well: its consumers may follow it in its stage)
+                const bool fuse = (x.kind == K_PAR || (xsvf && !splitCoefStage)) && (s.kind == K_PAR || blepSplit(s.n->op));
                 const int need = fuse ? s.level : s.level + 1;
                 if (need > lv) { lv = need; sub = 0; }
                 if (fuse && s.level == lv) sub = std::max(sub, s.sub + 1);
@@ -458,6 +468,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             x.sub = sub;
             // svf / shelf take two stages: sample-parallel coefficient pre-pass, then the scan
             if (x.n->op == OP_SVF || x.n->op == OP_SVFSHELF) lv += 1;
+            if (blepSplit(x.n->op)) lv += 1;   // recurrence at lv - 1, waveform (the node's output) at lv
             x.level = lv;
             x.lastUse = lv;
             maxStage = std::max(maxStage, lv);
@@ -511,10 +522,14 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 if (x.level != stage + 1 || (x.n->op != OP_SVF && x.n->op != OP_SVFSHELF)) continue;
                 x.scratch = takeSlots(stage, scratchSlots(x.n->op), stage + 1);
             }
+            for (int k : B.nodes) {   // out slot of a split oscillator: carries the phase from the recurrence stage on
+                NI& x = ni[k];
+                if (x.level == stage + 1 && blepSplit(x.n->op) && x.needLds) x.lds = takeSlots(stage, 1, x.lastUse);
+            }
             for (int k : B.nodes) {
                 NI& x = ni[k];
                 if (x.level != stage) continue;
-                if (x.needLds) x.lds = takeSlots(stage, 1, x.lastUse);
+                if (x.needLds && !blepSplit(x.n->op)) x.lds = takeSlots(stage, 1, x.lastUse);
                 const uint32_t sc = scratchSlots(x.n->op);
                 if (sc && x.n->op != OP_SVF && x.n->op != OP_SVFSHELF) x.scratch = takeSlots(stage, sc, stage);
             }
@@ -644,8 +659,10 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 NI& x = ni[k];
                 if (x.level == stage + 1 && x.n->op == OP_SVF) par[{1 << 20, OP_SVF_COEF}].push_back(k);
                 if (x.level == stage + 1 && x.n->op == OP_SVFSHELF) par[{1 << 20, OP_SHELF_COEF}].push_back(k);
+                if (x.level == stage + 1 && blepSplit(x.n->op)) chain[(uint32_t)x.n->op | (constMaskOf(x) << 16)].push_back(k);
                 if (x.level != stage) continue;
-                if (x.kind == K_CHAIN) chain[(uint32_t)x.n->op | (constMaskOf(x) << 16)].push_back(k);
+                if (blepSplit(x.n->op)) par[{0, x.n->op == OP_BLEPSAW ? OP_SAW_SHAPE : OP_SQUARE_SHAPE}].push_back(k);
+                else if (x.kind == K_CHAIN) chain[(uint32_t)x.n->op | (constMaskOf(x) << 16)].push_back(k);
                 else if (x.kind == K_SINGLE) single[x.n->op].push_back(k);
                 else par[{x.sub, x.n->op}].push_back(k);
             }
@@ -722,7 +739,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 const uint32_t cst = taskCost(tasks[q].opcode, ((uint32_t)tasks[q].s1 - tasks[q].s0 + 63u) / 64u, tasks[q].count);
                 bool found = false;
                 for (Slot& sl : slots) if (sl.stage == tasks[q].stage && sl.wave == taskWave[q]) { sl.cost += cst; found = true; break; }
-                if (!found) slots.push_back(Slot{tasks[q].stage, taskWave[q], cst});
+                if (!found) slots.push_back(Slot{tasks[q].stage, taskWave[q], kSlotGap + cst});
             }
             std::vector<size_t> order(slots.size());
             std::iota(order.begin(), order.end(), (size_t)0);
@@ -1035,6 +1052,17 @@ std::string Engine::describePlan() {
         {   // first stage of each pipeline phase (stage tables of the island's program blob)
             const uint32_t* tab = p.prog.data() + I.progBegin + I.stageOff + 2 * I.numStages + kWaves * (I.numStages + 1);
             for (uint32_t d = 0; d <= I.copies; ++d) { if (d) s += ","; s += std::to_string(tab[d]); }
+        }
+        s += "],\"waves\":[";
+        for (uint32_t w = 0; w < kWaves; ++w) {   // per program wave: [opcode, stage] of its tasks in program order
+            if (w) s += ",";
+            s += "[";
+            for (uint32_t t = I.waveTask[w]; t < I.waveTask[w + 1]; ++t) {
+                const uint32_t d0 = p.prog[I.progBegin + t * 8u];
+                if (t != I.waveTask[w]) s += ",";
+                s += "[" + std::to_string(d0 & 0xFFFFu) + "," + std::to_string((d0 >> 16) & 0xFFu) + "]";
+            }
+            s += "]";
         }
         s += "]}";
         if (i >= 63) break;

@@ -20,12 +20,14 @@ def trace(rt, nout, level=0):
             d0, t0, t1 = buf[o+3*(k+2)], buf[o+3*(k+2)+1], buf[o+3*(k+2)+2]
             print(f"    {names.get(d0 & 0xFFFF, d0 & 0xFFFF):12s} stage {(d0>>16)&0xFF:2d} blk {(d0>>32)&0xFFFF:2d}  [{t0-base:7d} .. {t1-base:7d}]  {t1-t0:6d} clk")
 which = sys.argv[1] if len(sys.argv) > 1 else "voice"
-if which == "pipe32":
-    rt = Runtime(48000.0, 512); assert rt.render(*[graphs.c2_voice(k) for k in range(8)])["result"] == 0
-    rt.process_blocks(8, 8); rt.set_option("time_batch", 32)
+if which in ("pipe32", "c2pipe"):
+    rt = Runtime(48000.0, 512)
+    nout = 8 if which == "pipe32" else 2
+    assert rt.render(*([graphs.c2_voice(k) for k in range(8)] if which == "pipe32" else graphs.c2_graph()))["result"] == 0
+    rt.process_blocks(8, nout); rt.set_option("time_batch", 32)
     buf = (C.c_ulonglong * (8*192))()
     for _ in range(3):
-        rc = lib.elemhip_trace_level(rt._h, 8, 0, buf, 8*192); assert rc == 0, rc
+        rc = lib.elemhip_trace_level(rt._h, nout, 0, buf, 8*192); assert rc == 0, rc
     base = min(buf[w*192+1] for w in range(8) if buf[w*192+1])
     for w in range(8):
         o = w*192; nt = buf[o]
