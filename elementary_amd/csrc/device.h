@@ -124,7 +124,13 @@ struct Island {
     uint32_t recOff;               // dword offset (whole blob) of the island's record table: global record index per local index
     uint32_t numRecs;              // Member.rec is a LOCAL index into that table: the records are staged in LDS for the launch
     uint32_t ldsRecs;              // LDS word of the staged records [numRecs][kRecDwords]
+    uint32_t slotArea;             // LDS words of one copy's block buffers: copy d's buffers sit d * slotArea words behind copy 0's
 };
+
+// Task flag bit 6 (recurrence tasks of a pipelined island): the task is the only one of its wave, exports nothing and keeps
+// its whole state in registers, so it renders every block of the launch itself — publish, wait for the next block's inputs,
+// run again — instead of returning to the walk between blocks (island.inc chain_blocks).
+constexpr uint32_t kTaskOwnsWave = 0x40u;
 
 struct ConstCell {
     uint32_t ldsWord;    // destination LDS word

@@ -813,6 +813,23 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 (m0.outLds != kNone || m0.outHbm != kNone))
                 t.flags |= 0x80u;
         }
+        if (copies > 1) {   // recurrence tasks that have a wave to themselves render all blocks of a launch in one go (kTaskOwnsWave)
+            for (uint32_t w = 0; w < kWaves; ++w) {
+                if (I.waveTask[w + 1] - I.waveTask[w] != 1u) continue;
+                Task& t = tasks[I.waveTask[w]];
+                const uint16_t op = t.opcode;
+                const bool plain = op == OP_PHASOR || op == OP_SPHASOR || op == OP_POLE || op == OP_ENV || op == OP_BIQUAD || op == OP_COUNTER ||
+                                   op == OP_ACCUM || op == OP_LATCH || op == OP_MAXHOLD;
+                const bool osc = blepSplit(op) && (t.flags & 1u);            // constant frequency: no per-block pre-pass
+                if (!plain && !osc) continue;
+                bool ok = (t.flags & 0xC0u) == 0u;
+                for (uint32_t k = 0; k < t.count && ok; ++k) {
+                    const Member& m = members[t.first + k];
+                    if (m.outHbm != kNone || m.outLds == kNone || m.nin == kNone || m.nin < leafArity(op)) ok = false;
+                }
+                if (ok) t.flags |= (uint8_t)kTaskOwnsWave;
+            }
+        }
         // a pure sample-parallel island that streams many HBM buffers (a mixer) runs as several
         // workgroups, each rendering a slice of the block
         {
@@ -914,6 +931,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         I.opndOff = I.memOff + (uint32_t)members.size() * 8u;
         I.copyDwords = (I.opndOff + (uint32_t)operands.size() + 3u) & ~3u;
         I.copies = copies;
+        I.slotArea = slotArea;
         I.stateless = statelessIsland ? 1u : 0u;
         I.cellOff = I.copyDwords * copies;
         I.numCells = (uint32_t)cells.size();

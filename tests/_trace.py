@@ -20,10 +20,12 @@ def trace(rt, nout, level=0):
             d0, t0, t1 = buf[o+3*(k+2)], buf[o+3*(k+2)+1], buf[o+3*(k+2)+2]
             print(f"    {names.get(d0 & 0xFFFF, d0 & 0xFFFF):12s} stage {(d0>>16)&0xFF:2d} blk {(d0>>32)&0xFFFF:2d}  [{t0-base:7d} .. {t1-base:7d}]  {t1-t0:6d} clk")
 which = sys.argv[1] if len(sys.argv) > 1 else "voice"
-if which in ("pipe32", "c2pipe"):
+if which in ("pipe32", "c2pipe", "c4pipe", "c1pipe"):
     rt = Runtime(48000.0, 512)
-    nout = 8 if which == "pipe32" else 2
-    assert rt.render(*([graphs.c2_voice(k) for k in range(8)] if which == "pipe32" else graphs.c2_graph()))["result"] == 0
+    nout = {"pipe32": 8, "c2pipe": 2, "c4pipe": 128, "c1pipe": 2}[which]
+    roots = {"pipe32": lambda: [graphs.c2_voice(k) for k in range(8)], "c2pipe": graphs.c2_graph,
+             "c4pipe": lambda: [graphs.c4_instance(k) for k in range(128)], "c1pipe": graphs.c1_graph}[which]()
+    assert rt.render(*roots)["result"] == 0
     rt.process_blocks(8, nout); rt.set_option("time_batch", 32)
     buf = (C.c_ulonglong * (8*192))()
     for _ in range(3):
