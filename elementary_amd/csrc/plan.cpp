@@ -726,10 +726,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             if (freeWaves.empty()) freeWaves.push_back(pickWave());
             std::sort(freeWaves.begin(), freeWaves.end(), [&](int a, int b) { return waveLoad[a] < waveLoad[b]; });
             // Light sample-parallel ops cost mostly per-task overhead. In a pipelined island (blocks overlap, so
-            // there is always other work for the other waves) a stage's ops therefore run unsplit on ONE wave;
-            // stages with a filter-coefficient pre-pass (heavy, and fused with its producers) keep the 4-way split.
-            bool hasCoef = false;
-            for (auto& kv : par) if (kv.first.second == OP_SVF_COEF || kv.first.second == OP_SHELF_COEF) hasCoef = true;
+            // there is always other work for the other waves) a stage's ops therefore run unsplit on ONE wave
+            // unless their cost says otherwise (below).
             std::vector<int> parWaves = freeWaves;
             if (parWaves.size() > 4) parWaves.resize(4);   // a finer split only multiplies per-task overhead
             if (copies > 1) {

@@ -96,6 +96,47 @@ def test_plan_shape_for_the_benchmark_graph():
     assert p["num_hbm_buffers"] == 32 + 256 + 2     # host inputs + voice exports + roots
 
 
+def _op_names():
+    import os, re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "elementary_amd", "csrc", "device.h")).read()
+    body = src[src.index("enum Op : uint16_t {"):src.index("OP_COUNT_")]
+    return {i: t[3:].lower() for i, t in enumerate(re.findall(r"OP_[A-Z0-9_]+", body))}
+
+
+def test_voice_island_schedule():
+    """Planner rules visible in the per-wave task lists of a C2 voice island: the oscillator is two tasks (phase
+    recurrence, then the waveform with its consumers in the next stage), the filter-coefficient pre-pass shares
+    a stage with its producers and is split over two waves, every recurrence has a wave to itself, and no stage
+    order is violated inside a wave."""
+    names = _op_names()
+    rt = dry(graphs.C2_SAMPLE_RATE)
+    assert rt.render(*graphs.c2_graph())["result"] == 0
+    isl = rt.describe_plan()["islands"][0]
+    waves = [[(names[o], st) for o, st in w] for w in isl["waves"]]
+    flat = [t for w in waves for t in w]
+    assert isl["stages"] == 6 and len(flat) == isl["tasks"]
+    stage_of = lambda name: sorted({st for n, st in flat if n == name})
+    assert stage_of("blepsaw") == [0] and stage_of("saw_shape") == [1]
+    (coef_stage,) = stage_of("svf_coef")
+    assert stage_of("svf") == [coef_stage + 1]
+    coef_waves = [w for w in waves if ("svf_coef", coef_stage) in w]
+    assert len(coef_waves) == 2 and all(w[-1][0] == "svf_coef" and len(w) == 3 for w in coef_waves)   # mul, add, coef
+    for rec in ("blepsaw", "phasor", "pole", "svf"):
+        assert [w for w in waves if any(n == rec for n, _ in w)] == [[(rec, stage_of(rec)[0])]], rec
+    for w in waves:
+        assert [st for _, st in w] == sorted(st for _, st in w)
+
+
+def test_small_island_uses_spare_waves():
+    """C1 (one 18-node island): 4 of its 8 waves would idle, so the heavy sample-parallel stage is cut four ways."""
+    names = _op_names()
+    rt = dry(graphs.C1_SAMPLE_RATE)
+    assert rt.render(*graphs.c1_graph())["result"] == 0
+    isl = rt.describe_plan()["islands"][0]
+    coef = [w for w in isl["waves"] if any(names[o] == "svf_coef" for o, _ in w)]
+    assert len(coef) == 4
+
+
 def test_plan_handles_deep_and_wide_graphs():
     x = el.in_({"channel": 0})
     for k in range(300):                             # 300-deep chain -> several islands in sequence
