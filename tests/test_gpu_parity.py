@@ -44,6 +44,33 @@ def test_node_parity(gpu_required, name):
     assert err <= TOL * scale, f"{name}: max abs err {err:.3e} (max |ref| {scale:.3g})"
 
 
+@pytest.mark.parametrize("name", sorted(NODE_CASES))
+def test_node_batched_equals_blockwise(gpu_required, name):
+    """Every node case through multi-block launches (5 blocks per launch, 17 blocks: three full launches and a ragged one)
+    vs the same engine block by block: bit-identical. Small graphs give every recurrence a wave of its own, so this is
+    the coverage of the tasks that render a whole launch without returning to the walk (kTaskOwnsWave)."""
+    import torch
+    from elementary_amd.runtime import Runtime
+    roots_fn, n_in = NODE_CASES[name]
+    nb = 17
+    a, b = Runtime(44100.0, 512), Runtime(44100.0, 512)
+    a.set_option("batch_blocks", 5)
+    for rt in (a, b):
+        for rname, data in node_case_resources().items():
+            assert rt.add_shared_resource(rname, data)
+    roots = roots_fn()
+    n_out = len(roots)
+    assert a.render(*roots)["result"] == 0 and b.render(*roots)["result"] == 0
+    x = np.stack([np.stack([lcg_noise(512, 1 + c + 97 * k, 0.5) for c in range(max(n_in, 1))]) for k in range(nb)])
+    xin = torch.from_numpy(x).cuda()
+    out = torch.zeros((nb, n_out, 512), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    a.process_blocks(nb, n_out, out_ptr=out.data_ptr(), in_ptr=xin.data_ptr(), num_inputs=max(n_in, 1))
+    ref = np.stack([b.process(x[k], n_out, 512) for k in range(nb)])
+    got = out.cpu().numpy()
+    assert np.array_equal(got, ref), f"{name}: max abs diff {np.abs(got - ref).max():.3e}"
+
+
 def test_c1_benchmark_graph(gpu_required):
     hip, chk = _engines()
     a, b = render_pair(hip, chk, graphs.c1_graph, sample_rate=graphs.C1_SAMPLE_RATE, blocks=200)
