@@ -2,11 +2,16 @@
 """bench.py — BASELINE.json's headline metric on its 1-GPU configuration (configs[1], "C2"):
 audio samples/sec for the 4107-node / 256-voice subtractive-synth graph at blockSize 512.
 
-A *step* is one 512-frame block of that graph rendered by the HIP engine through the offline
-entry point (``elemhip_process_blocks``: outputs stay resident in HBM).  With N > 1 GPUs every rank
-renders its own 256-voice shard (weak scaling, independent voices, no data-path collective) and
-the per-rank output buses are sum-reduced to rank 0 over RCCL inside the timed region
-(SURVEY.md §8(e)).  ``value`` = frames rendered by all ranks / max-over-ranks wall time.
+A *step* is one pass of the hot path over one batch: ONE LAUNCH SET = 64 consecutive 512-frame blocks of
+that graph (32 768 output frames) rendered by the HIP engine through the offline entry point
+(``elemhip_process_blocks``: one multi-block kernel launch per island level, outputs resident in HBM).
+``--steps K --warmup W`` therefore renders W + K full launch sets whatever K is, and the roofline
+figures are computed from the K timed steps themselves (wall clock for the headline fraction, HIP
+event pairs recorded inside the timed region for the dominant kernel).  With N > 1 GPUs the voices
+shard over the ranks with no data-path collective; the per-rank output buses are sum-reduced to
+rank 0 over RCCL inside the timed region.  ``--scaling weak`` (default): every rank
+renders its own 256-voice graph, ``value`` = frames of all N graphs / max-over-ranks wall time;
+``--scaling strong``: the ONE 256-voice graph is split over the ranks, ``value`` = its frames / time.
 
 Launch (N > 1):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
                  --master-port P bench.py --gpus N --steps K --warmup W
@@ -99,14 +104,16 @@ def cpu_baseline_multicore(single_ms_per_block: float, target_seconds: float = 8
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4096)
-    ap.add_argument("--warmup", type=int, default=256)
-    ap.add_argument("--chunk", type=int, default=256, help="blocks per elemhip_process_blocks call")
+    ap.add_argument("--steps", type=int, default=64, help="timed steps; one step = one launch set of --batch-blocks blocks")
+    ap.add_argument("--warmup", type=int, default=8, help="untimed steps")
+    ap.add_argument("--batch-blocks", type=int, default=64, help="512-frame blocks per step (= per multi-block launch set)")
+    ap.add_argument("--steps-per-call", type=int, default=16, help="steps per elemhip_process_blocks call")
     ap.add_argument("--graph-blocks", type=int, default=8, help="blocks per captured hipGraph (per-block launch path)")
-    ap.add_argument("--batch-blocks", type=int, default=64, help="blocks per multi-block launch (1 = per-block launches)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--voices", type=int, default=256)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every rank renders --voices voices; strong = the --voices-voice graph is split over the ranks")
     args = ap.parse_args()
 
     import torch
@@ -114,7 +121,7 @@ def main() -> None:
 
     from elementary_amd import graphs
     from elementary_amd.runtime import Runtime
-    from elementary_amd.sharded import reduce_bus
+    from elementary_amd.sharded import reduce_bus, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,30 +134,38 @@ def main() -> None:
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
 
-    # ---- build this rank's shard: voices [256*rank, 256*rank + 256) of a 256*N-voice synth ----
+    # ---- this rank's shard of the synth (independent voices: no data-path collective) ----
+    if args.scaling == "strong":
+        lo, hi = shard_range(args.voices, world, rank)
+        first, my_voices = lo, hi - lo
+        total_voices = args.voices
+    else:
+        first, my_voices = args.voices * rank, args.voices
+        total_voices = args.voices * world
+    B = max(1, min(64, args.batch_blocks))          # blocks per step
     rt = Runtime(graphs.C2_SAMPLE_RATE, BLOCK, device=local)
     rt.set_option("use_graph", 0 if args.no_graph else 1)
     rt.set_option("graph_blocks", args.graph_blocks)
-    rt.set_option("batch_blocks", args.batch_blocks)
+    rt.set_option("batch_blocks", B)
     t0 = time.perf_counter()
-    res = rt.render(*graphs.c2_graph(voices=args.voices, channels=2, first_voice=args.voices * rank))
+    res = rt.render(*graphs.c2_graph(voices=my_voices, channels=2, first_voice=first))
     assert res["result"] == 0, res["result"]
     build_ms = 1e3 * (time.perf_counter() - t0)
 
-    chunk = max(1, min(args.chunk, args.steps))
-    bufs = [torch.zeros((chunk, 2, BLOCK), dtype=torch.float32, device="cuda") for _ in range(2)]
+    spc = max(1, args.steps_per_call)
+    bufs = [torch.zeros((spc * B, 2, BLOCK), dtype=torch.float32, device="cuda") for _ in range(2)]
 
-    def run(blocks: int) -> None:
+    def run(steps: int) -> None:
         done, k, works = 0, 0, []
-        while done < blocks:
-            c = min(chunk, blocks - done)
+        while done < steps:
+            c = min(spc, steps - done)
             buf = bufs[k % 2]
             if world > 1 and len(works) >= 2:
                 works.pop(0).wait()            # the buffer we are about to overwrite has been reduced
                 torch.cuda.current_stream().synchronize()   # the engine renders on its own stream
-            rt.process_blocks(c, 2, out_ptr=buf.data_ptr())
+            rt.process_blocks(c * B, 2, out_ptr=buf.data_ptr())
             if world > 1:
-                works.append(reduce_bus(buf[:c], dst=0, async_op=True))
+                works.append(reduce_bus(buf[:c * B], dst=0, async_op=True))
             done += c
             k += 1
         for w in works:
@@ -160,12 +175,15 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    rt.set_option("profile_launches", 1)            # HIP event pair around every launch of the timed region
     t0 = time.perf_counter()
     run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    prof = rt.launch_profile()
+    rt.set_option("profile_launches", 0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -173,25 +191,30 @@ def main() -> None:
 
     if rank == 0:
         stats = rt.stats()
-        # ---- roofline of the dominant kernel (elemhip_island_kernel), HIP events on the engine's stream ----
-        # One launch of a level renders `batch` blocks (the same launches the timed region issued).
-        rt.set_option("time_batch", args.batch_blocks)
-        lv = rt.time_launches(2, 50)
-        batch = rt.last_time_batch
-        island_ms = sum(lv[:-1])
-        alg_bytes = graphs.c2_algorithmic_bytes(args.voices, 2, BLOCK)
-        achieved = alg_bytes * batch / (island_ms * 1e-3) / 1e9
+        blocks = args.steps * B                      # blocks of THE graph rendered in the timed region (per rank in weak mode)
+        graph_frames = BLOCK * blocks                # output frames of one rank's graph
+        # weak scaling: N independent `--voices`-voice graphs; strong: one graph, its voices split over the ranks
+        value = (world if args.scaling == "weak" else 1) * graph_frames / dt
+        # ---- roofline (SURVEY §8(d) algorithmic bytes; whole timed region AND the dominant kernel by HIP events) ----
+        alg_bytes = graphs.c2_algorithmic_bytes(my_voices, 2, BLOCK)         # per block, this rank
+        us_per_block = 1e6 * dt / blocks
+        achieved = alg_bytes / (us_per_block * 1e-6) / 1e9                    # GB/s over the timed region
+        sets = max(1, prof["launch_sets"])
+        lvl_us = [1e3 * x / sets for x in prof["level_ms"]]                   # mean per launch (one launch = B blocks)
+        dom = max(range(len(lvl_us)), key=lambda i: lvl_us[i]) if lvl_us else 0
+        lvl_alg = graphs.c2_level_algorithmic_bytes(my_voices, 2, BLOCK)     # per block: [voices level, mixer level]
+        dom_alg = lvl_alg[dom] if dom < len(lvl_alg) else alg_bytes
+        dom_achieved = dom_alg * B / (lvl_us[dom] * 1e-6) / 1e9 if lvl_us and lvl_us[dom] > 0 else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("c2_hbm_bytes_per_launch_set") if batch > 1 else tj.get("c2_hbm_bytes_per_block")
+                traffic = json.load(open(tpath)).get("c2_hbm_bytes_per_launch_set")
             except Exception:
                 traffic = None
+        # ---- latency figures outside the timed region ----
         rt.set_option("time_batch", 1)
         lv1 = rt.time_launches(2, 100)
-        # ---- synchronous single-block latency through host buffers (cli/Benchmark.cpp style) ----
         for _ in range(20):
             rt.process(None, 2, BLOCK)
         t1 = time.perf_counter()
@@ -200,47 +223,58 @@ def main() -> None:
         sync_us = 1e6 * (time.perf_counter() - t1) / 200
 
         out = {
-            "metric": "audio samples/sec (48kHz-equiv), 4107-node/256-voice synth graph per GPU, blockSize=512",
-            "value": world * BLOCK * args.steps / dt,
+            "metric": "audio samples/sec (48kHz-equiv), 4107-node/256-voice synth graph, blockSize=512",
+            "value": value,
             "unit": "samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1] (C2): 256-voice subtractive synth, 4107 nodes "
                             "(2 blepsaw, train gate, pole envelope, svf lowpass, tanh per voice; 2 mix adds, 2 roots), "
-                            "sr 48000, blockSize 512, 0 in / 2 out, per GPU",
+                            "sr 48000, blockSize 512, 0 in / 2 out"
+                            + (", per GPU" if args.scaling == "weak" and world > 1 else ""),
+                "step": f"one launch set = {B} consecutive 512-frame blocks of the whole graph ({B * BLOCK} output frames)",
+                "blocks_per_step": B,
+                "frames_per_step": B * BLOCK,
                 "nodes_per_gpu": stats["num_nodes_in_plan"],
-                "voices_per_gpu": args.voices,
+                "voices_per_gpu": my_voices,
+                "voices_total": total_voices,
                 "block_size": BLOCK,
                 "mode": "offline elemhip_process_blocks, output bus resident in HBM"
-                        + (", RCCL sum-reduce of the bus to rank 0 per chunk" if world > 1 else ""),
-                "blocks_per_call": chunk,
-                "blocks_per_launch": batch,
+                        + (", RCCL sum-reduce of the bus to rank 0 per call" if world > 1 else ""),
+                "steps_per_call": spc,
                 "pipelined_blocks_in_flight": rt.describe_plan()["islands"][0]["copies"],
                 "islands": stats["num_islands"], "launch_levels": stats["num_levels"], "max_lds_bytes": stats["max_lds_bytes"],
             },
-            "realtime_factor_48k": world * BLOCK * args.steps / dt / 48000.0,
+            "us_per_block": us_per_block,
+            "realtime_factor_48k": value / 48000.0,
             "plan_build_ms": build_ms,
             "sync_process_us_per_block": sync_us,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": "elemhip_island_kernel", "launches_per_batch": len(lv) - 1, "blocks_per_launch": batch,
-                "kernel_us_per_launch": [1e3 * x for x in lv[:-1]], "epilogue_us": 1e3 * lv[-1],
-                "kernel_us_per_block": [1e3 * x / batch for x in lv[:-1]],
-                "event_pair_overhead_us_subtracted": 1e3 * rt.last_event_overhead_ms,
-                "algorithmic_bytes_per_block": alg_bytes, "algorithmic_bytes_per_launch_set": alg_bytes * batch,
+                "basis": "timed region: algorithmic bytes per block x blocks / wall time of the K timed steps",
+                "algorithmic_bytes_per_block": alg_bytes, "algorithmic_bytes_per_step": alg_bytes * B,
+                "dominant_kernel": {
+                    "kernel": "elemhip_island_kernel", "level": dom, "blocks_per_launch": B,
+                    "us_per_launch": lvl_us[dom] if lvl_us else None,
+                    "algorithmic_bytes_per_launch": dom_alg * B,
+                    "achieved": dom_achieved, "frac": (dom_achieved / HBM_PEAK_GBPS) if dom_achieved else None,
+                    "timing": "HIP event pairs on the engine's stream around every launch of the timed region",
+                },
+                "launch_us_per_step": lvl_us, "epilogue_us_per_step": 1e3 * prof["epilogue_ms"] / sets,
+                "launch_sets_profiled": prof["launch_sets"],
+                "kernel_time_fraction_of_step": (sum(lvl_us) + 1e3 * prof["epilogue_ms"] / sets) / (1e3 * 1e3 * dt / args.steps) if lvl_us else None,
                 "single_block_launch_us": [1e3 * x for x in lv1],
-                "note": "achieved = SURVEY §8(d) algorithmic bytes of the blocks one launch set renders / summed HIP-event "
-                        "duration of that set's island-kernel launches (one per level); `traffic` = PMC HBM bytes of the same "
-                        "launch set; buffers inside an island live in LDS and never reach HBM",
+                "note": "`traffic` = PMC HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md) of one launch set; buffers "
+                        "inside an island live in LDS and never reach HBM, so traffic sits far below the algorithmic bytes",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

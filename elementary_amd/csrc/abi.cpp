@@ -1,6 +1,7 @@
 // abi.cpp — the extern "C" surface declared in include/elemhip.h.
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -11,7 +12,14 @@
 using elemhip::Engine;
 using elemhip::Value;
 
-struct elemhip_s { Engine engine; elemhip_s(double sr, int bs, int dev) : engine(sr, bs, dev) {} };
+struct elemhip_s {
+    Engine engine;
+    // typed path: root ids staged by elemhip_activate_roots until the next elemhip_commit of THIS handle (any thread)
+    std::mutex stagedMu;
+    std::vector<int32_t> stagedRoots;
+    bool haveStaged = false;
+    elemhip_s(double sr, int bs, int dev) : engine(sr, bs, dev) {}
+};
 
 static std::atomic<int> g_lastCreateError{0};
 
@@ -69,27 +77,30 @@ int elemhip_set_property_json(elemhip_t* h, int32_t id, const char* key, const c
 }
 
 // ACTIVATE_ROOTS and COMMIT_UPDATES only rebuild when they share a batch (Runtime.h:172,199-205),
-// so the typed path keeps the pair together: activate stages the ids, commit sends [4,...],[5].
-static thread_local std::vector<int32_t> t_stagedRoots;
-static thread_local bool t_haveStaged = false;
-
+// so the typed path keeps the pair together: activate validates and stages the ids in the handle,
+// commit sends [4,...],[5].
 int elemhip_activate_roots(elemhip_t* h, const int32_t* ids, size_t n) {
     if (!h || (!ids && n)) return elemhip::kInvalidInstructionFormat;
-    t_stagedRoots.assign(ids, ids + n);
-    t_haveStaged = true;
+    for (size_t i = 0; i < n; ++i) if (!h->engine.hasNode(ids[i])) return elemhip::kNodeNotFound;   // Runtime.h:386-390
+    std::lock_guard<std::mutex> lock(h->stagedMu);
+    h->stagedRoots.assign(ids, ids + n);
+    h->haveStaged = true;
     return elemhip::kOk;
 }
 
 int elemhip_commit(elemhip_t* h) {
     if (!h) return elemhip::kInvalidInstructionFormat;
     Value batch; batch.type = Value::Array;
-    if (t_haveStaged) {
-        Value roots; roots.type = Value::Array;
-        for (int32_t id : t_stagedRoots) roots.arr.push_back(Value::number(id));
-        Value a; a.type = Value::Array;
-        a.arr = {Value::number(4), roots};
-        batch.arr.push_back(std::move(a));
-        t_haveStaged = false;
+    {
+        std::lock_guard<std::mutex> lock(h->stagedMu);
+        if (h->haveStaged) {
+            Value roots; roots.type = Value::Array;
+            for (int32_t id : h->stagedRoots) roots.arr.push_back(Value::number(id));
+            Value a; a.type = Value::Array;
+            a.arr = {Value::number(4), roots};
+            batch.arr.push_back(std::move(a));
+            h->haveStaged = false;
+        }
     }
     Value c; c.type = Value::Array; c.arr = {Value::number(5)};
     batch.arr.push_back(std::move(c));
@@ -113,6 +124,7 @@ int elemhip_add_shared_resource(elemhip_t* h, const char* name, const float* con
 
 void elemhip_prune_shared_resources(elemhip_t* h) { if (h) h->engine.pruneSharedResources(); }
 size_t elemhip_gc(elemhip_t* h, int32_t* out, size_t cap) { return h ? h->engine.gc(out, cap) : 0; }
+size_t elemhip_last_gc(elemhip_t* h, int32_t* out, size_t cap) { return h ? h->engine.lastGc(out, cap) : 0; }
 void elemhip_reset(elemhip_t* h) { if (h) h->engine.reset(); }
 const char* elemhip_describe(int code) { return elemhip::describe(code); }
 
@@ -135,6 +147,11 @@ int elemhip_get_stats(elemhip_t* h, elemhip_stats* out) {
 int elemhip_time_launches(elemhip_t* h, size_t nOut, size_t numBlocks, float* msOut, size_t cap) {
     if (!h || !msOut) return -elemhip::kInvalidInstructionFormat;
     return h->engine.timeLaunches(nOut, numBlocks, msOut, cap);
+}
+
+int elemhip_get_launch_profile(elemhip_t* h, double* msOut, size_t cap, uint64_t* launchSets, uint64_t* blocks) {
+    if (!h || !msOut) return -elemhip::kInvalidInstructionFormat;
+    return h->engine.launchProfile(msOut, cap, launchSets, blocks);
 }
 
 int elemhip_trace_level(elemhip_t* h, size_t nOut, uint32_t level, unsigned long long* out, size_t cap) {

@@ -103,7 +103,8 @@ Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), devi
 
     recCapacity = 8192;
     if (hipMalloc(&dRecs, (size_t)recCapacity * kRecDwords * 4) != hipSuccess) { fail(kHipError); return; }
-    (void)hipMemset(dRecs, 0, (size_t)recCapacity * kRecDwords * 4);
+    (void)hipMemsetAsync(dRecs, 0, (size_t)recCapacity * kRecDwords * 4, stream);
+    (void)hipStreamSynchronize(stream);
     shadow.reserve((size_t)recCapacity * kRecDwords);
 
     patchCap = 1u << 16;
@@ -158,6 +159,7 @@ Engine::~Engine() {
     if (dLcg) (void)hipFree(dLcg);
     if (dHbm) (void)hipFree(dHbm);
     if (dOutRing) (void)hipFree(dOutRing);
+    for (hipEvent_t e : profEvents) (void)hipEventDestroy(e);
     if (hPatches) (void)hipHostFree(hPatches);
     if (hOut) (void)hipHostFree(hOut);
     if (hIn) (void)hipHostFree(hIn);
@@ -186,7 +188,7 @@ int Engine::ensureHbm(size_t buffers) {
     // + slack: vector loads of a 64*V-frame task may read (never write) past a short block's buffer
     const size_t floats = want * blockSize + 1024;
     HIP_OK(hipMalloc(&nb, floats * sizeof(float)));
-    HIP_OK(hipMemset(nb, 0, floats * sizeof(float)));
+    HIP_OK(hipMemsetAsync(nb, 0, floats * sizeof(float), stream));   // ordered with the kernels: they run on `stream` (non-blocking w.r.t. the null stream)
     if (dHbm) deferredFree.push_back(dHbm);
     dHbm = nb; hbmBuffers = want;
     if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
@@ -197,7 +199,7 @@ int Engine::ensureOutRing(size_t floats) {
     if (floats <= outRingFloats) return kOk;
     float* nb = nullptr;
     HIP_OK(hipMalloc(&nb, floats * sizeof(float)));
-    HIP_OK(hipMemset(nb, 0, floats * sizeof(float)));
+    HIP_OK(hipMemsetAsync(nb, 0, floats * sizeof(float), stream));
     if (dOutRing) deferredFree.push_back(dOutRing);
     dOutRing = nb; outRingFloats = floats;
     if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
@@ -240,7 +242,8 @@ int Engine::allocRing(Node& n, size_t floats) {
         return kOk;
     }
     HIP_OK(hipMalloc(&p, bytes));
-    HIP_OK(hipMemset(p, 0, bytes));
+    HIP_OK(hipMemsetAsync(p, 0, bytes, stream));
+    HIP_OK(hipStreamSynchronize(stream));   // callers follow up with blocking hipMemcpy's into the buffer
     if (n.ring.ptr) deferredFree.push_back(n.ring.ptr);
     n.ring.ptr = p; n.ring.bytes = bytes;
     return kOk;
@@ -305,7 +308,8 @@ int Engine::ensureResourceOnDevice(const ResourcePtr& r) {
     void* p = nullptr;
     if (dry) { r->dev.ptr = std::calloc(floats, sizeof(float)); r->dev.bytes = floats * sizeof(float); return kOk; }
     HIP_OK(hipMalloc(&p, floats * sizeof(float)));
-    HIP_OK(hipMemset(p, 0, floats * sizeof(float)));
+    HIP_OK(hipMemsetAsync(p, 0, floats * sizeof(float), stream));
+    HIP_OK(hipStreamSynchronize(stream));
     if (have) HIP_OK(hipMemcpy(p, r->channels[0].data(), have * sizeof(float), hipMemcpyHostToDevice));
     r->dev.ptr = p; r->dev.bytes = floats * sizeof(float);
     return kOk;
@@ -683,7 +687,9 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
     return kOk;
 }
 
-int Engine::activateRoots(const std::vector<int32_t>& ids) {   // Runtime.h:368-433
+// `malformedTail`: the id list was cut at a non-number entry. Like the reference (Runtime.h:375-380) the roots in front
+// of it have been activated by then, and the call fails before anything is deactivated or swapped.
+int Engine::activateRoots(const std::vector<int32_t>& ids, bool malformedTail) {   // Runtime.h:368-433
     std::set<int32_t> active;
     for (int32_t id : ids) {
         auto it = nodes.find(id);
@@ -693,6 +699,7 @@ int Engine::activateRoots(const std::vector<int32_t>& ids) {   // Runtime.h:368-
             active.insert(id);
         }
     }
+    if (malformedTail) return kInvalidInstructionFormat;
     for (int32_t id : currentRoots) {
         auto it = nodes.find(id);
         if (it == nodes.end() || it->second.op != OP_ROOT) continue;
@@ -708,11 +715,14 @@ int Engine::activateRoots(const std::vector<int32_t>& ids) {   // Runtime.h:368-
 }
 
 int Engine::commit() {   // Runtime.h:202-206
-    if (shouldRebuild || (planStale && (current || pending))) {
+    if (shouldRebuild || rebuildOwed || (planStale && (current || pending))) {
         planStale = false;
         auto t0 = std::chrono::steady_clock::now();
         auto p = buildPlan();
-        if (!p) return kUnsupportedGraph;
+        // (not a reference code path: its buildRenderSequence cannot fail. The roots stay swapped as in the reference;
+        // the rebuild stays owed so that the next commit retries instead of rendering the old sequence forever.)
+        if (!p) { rebuildOwed = true; return kUnsupportedGraph; }
+        rebuildOwed = false;
         pending = p;
         shouldRebuild = false;
         st.plansBuilt++;
@@ -753,8 +763,7 @@ int Engine::apply(const Value& batch) {   // Runtime.h:170-218
                 bool bad = false;
                 for (const Value& v : arg(1).arr) { if (!v.isNumber()) { bad = true; break; } ids.push_back((int32_t)v.num); }
                 // the reference activates the roots preceding a malformed id before failing
-                res = activateRoots(ids);
-                if (res == kOk && bad) res = kInvalidInstructionFormat;
+                res = activateRoots(ids, bad);
                 shouldRebuild = true;
                 break;
             }
@@ -864,7 +873,20 @@ size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
     std::sort(pruned.begin(), pruned.end());
     size_t k = 0;
     for (int32_t id : pruned) { if (out && k < cap) out[k] = id; ++k; }
+    lastPruned.swap(pruned);
     return k;
+}
+
+size_t Engine::lastGc(int32_t* out, size_t cap) {
+    std::lock_guard<std::mutex> lock(mu);
+    size_t k = 0;
+    for (int32_t id : lastPruned) { if (out && k < cap) out[k] = id; ++k; }
+    return k;
+}
+
+bool Engine::hasNode(int32_t id) {
+    std::lock_guard<std::mutex> lock(mu);
+    return nodes.find(id) != nodes.end();
 }
 
 void Engine::reset() {}   // Runtime.h:448-458: only SampleNode (out of scope) reacts to reset()
@@ -894,24 +916,30 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
     if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(64, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
     if (key == "pipeline_copies") { pipelineCopies = std::max(1, std::min(6, (int)value)); planStale = true; return kOk; }   // next commit re-plans
+    if (key == "profile_launches") {
+        profileLaunches = value != 0.0;
+        if (profileLaunches) { profMs.clear(); profSets = 0; profBlocks = 0; }
+        return kOk;
+    }
     if (key == "time_batch") { timeBatch = std::max(1, std::min(64, (int)value)); return kOk; }
     if (key == "graph_blocks") { graphBlocks = std::max(1, (int)value); if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; } return kOk; }
     return kInvalidPropertyValue;
 }
 
 // ---- block rendering ----------------------------------------------------------------------------------
-void Engine::flushPending() {
+int Engine::flushPending() {
     if (nextRec > recCapacity) {   // grow the record arena (device idle: we hold `mu` and sync every call)
         uint32_t cap = recCapacity;
         while (cap < nextRec) cap *= 2;
         uint32_t* nr = nullptr;
-        if (hipMalloc(&nr, (size_t)cap * kRecDwords * 4) == hipSuccess) {
-            (void)hipMemset(nr, 0, (size_t)cap * kRecDwords * 4);
-            (void)hipMemcpy(nr, dRecs, (size_t)recCapacity * kRecDwords * 4, hipMemcpyDeviceToDevice);
-            (void)hipFree(dRecs);
-            dRecs = nr; recCapacity = cap;
-            if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
-        }
+        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipMalloc(&nr, (size_t)cap * kRecDwords * 4));
+        HIP_OK(hipMemsetAsync(nr, 0, (size_t)cap * kRecDwords * 4, stream));
+        HIP_OK(hipMemcpyAsync(nr, dRecs, (size_t)recCapacity * kRecDwords * 4, hipMemcpyDeviceToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        (void)hipFree(dRecs);
+        dRecs = nr; recCapacity = cap;
+        if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
     }
     if (!freshRecs.empty()) {
         std::sort(freshRecs.begin(), freshRecs.end());
@@ -941,6 +969,7 @@ void Engine::flushPending() {
         off += cnt;
     }
     patches.clear();
+    return kOk;
 }
 
 int Engine::setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime) {
@@ -1050,7 +1079,8 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
         }
         HIP_OK(hipMemcpyAsync(dHbm, hIn, floats * sizeof(float), hipMemcpyHostToDevice, stream));
     }
-    flushPending();
+    rc = flushPending();
+    if (rc != kOk) return rc;
     enqueueBlock(p);
     if (nOut > 0) {
         const size_t floats = nOut * (size_t)blockSize;
@@ -1090,7 +1120,8 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
     }
     setGlobalsFor(0, nOut, (size_t)blockSize, hGlobals.sampleTime);
     setInRing(nullptr, 0);
-    flushPending();
+    rc = flushPending();
+    if (rc != kOk) return -rc;
     std::vector<hipEvent_t> ev(2 * (L + 2));   // + one empty pair: the cost of the event pair itself
     for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -kHipError;
     std::vector<double> acc(L + 2, 0.0);
@@ -1153,7 +1184,8 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
     }
     setGlobalsFor(0, nOut, (size_t)blockSize, hGlobals.sampleTime);
     setInRing(nullptr, 0);
-    flushPending();
+    rc = flushPending();
+    if (rc != kOk) return rc;
     const uint64_t tp = (uint64_t)reinterpret_cast<uintptr_t>(dTrace);
     const uint32_t batch = (timeBatch > 1 && batchEligible(p, nOut)) ? (uint32_t)timeBatch : 1u;
     const uint32_t arenaFloats = batch > 1 ? p.numHbmBuffers * (uint32_t)blockSize : 0u;
@@ -1196,14 +1228,46 @@ bool Engine::batchEligible(const Plan& p, size_t nOut) const {
     return true;
 }
 
+hipEvent_t Engine::profEvent() {
+    if (profUsed == profEvents.size()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); profEvents.push_back(e); }
+    return profEvents[profUsed++];
+}
+
+// after a stream synchronize: fold the event pairs of this call into the per-level sums
+void Engine::profCollect() {
+    for (size_t k = 0; k + 1 < profUsed; k += 2) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, profEvents[k], profEvents[k + 1]) != hipSuccess) continue;
+        const uint32_t slot = profSlots[k / 2];
+        if (profMs.size() <= slot) profMs.resize(slot + 1, 0.0);
+        profMs[slot] += ms;
+    }
+    profUsed = 0; profSlots.clear();
+}
+
+int Engine::launchProfile(double* msOut, size_t cap, uint64_t* launchSets, uint64_t* blocks) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (launchSets) *launchSets = profSets;
+    if (blocks) *blocks = profBlocks;
+    const size_t n = std::min(cap, profMs.size());
+    for (size_t i = 0; i < n; ++i) msOut[i] = profMs[i];
+    return (int)profMs.size();
+}
+
 void Engine::enqueueBatch(const Plan& p, uint32_t batch) {
     const uint32_t arenaFloats = p.numHbmBuffers * (uint32_t)blockSize;
     const size_t L = p.levelOffsets.size() - 1;
+    const bool prof = profileLaunches;
     for (size_t l = 0; l < L; ++l) {
         const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
-        if (e > b) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats);
+        if (e <= b) continue;
+        if (prof) (void)hipEventRecord(profEvent(), stream);
+        launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats);
+        if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)l); }
     }
+    if (prof) (void)hipEventRecord(profEvent(), stream);
     launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, dOutRing, batch, arenaFloats);
+    if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)L); profSets++; profBlocks += batch; }
 }
 
 int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime) {
@@ -1237,7 +1301,8 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             if (haveIn)   // host inputs of block b -> arena buffers 0..nIn-1 of block b's arena
                 HIP_OK(hipMemcpy2DAsync(dHbm, (size_t)p.numHbmBuffers * bs * sizeof(float), inDev + done * nIn * bs, nIn * bs * sizeof(float),
                                         nIn * bs * sizeof(float), chunk, hipMemcpyDeviceToDevice, stream));
-            flushPending();
+            rc = flushPending();
+            if (rc != kOk) return rc;
             enqueueBatch(p, (uint32_t)chunk);
             if (outDev && nOut > 0)
                 HIP_OK(hipMemcpyAsync(outDev + done * nOut * bs, dOutRing, chunk * nOut * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -1257,7 +1322,8 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
         // host inputs: block 0 of the chunk is copied here, the epilogue of block k stages block k + 1
         setInRing(haveIn ? inDev + done * nIn * bs : nullptr, haveIn ? (uint32_t)chunk : 0u);
         if (haveIn) HIP_OK(hipMemcpyAsync(dHbm, inDev + done * nIn * bs, nIn * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        flushPending();
+        rc = flushPending();
+        if (rc != kOk) return rc;
         if (graphOk && chunk == G) {
             if (!p.graphExec || p.graphBlocks != (int)G) {
                 if (p.graphExec) { (void)hipGraphExecDestroy(p.graphExec); p.graphExec = nullptr; }
@@ -1287,6 +1353,7 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
     }
     HIP_OK(hipStreamSynchronize(stream));
     HIP_OK(hipGetLastError());
+    if (profUsed) profCollect();
     freeDeferred();
     return kOk;
 }

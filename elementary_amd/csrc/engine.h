@@ -89,7 +89,7 @@ public:
     int createNode(int32_t id, const std::string& type);
     int appendChild(int32_t parent, int32_t child, int32_t channel);
     int setProperty(int32_t id, const std::string& key, const Value& v);
-    int activateRoots(const std::vector<int32_t>& ids);
+    int activateRoots(const std::vector<int32_t>& ids, bool malformedTail = false);
     int commit();
 
     // one block, host buffers (Runtime::process)
@@ -106,6 +106,8 @@ public:
     bool addSharedResource(const std::string& name, const float* const* ch, size_t nCh, size_t nSamples);
     void pruneSharedResources();
     size_t gc(int32_t* out, size_t cap);
+    size_t lastGc(int32_t* out, size_t cap);          // the ids the most recent gc() pruned (ascending)
+    bool hasNode(int32_t id);
     void reset();
     // Runtime::processQueuedEvents (Runtime.h:64, 437-446): relays the newest meter / snapshot readout of every such node
     // of the current render sequence whose root is active. cb(type, json payload, user).
@@ -116,6 +118,9 @@ public:
     std::string describePlan();
     int setOption(const std::string& key, double value);
     uint32_t lastTimedBatch() const { return lastTimeBatch; }
+    // option "profile_launches": HIP event pairs around every multi-block launch of processBlocks (same stream, inside
+    // whatever region the caller times). msOut[l] = summed ms of level l, msOut[levels] = epilogue; launchSets = sets timed.
+    int launchProfile(double* msOut, size_t cap, uint64_t* launchSets, uint64_t* blocks);
 
 private:
     friend struct PlanBuilder;
@@ -133,6 +138,8 @@ private:
     std::set<int32_t> currentRoots;
     std::unordered_map<std::string, ResourcePtr> resources;
     bool shouldRebuild = false;
+    bool rebuildOwed = false;              // a commit failed to build its plan: the next commit retries even without ACTIVATE_ROOTS
+    std::vector<int32_t> lastPruned;
     bool planStale = false;                // a property changed the launch shape of the plan (convolve IR length)
 
     // record arena
@@ -167,6 +174,14 @@ private:
     int  batchBlocks = 64;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)
     int  pipelineCopies = 6;               // blocks a stateful island keeps in flight inside a multi-block launch
     int  timeBatch = 1;
+    bool profileLaunches = false;
+    std::vector<double> profMs;            // per level + epilogue, summed over the launch sets profiled so far
+    uint64_t profSets = 0, profBlocks = 0;
+    std::vector<hipEvent_t> profEvents;    // event pool of the current processBlocks call
+    size_t profUsed = 0;
+    std::vector<uint32_t> profSlots;       // per used pair: which profMs slot it feeds
+    hipEvent_t profEvent();
+    void profCollect();
     uint32_t lastTimeBatch = 1;            // blocks per launch the last timeLaunches actually used                    // timeLaunches: blocks per timed launch
 
     uint32_t allocRec();
@@ -178,7 +193,7 @@ private:
     int  setConvolverIr(Node& n, const ResourcePtr& res);
     ResourcePtr tapResource(const std::string& name);
     void rootUpdateStep(Node& n);
-    void flushPending();                   // fresh records + patches -> device (stream-ordered)
+    int  flushPending();                   // fresh records + patches -> device (stream-ordered)
     void freeDeferred();
     int  ensureHbm(size_t buffers);
     int  ensureOutRing(size_t floats);

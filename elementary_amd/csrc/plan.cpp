@@ -1068,9 +1068,10 @@ namespace elemhip {
 // JSON description of the render plan (islands, levels, tasks) for host-logic tests and debugging.
 std::string Engine::describePlan() {
     std::lock_guard<std::mutex> lock(mu);
-    if (pending) { current = pending; pending.reset(); }
-    if (!current) return "null";
-    const Plan& p = *current;
+    // the newest plan (pending if a commit has not been rendered yet); nothing is adopted here
+    const std::shared_ptr<Plan> shown = pending ? pending : current;
+    if (!shown) return "null";
+    const Plan& p = *shown;
     std::string s = "{";
     auto kv = [&](const char* k, uint64_t v, bool comma = true) { s += "\"" + std::string(k) + "\":" + std::to_string(v) + (comma ? "," : ""); };
     kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.numTasks);

@@ -63,6 +63,12 @@ def c2_algorithmic_bytes(voices: int = 256, channels: int = 2, block: int = 512)
     return (voices * per_voice + mix) * block * 4 + channels * block * 4
 
 
+def c2_level_algorithmic_bytes(voices: int = 256, channels: int = 2, block: int = 512):
+    """The same figure split by launch level: [voice islands, mixers + roots] (the bus RMW belongs to the epilogue)."""
+    mix = channels * (voices // channels + 1) + channels * 2 + 7
+    return [voices * 39 * block * 4, mix * block * 4]
+
+
 # ---- C4: independent offline-render instances (mixed filter + delay chains), 16 nodes each ----
 C4_SAMPLE_RATE = 48000.0
 

@@ -268,6 +268,9 @@ class Renderer:
         render_with_delegate(self._delegate, [resolve(r) for r in roots], root_fade_in_ms, root_fade_out_ms)
         batch = self._delegate.packed()
         result = self._send(batch)
+        if result != 0:
+            # the engine stopped somewhere inside the batch: force ACTIVATE_ROOTS (and with it a rebuild) into the next render
+            self._delegate.current_active_roots = set()
         return {
             "result": result,
             "nodesAdded": self._delegate.nodes_added,

@@ -111,6 +111,20 @@ class Runtime(CRuntime):
         self.sample_time += int(num_blocks) * self.block_size * self.last_time_batch
         return [float(buf[i]) for i in range(k)]
 
+    def launch_profile(self):
+        """Per-launch-level HIP-event time of the multi-block launches issued since ``set_option('profile_launches', 1)``:
+        ``{'level_ms': [...], 'epilogue_ms': x, 'launch_sets': n, 'blocks': b}`` (sums over the profiled launch sets)."""
+        buf = (C.c_double * 64)()
+        sets, blocks = C.c_uint64(0), C.c_uint64(0)
+        f = self._lib.elemhip_get_launch_profile
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        f.restype = C.c_int
+        k = f(self._h, buf, 64, C.byref(sets), C.byref(blocks))
+        if k <= 0:
+            return {"level_ms": [], "epilogue_ms": 0.0, "launch_sets": int(sets.value), "blocks": int(blocks.value)}
+        vals = [float(buf[i]) for i in range(k)]
+        return {"level_ms": vals[:-1], "epilogue_ms": vals[-1], "launch_sets": int(sets.value), "blocks": int(blocks.value)}
+
     def describe_plan(self) -> Dict[str, Any]:
         import json
         buf = C.create_string_buffer(1 << 20)

@@ -72,8 +72,11 @@ int elemhip_process_blocks(elemhip_t*, const float* in_dev, size_t nIn, float* o
 int    elemhip_add_shared_resource(elemhip_t*, const char* name, const float* const* channels, size_t nCh, size_t nSamples);
 /* void pruneSharedResources()                                    Runtime.h:89,467-471 */
 void   elemhip_prune_shared_resources(elemhip_t*);
-/* std::set<NodeId> gc()                                          Runtime.h:76,220-272; returns the count */
+/* std::set<NodeId> gc()                                          Runtime.h:76,220-272
+ * Prunes every unreferenced node and returns how many; the first min(count, cap) ids (ascending) land in prunedOut.
+ * When count > cap the full set of THAT pass can still be read with elemhip_last_gc (same ordering). */
 size_t elemhip_gc(elemhip_t*, int32_t* prunedOut, size_t cap);
+size_t elemhip_last_gc(elemhip_t*, int32_t* prunedOut, size_t cap);
 /* void reset()                                                   Runtime.h:70,448-458 */
 void   elemhip_reset(elemhip_t*);
 
@@ -84,6 +87,11 @@ int  elemhip_get_stats(elemhip_t*, elemhip_stats* out);
  * kernel launch on the engine's stream. msOut[l] = mean ms of launch level l, msOut[levels] = the
  * epilogue kernel. Returns the number of entries written (levels + 1) or a negated error code. */
 int  elemhip_time_launches(elemhip_t*, size_t nOut, size_t numBlocks, float* msOut, size_t cap);
+/* Measurement hook for timed regions: after elemhip_set_option("profile_launches", 1) every multi-block launch that
+ * elemhip_process_blocks issues is bracketed by a HIP event pair on the engine's stream. msOut[l] = summed ms of launch
+ * level l, msOut[levels] = the epilogue kernel; *launchSets / *blocks = launch sets and blocks covered. Returns the number
+ * of entries available (levels + 1). Setting the option to 1 again clears the sums. */
+int  elemhip_get_launch_profile(elemhip_t*, double* msOut, size_t cap, uint64_t* launchSets, uint64_t* blocks);
 /* Tracing hook: render one block while workgroup 0 of launch level `level` logs shader-clock
  * timestamps per task. out[wave*192 + 0..3] = {tasks, kernel start, prologue end, kernel end};
  * out[wave*192 + 3*(k+2) + 0..2] = {opcode | stage<<16 | flags<<24, start, end} for the wave's k-th task. */

@@ -1,3 +1,4 @@
+import os as _os, sys as _sys; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))); _sys.path[:0] = [_R, _os.path.join(_R, 'tests')]
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')

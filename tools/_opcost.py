@@ -1,4 +1,6 @@
 """Per-op latency probe: 64 independent single-op islands, HIP-event kernel time."""
+import os as _os, sys as _sys; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))); _sys.path[:0] = [_R, _os.path.join(_R, 'tests')]
+
 import sys
 sys.path.insert(0, '.')
 from elementary_amd import el, graphs

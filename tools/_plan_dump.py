@@ -1,4 +1,6 @@
 """dev tool: per-wave task lists of the first island of a graph's plan (dry handle, no GPU)."""
+import os as _os, sys as _sys; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))); _sys.path[:0] = [_R, _os.path.join(_R, 'tests')]
+
 import os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from elementary_amd.runtime import Runtime
