@@ -112,6 +112,8 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--voices", type=int, default=256)
+    ap.add_argument("--specialize", type=int, default=2, choices=[0, 1, 2],
+                    help="0: interpreter island kernels only; 2: per-island-shape kernels compiled at plan build (kcache/ on disk)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every rank renders --voices voices; strong = the --voices-voice graph is split over the ranks")
     args = ap.parse_args()
@@ -147,6 +149,7 @@ def main() -> None:
     rt.set_option("use_graph", 0 if args.no_graph else 1)
     rt.set_option("graph_blocks", args.graph_blocks)
     rt.set_option("batch_blocks", B)
+    rt.set_option("specialize", args.specialize)
     t0 = time.perf_counter()
     res = rt.render(*graphs.c2_graph(voices=my_voices, channels=2, first_voice=first))
     assert res["result"] == 0, res["result"]
@@ -252,6 +255,10 @@ def main() -> None:
                 "steps_per_call": spc,
                 "pipelined_blocks_in_flight": rt.describe_plan()["islands"][0]["copies"],
                 "islands": stats["num_islands"], "launch_levels": stats["num_levels"], "max_lds_bytes": stats["max_lds_bytes"],
+                "island_kernels": ("run-time specialised per island shape (hiprtc, gfx950): %d shape(s) covering %d islands, %d launches; "
+                                   "compile wait %.0f ms inside plan_build_ms (0 = on-disk cache hit)"
+                                   % (stats["spec_shapes"], stats["spec_islands"], stats["spec_launches"], stats["last_jit_wait_ms"]))
+                                  if args.specialize and stats["spec_launches"] else "ahead-of-time interpreter kernel",
             },
             "us_per_block": us_per_block,
             "realtime_factor_48k": value / 48000.0,
@@ -263,7 +270,7 @@ def main() -> None:
                 "basis": "timed region: algorithmic bytes per block x blocks / wall time of the K timed steps",
                 "algorithmic_bytes_per_block": alg_bytes, "algorithmic_bytes_per_step": alg_bytes * B,
                 "dominant_kernel": {
-                    "kernel": "elemhip_island_kernel", "level": dom, "blocks_per_launch": B,
+                    "kernel": "elemhip_spec_island" if (args.specialize and stats["spec_launches"]) else "elemhip_island_kernel", "level": dom, "blocks_per_launch": B,
                     "us_per_launch": lvl_us[dom] if lvl_us else None,
                     "algorithmic_bytes_per_launch": dom_alg * B,
                     "achieved": dom_achieved, "frac": (dom_achieved / HBM_PEAK_GBPS) if dom_achieved else None,

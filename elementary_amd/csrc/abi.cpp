@@ -128,6 +128,20 @@ size_t elemhip_last_gc(elemhip_t* h, int32_t* out, size_t cap) { return h ? h->e
 void elemhip_reset(elemhip_t* h) { if (h) h->engine.reset(); }
 const char* elemhip_describe(int code) { return elemhip::describe(code); }
 
+int elemhip_register_node_type(elemhip_t* h, const char* type, const elemhip_node_type* vt) {
+    if (!h || !type || !vt) return elemhip::kInvalidInstructionFormat;
+    elemhip::HostVTable t;
+    t.create = vt->create; t.destroy = vt->destroy; t.setProperty = vt->set_property; t.process = vt->process; t.reset = vt->reset; t.user = vt->user;
+    return h->engine.registerNodeType(type, t);
+}
+
+static size_t copyOut(const std::string& s, char* buf, size_t cap) {
+    if (buf && cap) { const size_t n = s.size() < cap - 1 ? s.size() : cap - 1; std::memcpy(buf, s.data(), n); buf[n] = 0; }
+    return s.size() + 1;
+}
+size_t elemhip_snapshot_json(elemhip_t* h, char* buf, size_t cap) { return h ? copyOut(h->engine.snapshotJson(), buf, cap) : 0; }
+size_t elemhip_shared_resource_keys_json(elemhip_t* h, char* buf, size_t cap) { return h ? copyOut(h->engine.sharedResourceKeysJson(), buf, cap) : 0; }
+
 int elemhip_process_queued_events(elemhip_t* h, elemhip_event_cb cb, void* user) {
     if (!h) return elemhip::kInvalidInstructionFormat;
     return h->engine.processQueuedEvents(cb, user);
@@ -141,6 +155,8 @@ int elemhip_get_stats(elemhip_t* h, elemhip_stats* out) {
     out->num_nodes_in_plan = s.numNodesInPlan; out->max_lds_bytes = s.maxLdsBytes; out->num_hbm_buffers = s.numHbmBuffers;
     out->graph_replays = s.graphReplays; out->graph_captures = s.graphCaptures;
     out->batch_launches = s.batchLaunches;
+    out->spec_launches = s.specLaunches; out->spec_shapes = s.specShapes; out->spec_islands = s.specIslands;
+    out->last_jit_wait_ms = s.lastJitWaitMs;
     return elemhip::kOk;
 }
 
@@ -165,6 +181,17 @@ size_t elemhip_describe_plan(elemhip_t* h, char* buf, size_t cap) {
     const std::string s = h->engine.describePlan();
     if (buf && cap) { const size_t n = s.size() < cap - 1 ? s.size() : cap - 1; std::memcpy(buf, s.data(), n); buf[n] = 0; }
     return s.size() + 1;
+}
+
+// Debug/test hook: the k-th specialised island shape of the newest plan. Returns the number of shapes (or -1);
+// *state = 0 compiling, 1 ready, -1 failed; the program text / compiler log are copied when buffers are given.
+int elemhip_spec_info(elemhip_t* h, size_t k, char* src, size_t srcCap, char* log, size_t logCap, int* state, uint32_t* islands) {
+    if (!h) return -1;
+    std::string s, l;
+    const int n = h->engine.specInfo(k, src ? &s : nullptr, log ? &l : nullptr, state, islands);
+    auto copy = [](const std::string& from, char* to, size_t cap) { if (to && cap) { const size_t m = from.size() < cap - 1 ? from.size() : cap - 1; std::memcpy(to, from.data(), m); to[m] = 0; } };
+    copy(s, src, srcCap); copy(l, log, logCap);
+    return n;
 }
 
 int elemhip_set_stream(elemhip_t* h, void* stream) {

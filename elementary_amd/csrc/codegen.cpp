@@ -1,0 +1,100 @@
+// codegen.cpp — writes the per-island-SHAPE part of a specialised kernel (island_spec.inc explains the scheme).
+//
+// Input: one island's program exactly as the planner built it for the interpreter (tasks sorted by (wave, stage),
+// members, operand codes of buffer set 0, stage tables). Output: HIP source text that declares, as compile-time
+// constants, what the interpreter reads from LDS tables at run time. Nothing that differs between two islands of the
+// same shape appears in the text — record numbers are island-local, HBM arena indices and the root record are read
+// from the staged tables at run time — so 256 voices of one synth patch share one kernel (the text is the cache key).
+#include <cstdio>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace elemhip {
+
+uint32_t leafArityForCodegen(uint16_t op);   // plan.cpp
+
+static std::string u(uint32_t v) {
+    if (v == kNone) return "kNone";
+    char b[32]; std::snprintf(b, sizeof b, "%uu", v); return b;
+}
+
+// operand code -> expression of (c, off)
+static std::string opndExpr(uint32_t code, uint32_t opndIndex) {
+    const uint32_t kind = code & kOpKindMask, v = code & kOpValMask;
+    if (kind == kOpLds)   return "((kOpLds | " + u(v) + ") + off)";
+    if (kind == kOpConst) return "(kOpConst | " + u(v) + ")";
+    if (kind == kOpHbm)   return "UNI(ldsu(c.operands + " + u(opndIndex) + "))";   // arena index: differs per island instance
+    return "(uint32_t)kOpZero";
+}
+
+std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, const std::vector<Member>& members,
+                           const std::vector<uint32_t>& operands, const std::vector<uint32_t>& stageTab, uint32_t blockSize) {
+    std::ostringstream o;
+    const uint32_t S = I.numStages;
+    uint32_t lastStage = S - 1u;
+    o << "namespace gen {\n";
+    // ---- tasks ----
+    for (size_t q = 0; q < tasks.size(); ++q) {
+        const Task& t = tasks[q];
+        o << "struct T" << q << " {\n";
+        o << "    static constexpr uint32_t opcode = " << t.opcode << "u, flags = " << (uint32_t)(t.flags & 0x3Fu) << "u, s0 = " << t.s0
+          << "u, s1 = " << t.s1 << "u, count = " << t.count << "u;\n";
+        o << "    template <int K> static __device__ __forceinline__ Member member(const Ctx& c, uint32_t off) {\n        Member m;\n";
+        for (uint32_t k = 0; k < t.count; ++k) {
+            const uint32_t mi = t.first + k;
+            const Member& m = members[mi];
+            const uint32_t nops = m.nin == kNone ? std::min<uint32_t>(leafArityForCodegen(t.opcode), kMaxHostIn) : m.nin;
+            o << "        " << (k ? "else " : "") << "if constexpr (K == " << k << ") {\n";
+            o << "            m.rec = " << u(m.rec) << "; m.opnd = " << u(m.opnd) << "; m.nin = " << u(m.nin) << ";\n";
+            o << "            m.outLds = " << (m.outLds == kNone ? std::string("kNone") : u(m.outLds) + " + off") << ";\n";
+            o << "            m.outHbm = " << (m.outHbm == kNone ? std::string("kNone") : "UNI(ldsu(c.members + " + u(mi * 8u + 4u) + "))") << ";\n";
+            o << "            m.scratch = " << (m.scratch == kNone ? std::string("kNone") : u(m.scratch) + " + off") << ";\n";
+            for (uint32_t j = 0; j < 6; ++j)
+                o << "            m.sops[" << j << "] = " << (j < nops ? opndExpr(operands[m.opnd + j], m.opnd + j) : std::string("(uint32_t)kOpZero")) << ";\n";
+            o << "        }\n";
+        }
+        o << "        m.pad0_ = m.sops[0]; m.pad1_ = m.sops[1]; m.off = off;\n        return m;\n    }\n";
+        o << "    template <int K> static constexpr bool hasHbm() { return ";
+        for (uint32_t k = 0; k < t.count; ++k) o << (k ? " : " : "") << "K == " << k << " ? " << (members[t.first + k].outHbm != kNone ? "true" : "false");
+        o << " : false; }\n";
+        o << "    static __device__ __forceinline__ Member member_lane(const Ctx& c, uint32_t off, uint32_t lane) {\n        Member m = member<0>(c, off);\n";
+        for (uint32_t k = 1; k < t.count && k < 64u; ++k) o << "        m = spec_sel(lane >= " << k << "u, member<" << k << ">(c, off), m);\n";
+        o << "        return m;\n    }\n};\n";
+    }
+    // ---- (wave, stage) slots, later stages first ----
+    int waveSlots[kWaves];
+    for (uint32_t w = 0; w < kWaves; ++w) {
+        std::vector<uint32_t> stages;
+        for (uint32_t q = I.waveTask[w]; q < I.waveTask[w + 1]; ++q)
+            if (stages.empty() || stages.back() != tasks[q].stage) stages.push_back(tasks[q].stage);
+        waveSlots[w] = (int)stages.size();
+        for (int j = 0; j < (int)stages.size(); ++j) {
+            const uint32_t st = stages[stages.size() - 1 - (size_t)j];
+            const uint32_t prev = stageTab[S + st];
+            uint32_t ntasks = 0;
+            o << "template <> struct Slot<" << w << ", " << j << "> {\n";
+            std::ostringstream body;
+            for (uint32_t q = I.waveTask[w]; q < I.waveTask[w + 1]; ++q)
+                if (tasks[q].stage == st) { body << "        spec_task<T" << q << ">(c, off);\n"; ++ntasks; }
+            o << "    static constexpr uint32_t stage = " << st << "u, prev = " << u(prev) << ", prevT = " << (prev == kNone ? 0u : stageTab[prev])
+              << "u, ntasks = " << ntasks << "u;\n";
+            o << "    static __device__ __forceinline__ void run(const Ctx& c, uint32_t off) {\n" << body.str() << "    }\n};\n";
+        }
+    }
+    o << "struct P {\n    static constexpr uint32_t S = " << S << "u, D = " << I.copies << "u, slotArea = " << I.slotArea << "u, ldsProg = " << I.ldsProg
+      << "u, memOff = " << I.memOff << "u, opndOff = " << I.opndOff << "u, cellOff = " << I.cellOff << "u, numCells = " << I.numCells
+      << "u, recOff = " << I.recOff << "u, numRecs = " << I.numRecs << "u, progDwords = " << I.progDwords << "u, ldsCounters = " << I.ldsCounters
+      << "u, ldsRecs = " << I.ldsRecs << "u, lastStage = " << lastStage << "u, lastT = " << stageTab[lastStage] << "u, block = " << blockSize << "u;\n";
+    o << "    static constexpr int waveSlots[8] = {";
+    for (uint32_t w = 0; w < kWaves; ++w) o << (w ? ", " : "") << waveSlots[w];
+    o << "};\n};\n} // namespace gen\n";
+    o << "extern \"C\" __global__ __launch_bounds__(512) void elemhip_spec_island(PlanView pv, uint32_t* recs, float* hbm, const Globals* g,\n"
+         "        const uint32_t* lcg, const uint32_t* islandList, uint32_t batch, uint32_t arenaFloats) {\n"
+         "    spec_island_main<gen::P>(pv, recs, hbm, g, lcg, islandList, batch, arenaFloats);\n}\n";
+    return o.str();
+}
+
+} // namespace elemhip

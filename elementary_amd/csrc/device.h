@@ -13,7 +13,9 @@
 //   task         : a group of 1..64 same-opcode nodes of one island stage. Stateless ops run
 //                  sample-parallel (64 lanes x samples); stateful recurrences run lane-per-node.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 namespace elemhip {
 
@@ -75,6 +77,12 @@ struct Member {
     uint32_t outHbm;     // HBM arena buffer index to (also) write, or kNone
     uint32_t scratch;    // LDS word offset of op scratch, or kNone
     uint32_t pad0_, pad1_;
+#ifdef ELEMHIP_SPEC
+    // specialised kernels (island_spec.inc): the member is built from compile-time constants; its first operand codes
+    // travel with it (already moved to the block's buffer set), `off` = LDS word offset of that buffer set
+    uint32_t sops[6];
+    uint32_t off;
+#endif
 };
 
 // 8 dwords in the island program (two 16-byte LDS reads). The second half repeats what the

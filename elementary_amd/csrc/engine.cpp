@@ -84,6 +84,7 @@ Plan::~Plan() {
 // ---------------------------------------------------------------------------------------------
 Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), device(dev) {
     auto fail = [&](int code) { initErr = code; };
+    if (const char* e = std::getenv("ELEMHIP_SPECIALIZE")) specialize = std::max(0, std::min(2, std::atoi(e)));
     if (bs <= 0 || bs > (int)kMaxBlock) { fail(kBlockTooLarge); return; }
     if (dev == -1) {
         // "dry" engine: host logic only (instruction decode, graph mutation, plan build, gc) with
@@ -144,6 +145,7 @@ Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), devi
 }
 
 Engine::~Engine() {
+    for (auto& kv : nodes) if (kv.second.hostInst && kv.second.hostVt && kv.second.hostVt->destroy) kv.second.hostVt->destroy(kv.second.hostInst, kv.second.hostVt->user);
     if (dry) {
         for (auto& kv : nodes) std::free(kv.second.ring.ptr);
         for (auto& kv : resources) std::free(kv.second->dev.ptr);
@@ -335,6 +337,16 @@ void Engine::rootUpdateStep(Node& n) {
 
 // ---- instructions ------------------------------------------------------------------------------
 int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293-313
+    auto ht = hostTypes.find(type);
+    if (ht != hostTypes.end()) {               // a registered call-out type (Runtime.h:480-487)
+        if (nodes.find(id) != nodes.end()) return kNodeAlreadyExists;
+        Node n;
+        n.id = id; n.op = OP_HOST; n.rec = allocRec();
+        n.hostVt = ht->second.get();
+        n.hostInst = n.hostVt->create ? n.hostVt->create(id, sampleRate, blockSize, n.hostVt->user) : nullptr;
+        nodes.emplace(id, std::move(n));
+        return kOk;
+    }
     auto it = opTable().find(type);
     if (it == opTable().end()) return kUnknownNodeType;
     if (nodes.find(id) != nodes.end()) return kNodeAlreadyExists;
@@ -404,6 +416,16 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
     auto it = nodes.find(id);
     if (it == nodes.end()) return kNodeNotFound;
     Node& n = it->second;
+    if (n.op == OP_HOST) {                                         // GraphNode::setProperty of the user's node (GraphNode.h:49)
+        if (n.hostVt && n.hostVt->setProperty) {
+            std::string j;
+            toJson(v, j);
+            const int rc = n.hostVt->setProperty(n.hostInst, key.c_str(), j.c_str(), n.hostVt->user);
+            if (rc != kOk) return rc;
+        }
+        n.props[key] = v;
+        return kOk;
+    }
     switch (n.op) {
         case OP_CONST:                                             // Core.h:142-152
             if (key == "value") {
@@ -863,6 +885,7 @@ size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
     for (int32_t id : pruned) {
         Node& n = nodes.at(id);
         if (n.ring.ptr) { if (dry) std::free(n.ring.ptr); else (void)hipFree(n.ring.ptr); }   // device is idle whenever `mu` is free
+        if (n.hostInst && n.hostVt && n.hostVt->destroy) n.hostVt->destroy(n.hostInst, n.hostVt->user);
         // drop queued writes aimed at the record before it is recycled
         const uint32_t lo = n.rec * kRecDwords, hi = lo + kRecDwords;
         patches.erase(std::remove_if(patches.begin(), patches.end(), [&](const Patch& p) { return p.kind != 2 && p.index >= lo && p.index < hi; }), patches.end());
@@ -889,7 +912,66 @@ bool Engine::hasNode(int32_t id) {
     return nodes.find(id) != nodes.end();
 }
 
-void Engine::reset() {}   // Runtime.h:448-458: only SampleNode (out of scope) reacts to reset()
+// Runtime::reset (Runtime.h:448-458) forwards to every node; of the built-ins only SampleNode reacts: both readers get
+// noteOff(), i.e. target gain 0 (Sample.h:78-81, 174-177). The reader state lives in the node record.
+void Engine::reset() {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& kv : nodes) {
+        Node& n = kv.second;
+        if (n.op == OP_SAMPLE) {
+            writeParamF(n, rec::SMP_READER0, 0.0f);
+            writeParamF(n, rec::SMP_READER0 + rec::SMP_READER_DWORDS, 0.0f);
+        } else if (n.op == OP_HOST && n.hostVt && n.hostVt->reset) {
+            n.hostVt->reset(n.hostInst, n.hostVt->user);
+        }
+    }
+}
+
+int Engine::registerNodeType(const std::string& type, const HostVTable& vt) {   // Runtime.h:480-487
+    std::lock_guard<std::mutex> lock(mu);
+    if (hostTypes.count(type) || opTable().count(type)) return kNodeTypeAlreadyExists;
+    if (!vt.process) return kInvalidInstructionFormat;
+    hostTypes.emplace(type, std::unique_ptr<HostVTable>(new HostVTable(vt)));
+    return kOk;
+}
+
+static std::string idToHex(int32_t id) {   // Types.h:16-27
+    char b[16]; std::snprintf(b, sizeof b, "%08x", (uint32_t)id);
+    return b;
+}
+
+std::string Engine::snapshotJson() {   // Runtime.h:489-498: { nodeIdToHex(id): node.getProperties() }
+    std::lock_guard<std::mutex> lock(mu);
+    std::map<std::string, const Node*> sorted;
+    for (auto& kv : nodes) sorted.emplace(idToHex(kv.first), &kv.second);
+    std::string out = "{";
+    bool first = true;
+    for (auto& kv : sorted) {
+        if (!first) out += ',';
+        first = false;
+        out += '"' + kv.first + "\":{";
+        bool f2 = true;
+        for (auto& pr : kv.second->props) {
+            if (!f2) out += ',';
+            f2 = false;
+            toJson(Value::string(pr.first), out); out += ':'; toJson(pr.second, out);
+        }
+        out += '}';
+    }
+    out += '}';
+    return out;
+}
+
+std::string Engine::sharedResourceKeysJson() {   // SharedResourceMap::keys (SharedResource.h)
+    std::lock_guard<std::mutex> lock(mu);
+    std::vector<std::string> keys;
+    for (auto& kv : resources) keys.push_back(kv.first);
+    std::sort(keys.begin(), keys.end());
+    std::string out = "[";
+    for (size_t i = 0; i < keys.size(); ++i) { if (i) out += ','; toJson(Value::string(keys[i]), out); }
+    out += ']';
+    return out;
+}
 
 bool Engine::addSharedResource(const std::string& name, const float* const* ch, size_t nCh, size_t nSamples) {
     std::lock_guard<std::mutex> lock(mu);
@@ -916,6 +998,7 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
     if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(64, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
     if (key == "pipeline_copies") { pipelineCopies = std::max(1, std::min(6, (int)value)); planStale = true; return kOk; }   // next commit re-plans
+    if (key == "specialize") { specialize = std::max(0, std::min(2, (int)value)); planStale = true; return kOk; }   // next commit re-plans
     if (key == "profile_launches") {
         profileLaunches = value != 0.0;
         if (profileLaunches) { profMs.clear(); profSets = 0; profBlocks = 0; }
@@ -1026,8 +1109,50 @@ void Engine::enqueueBlock(const Plan& p) {
         if (e > b) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l]);
         const uint32_t cb = p.convLevelOffsets[l], ce = p.convLevelOffsets[l + 1];
         if (ce > cb) launch_convolve(stream, p.view, dRecs, dHbm, dGlobals, cb, ce - cb);
+        if (!p.hosts.empty()) (void)renderHostNodes(p, l);
     }
     launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, dOutRing);
+}
+
+// Call-out nodes of launch level `l` (GraphNode::process on the CPU, GraphNode.h:72): drain the stream, bring each node's
+// input buffers to the host, run the user's process(), put its output block back into the arena. Slow by construction
+// (two PCIe round trips and a pipeline drain per node and block) — the price of keeping custom CPU nodes usable.
+int Engine::renderHostNodes(const Plan& p, size_t l) {
+    bool any = false;
+    for (const Plan::HostDesc& h : p.hosts) if (h.level == (uint32_t)l) { any = true; break; }
+    if (!any) return kOk;
+    HIP_OK(hipStreamSynchronize(stream));
+    const size_t bs = (size_t)blockSize, n = hGlobals.numSamples, nInHost = hGlobals.numIn;
+    for (const Plan::HostDesc& h : p.hosts) {
+        if (h.level != (uint32_t)l) continue;
+        auto nit = nodes.find(h.nodeId), rit = nodes.find(h.rootId);
+        if (nit == nodes.end() || rit == nodes.end() || !nit->second.hostVt) continue;
+        const Node& r = rit->second;
+        const bool on = r.target > 0.5f, settled = std::fabs(r.target - r.gain) <= 1e-6f;
+        if (!((on || !settled) && r.channel >= 0 && (uint32_t)r.channel < hGlobals.numOut)) continue;   // GraphRenderSequence.h:214-219
+        const size_t k = h.leaf ? nInHost : h.inputs.size();
+        hostIn.assign(std::max<size_t>(k, 1) * bs, 0.0f);
+        hostOut.assign(bs, 0.0f);
+        for (size_t j = 0; j < k; ++j) {
+            float* dst = hostIn.data() + j * bs;
+            if (h.leaf) { HIP_OK(hipMemcpyAsync(dst, dHbm + j * bs, n * sizeof(float), hipMemcpyDeviceToHost, stream)); continue; }
+            const Plan::HostDesc::In& in = h.inputs[j];
+            if (in.kind == 1) HIP_OK(hipMemcpyAsync(dst, dHbm + (size_t)in.idx * bs, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+            else if (in.kind == 2) { float v; std::memcpy(&v, &shadow[(size_t)in.idx * kRecDwords + rec::P0], 4); std::fill(dst, dst + n, v); }
+            else if (in.kind == 3) {
+                const uint32_t ch = shadow[(size_t)in.idx * kRecDwords + rec::P0];
+                if (ch < nInHost) HIP_OK(hipMemcpyAsync(dst, dHbm + (size_t)ch * bs, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+            }
+        }
+        HIP_OK(hipStreamSynchronize(stream));
+        std::vector<const float*> ptrs(std::max<size_t>(k, 1));
+        for (size_t j = 0; j < k; ++j) ptrs[j] = hostIn.data() + j * bs;
+        const Node& hn = nit->second;
+        hn.hostVt->process(hn.hostInst, ptrs.data(), k, hostOut.data(), n, curBlockTime, h.active ? 1 : 0, hn.hostVt->user);
+        HIP_OK(hipMemcpyAsync(dHbm + (size_t)h.outHbm * bs, hostOut.data(), n * sizeof(float), hipMemcpyHostToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+    }
+    return kOk;
 }
 
 // Host mirror of what the epilogue kernel does to each root's fade (GainFade.h:56-72), so that
@@ -1081,6 +1206,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     }
     rc = flushPending();
     if (rc != kOk) return rc;
+    curBlockTime = sampleTime;
     enqueueBlock(p);
     if (nOut > 0) {
         const size_t floats = nOut * (size_t)blockSize;
@@ -1137,7 +1263,7 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
         for (size_t l = 0; l < L; ++l) {
             const uint32_t lb = p.levelOffsets[l], le = p.levelOffsets[l + 1];
             (void)hipEventRecord(ev[2 * l], stream);
-            if (le > lb) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l], batch, arenaFloats);
+            if (le > lb) { if (batch > 1) launchLevelBatch(p, l, batch, arenaFloats); else launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l], batch, arenaFloats); }
             if (p.convLevelOffsets[l + 1] > p.convLevelOffsets[l])
                 launch_convolve(stream, p.view, dRecs, dHbm, dGlobals, p.convLevelOffsets[l], p.convLevelOffsets[l + 1] - p.convLevelOffsets[l]);
             (void)hipEventRecord(ev[2 * l + 1], stream);
@@ -1197,7 +1323,7 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
         const uint32_t lb = p.levelOffsets[l], le = p.levelOffsets[l + 1];
         const uint64_t v = (l == level) ? tp : 0;
         HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(dGlobals) + offsetof(Globals, trace), &v, 8, hipMemcpyHostToDevice, stream));
-        if (le > lb) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l], batch, arenaFloats);
+        if (le > lb) { if (batch > 1) launchLevelBatch(p, l, batch, arenaFloats); else launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l], batch, arenaFloats); }
     }
     const uint64_t zero = 0;
     HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(dGlobals) + offsetof(Globals, trace), &zero, 8, hipMemcpyHostToDevice, stream));
@@ -1215,7 +1341,7 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
 // A multi-block launch carries no per-block root/tap/convolver bookkeeping: it is used only while every
 // running root's fade is settled (Core.h:28-31) and the plan has neither taps nor convolvers.
 bool Engine::batchEligible(const Plan& p, size_t nOut) const {
-    if (!p.taps.empty() || !p.convs.empty()) return false;
+    if (!p.taps.empty() || !p.convs.empty() || !p.hosts.empty()) return false;
     for (int32_t id : p.rootIds) {
         auto it = nodes.find(id);
         if (it == nodes.end()) return false;
@@ -1245,6 +1371,19 @@ void Engine::profCollect() {
     profUsed = 0; profSlots.clear();
 }
 
+// debug / tests: program text and compile state of the k-th specialised shape of the newest plan
+int Engine::specInfo(size_t k, std::string* source, std::string* log, int* state, uint32_t* islands) {
+    std::lock_guard<std::mutex> lock(mu);
+    const std::shared_ptr<Plan> pl = pending ? pending : current;
+    if (!pl || k >= pl->shapes.size()) return -1;
+    const Plan::SpecShape& sh = pl->shapes[k];
+    if (source) *source = sh.entry->source;
+    if (log) *log = sh.entry->log;
+    if (state) *state = sh.entry->state.load();
+    if (islands) *islands = sh.count;
+    return (int)pl->shapes.size();
+}
+
 int Engine::launchProfile(double* msOut, size_t cap, uint64_t* launchSets, uint64_t* blocks) {
     std::lock_guard<std::mutex> lock(mu);
     if (launchSets) *launchSets = profSets;
@@ -1252,6 +1391,41 @@ int Engine::launchProfile(double* msOut, size_t cap, uint64_t* launchSets, uint6
     const size_t n = std::min(cap, profMs.size());
     for (size_t i = 0; i < n; ++i) msOut[i] = profMs[i];
     return (int)profMs.size();
+}
+
+// One launch level of a multi-block launch. When every island shape of the level has its specialised kernel compiled
+// (jit.cpp) the level runs as one launch per shape plus an interpreter launch for the islands no shape covers
+// (stateless mixers and roots); until then the whole level goes through the interpreter kernel.
+void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t arenaFloats) {
+    const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
+    if (e <= b) return;
+    bool spec = specialize != 0 && !p.shapes.empty();
+    std::vector<std::pair<hipFunction_t, const Plan::SpecShape*>> fns;
+    if (spec) {
+        for (const Plan::SpecShape& sh : p.shapes) {
+            if (sh.level != (uint32_t)l) continue;
+            hipFunction_t fn = sh.entry->function(device);
+            if (!fn) { spec = false; break; }
+            fns.emplace_back(fn, &sh);
+        }
+        if (fns.empty()) spec = false;
+    }
+    if (!spec) { launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats); return; }
+    for (auto& f : fns) {
+        PlanView pv = p.view;
+        uint32_t* recs = dRecs; float* hbm = dHbm; const Globals* g = dGlobals; const uint32_t* lcg = dLcg;
+        const uint32_t* list = p.dSpecLists + f.second->listBegin;
+        uint32_t bt = batch, af = arenaFloats;
+        void* args[] = {&pv, &recs, &hbm, &g, &lcg, &list, &bt, &af};
+        HIP_WARN(hipModuleLaunchKernel(f.first, f.second->count, 1, 1, kThreads, 1, 1, 0, stream, args, nullptr));
+        st.specLaunches++;
+    }
+    const uint32_t rb = p.restOffsets[l], re = p.restOffsets[l + 1];
+    if (re > rb) {
+        PlanView pv = p.view;
+        pv.levelIslands = p.dRestIslands;
+        launch_level(stream, pv, dRecs, dHbm, dGlobals, dLcg, rb, re - rb, p.levelLdsBytes[l], batch, arenaFloats);
+    }
 }
 
 void Engine::enqueueBatch(const Plan& p, uint32_t batch) {
@@ -1262,7 +1436,7 @@ void Engine::enqueueBatch(const Plan& p, uint32_t batch) {
         const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
         if (e <= b) continue;
         if (prof) (void)hipEventRecord(profEvent(), stream);
-        launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats);
+        launchLevelBatch(p, l, batch, arenaFloats);
         if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)l); }
     }
     if (prof) (void)hipEventRecord(profEvent(), stream);
@@ -1280,7 +1454,7 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
     if (!current || numBlocks == 0) return kOk;
     Plan& p = *current;
     const size_t bs = (size_t)blockSize;
-    const bool graphOk = useGraph;
+    const bool graphOk = useGraph && p.hosts.empty();   // call-out nodes synchronise inside a block: nothing to capture
     const bool haveIn = nIn > 0 && inDev != nullptr;
     const size_t G = graphOk ? (size_t)graphBlocks : 1;
     rc = ensureOutRing(std::max<size_t>(nOut, 1) * bs * G);
@@ -1340,7 +1514,7 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             HIP_OK(hipGraphLaunch(p.graphExec, stream));
             st.graphReplays++;
         } else {
-            for (size_t b = 0; b < chunk; ++b) enqueueBlock(p);
+            for (size_t b = 0; b < chunk; ++b) { curBlockTime = hGlobals.sampleTime + (int64_t)(b * bs); enqueueBlock(p); }
         }
         if (outDev && nOut > 0)
             HIP_OK(hipMemcpyAsync(outDev + done * nOut * bs, dOutRing, chunk * nOut * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));

@@ -23,6 +23,7 @@
 
 #include "device.h"
 #include "json.h"
+#include "jit.h"
 
 namespace elemhip {
 
@@ -34,6 +35,18 @@ enum ReturnCode : int {
     kJsonParseError = 105,
 };
 const char* describe(int code);
+
+// Host call-out node types (Runtime::registerNodeType, runtime/elem/Runtime.h:105-106; GraphNode.h:19-96): a node whose
+// process() runs on the CPU between two launch levels. OP_HOST never reaches a kernel, so it is not a device opcode.
+constexpr uint16_t OP_HOST = 0x7F00;
+struct HostVTable {
+    void* (*create)(int32_t nodeId, double sampleRate, int blockSize, void* user) = nullptr;
+    void  (*destroy)(void* node, void* user) = nullptr;
+    int   (*setProperty)(void* node, const char* key, const char* jsonValue, void* user) = nullptr;
+    void  (*process)(void* node, const float* const* in, size_t nIn, float* out, size_t numSamples, int64_t sampleTime, int active, void* user) = nullptr;
+    void  (*reset)(void* node, void* user) = nullptr;
+    void* user = nullptr;
+};
 
 struct DevBuf {
     void* ptr = nullptr;
@@ -67,6 +80,8 @@ struct Node {
     ResourcePtr res;            // tap buffer / sample data held by the node
     uint32_t eventCount = 0;    // meter / snapshot: readouts already relayed by processQueuedEvents
     uint32_t convSlices = 1;    // convolve: helper slices its current impulse response wants (conv.hip)
+    void* hostInst = nullptr;   // OP_HOST: the instance its type's create() returned
+    const HostVTable* hostVt = nullptr;
 };
 
 struct Plan;   // plan.cpp
@@ -77,6 +92,9 @@ struct Stats {
     double   lastPlanBuildMs = 0.0;
     uint32_t numIslands = 0, numLevels = 0, numTasks = 0, numNodesInPlan = 0, maxLdsBytes = 0, numHbmBuffers = 0;
     uint64_t graphReplays = 0, graphCaptures = 0, batchLaunches = 0;
+    uint64_t specLaunches = 0;             // launches of run-time specialised island kernels
+    uint32_t specShapes = 0, specIslands = 0;
+    double   lastJitWaitMs = 0.0;
 };
 
 class Engine {
@@ -120,6 +138,10 @@ public:
     uint32_t lastTimedBatch() const { return lastTimeBatch; }
     // option "profile_launches": HIP event pairs around every multi-block launch of processBlocks (same stream, inside
     // whatever region the caller times). msOut[l] = summed ms of level l, msOut[levels] = epilogue; launchSets = sets timed.
+    int registerNodeType(const std::string& type, const HostVTable& vt);   // Runtime.h:480-487
+    std::string snapshotJson();                        // Runtime::snapshot (Runtime.h:110, 489-498)
+    std::string sharedResourceKeysJson();              // Runtime::getSharedResourceMapKeys (Runtime.h:94)
+    int specInfo(size_t k, std::string* source, std::string* log, int* state, uint32_t* islands);
     int launchProfile(double* msOut, size_t cap, uint64_t* launchSets, uint64_t* blocks);
 
 private:
@@ -137,6 +159,9 @@ private:
     std::unordered_map<int32_t, Node> nodes;
     std::set<int32_t> currentRoots;
     std::unordered_map<std::string, ResourcePtr> resources;
+    std::unordered_map<std::string, std::unique_ptr<HostVTable>> hostTypes;
+    std::vector<float> hostIn, hostOut;    // staging for call-out nodes
+    int64_t curBlockTime = 0;              // sample time of the block being enqueued (call-out nodes get it as userData)
     bool shouldRebuild = false;
     bool rebuildOwed = false;              // a commit failed to build its plan: the next commit retries even without ACTIVATE_ROOTS
     std::vector<int32_t> lastPruned;
@@ -174,6 +199,8 @@ private:
     int  batchBlocks = 64;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)
     int  pipelineCopies = 6;               // blocks a stateful island keeps in flight inside a multi-block launch
     int  timeBatch = 1;
+    int  specialize = 1;                   // 0: interpreter kernels only; 1: specialised kernels compiled in the background and used
+                                           // once ready; 2: commit() waits for them (deterministic: tests, benchmarks)
     bool profileLaunches = false;
     std::vector<double> profMs;            // per level + epilogue, summed over the launch sets profiled so far
     uint64_t profSets = 0, profBlocks = 0;
@@ -199,7 +226,9 @@ private:
     int  ensureOutRing(size_t floats);
     int  swapInPending();
     void enqueueBlock(const Plan& p);
+    int  renderHostNodes(const Plan& p, size_t level);   // call-out nodes of one launch level (synchronises the stream)
     void enqueueBatch(const Plan& p, uint32_t batch);
+    void launchLevelBatch(const Plan& p, size_t level, uint32_t batch, uint32_t arenaFloats);   // specialised kernels when ready, else the interpreter
     bool batchEligible(const Plan& p, size_t nOut) const;
     void mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn);
     int  setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime);
@@ -222,12 +251,35 @@ struct Plan {
     std::vector<uint32_t> convWork;        // conv workgroups, level-major
     std::vector<uint32_t> convLevelOffsets; // numLevels + 1
     std::vector<int32_t> rootIds;          // same order as `roots`
+    std::vector<uint32_t> islandLevel;     // launch level of each island
     std::set<int32_t> nodeIds;             // every node the render sequence references (gc)
     uint32_t numHbmBuffers = kMaxHostIn;
     uint32_t maxLdsBytes = 0;
     // device copies
     DevBuf dev;                            // one allocation holding all tables
     PlanView view{};
+    // host call-out nodes (OP_HOST): rendered on the CPU after the kernels of their launch level
+    struct HostDesc {
+        int32_t nodeId; int32_t rootId;
+        struct In { int kind; uint32_t idx; float value; };   // 0 zero, 1 HBM arena buffer, 2 constant, 3 host input channel idx
+        std::vector<In> inputs;
+        bool leaf = false;         // no inlets: the node reads the host input channels (GraphRenderSequence.h:107-141)
+        uint32_t outHbm; uint32_t level; bool active;
+    };
+    std::vector<HostDesc> hosts;
+    // specialised kernels (jit.cpp): islands of one launch level with the same generated program text share a kernel
+    struct SpecShape {
+        std::shared_ptr<SpecEntry> entry;
+        uint32_t level = 0;
+        uint32_t listBegin = 0, count = 0;     // its islands: specLists[listBegin, listBegin + count)
+    };
+    std::vector<SpecShape> shapes;
+    std::vector<uint32_t> specLists;           // island indices, shape-major
+    std::vector<uint32_t> restIslands;         // per level: the levelIslands entries no shape covers (interpreter launch)
+    std::vector<uint32_t> restOffsets;         // numLevels + 1
+    std::vector<std::string> specText;         // per island: generated text ("" = interpreter only), consumed by buildPlan
+    const uint32_t* dSpecLists = nullptr;      // device copies (inside `dev`)
+    const uint32_t* dRestIslands = nullptr;
     // captured launch sequence for multi-block offline rendering
     hipGraphExec_t graphExec = nullptr;
     int graphBlocks = 0;

@@ -5,6 +5,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -182,5 +183,39 @@ private:
         return true;
     }
 };
+
+// Value -> JSON text (the inverse of JsonParser; numbers with 17 significant digits round-trip every double)
+inline void toJson(const Value& v, std::string& out) {
+    switch (v.type) {
+        case Value::Bool: out += v.b ? "true" : "false"; break;
+        case Value::Number: {
+            if (!std::isfinite(v.num)) { out += "null"; break; }
+            char b[40]; std::snprintf(b, sizeof b, "%.17g", v.num); out += b; break;
+        }
+        case Value::String: {
+            out += '"';
+            for (unsigned char ch : v.str) {
+                if (ch == '"' || ch == '\\') { out += '\\'; out += (char)ch; }
+                else if (ch < 0x20) { char b[8]; std::snprintf(b, sizeof b, "\\u%04x", ch); out += b; }
+                else out += (char)ch;
+            }
+            out += '"';
+            break;
+        }
+        case Value::Array: {
+            out += '[';
+            for (size_t i = 0; i < v.arr.size(); ++i) { if (i) out += ','; toJson(v.arr[i], out); }
+            out += ']';
+            break;
+        }
+        case Value::Object: {
+            out += '{';
+            for (size_t i = 0; i < v.obj.size(); ++i) { if (i) out += ','; toJson(Value::string(v.obj[i].first), out); out += ':'; toJson(v.obj[i].second, out); }
+            out += '}';
+            break;
+        }
+        default: out += "null"; break;
+    }
+}
 
 } // namespace elemhip

@@ -12,6 +12,7 @@
 // by liveness, and order islands into launch levels.
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstdio>
 #include <functional>
 #include <numeric>
@@ -25,13 +26,14 @@ namespace elemhip {
 
 namespace {
 
-enum Kind : uint8_t { K_CONST, K_PAR, K_SINGLE, K_CHAIN, K_CONV };
+enum Kind : uint8_t { K_CONST, K_PAR, K_SINGLE, K_CHAIN, K_CONV, K_HOST };
 
 Kind kindOf(uint16_t op) {
     switch (op) {
         case OP_CONST: case OP_SR: return K_CONST;
         case OP_RAND: case OP_Z: case OP_SDELAY: case OP_DELAY: case OP_SAMPLESEQ: case OP_METER: case OP_SNAPSHOT: case OP_SCOPE: return K_SINGLE;
         case OP_CONVOLVE: return K_CONV;   // always an island of its own, rendered by conv.hip
+        case OP_HOST: return K_HOST;       // always an island of its own, rendered on the CPU between launch levels
         case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD:
         case OP_ONCE: case OP_SEQ: case OP_SEQ2: case OP_SAMPLE: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
         case OP_SVFSHELF: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
@@ -73,6 +75,12 @@ uint32_t leafArity(uint16_t op) {
 // and bounds a pipelined island's block rate, so nothing else rides on its wave.
 bool blepSplit(uint16_t op) { return op == OP_BLEPSAW || op == OP_BLEPSQUARE; }
 
+uint32_t leafArityOfOp(uint16_t op);
+} // namespace
+uint32_t leafArityForCodegen(uint16_t op) { return leafArityOfOp(op); }
+std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, const std::vector<Member>& members,
+                           const std::vector<uint32_t>& operands, const std::vector<uint32_t>& stageTab, uint32_t blockSize);   // codegen.cpp
+namespace {
 uint32_t leafArityOfOp(uint16_t op) {
     if (op == OP_SAW_SHAPE || op == OP_SQUARE_SHAPE) return 1;
     if (op == OP_SVF_COEF) return leafArity(OP_SVF);
@@ -165,6 +173,7 @@ struct PlanBuilder {
     }
 
     bool splitCoefStage = false;
+    bool wantSpec = false;                  // also write the specialised-kernel text of every pipelined island
     std::shared_ptr<Plan> build(uint32_t maxIslandNodes, uint32_t maxCopies);
 };
 
@@ -275,7 +284,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             deps.insert(rep(s.island));
         }
         int target = -1;
-        const bool sealed = x.kind == K_CONV;
+        const bool sealed = x.kind == K_CONV || x.kind == K_HOST;
         if (!deps.empty() && !sealed) {
             uint32_t total = w;
             for (int d : deps) total += weight[d];
@@ -345,7 +354,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     for (size_t k = 0; k < ni.size(); ++k) {
         NI& x = ni[k];
         if (x.kind == K_CONST) continue;
-        if (x.n->op == OP_ROOT || x.kind == K_CONV) x.exported = true;
+        if (x.n->op == OP_ROOT || x.kind == K_CONV || x.kind == K_HOST) x.exported = true;
         if (x.kind == K_CHAIN) x.needLds = true;
     }
     for (size_t k = 0; k < ni.size(); ++k) {
@@ -419,6 +428,28 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             I.rootRec = d.rootRec; I.split = 0;                                         // no island-kernel workgroup
             convLevel.push_back(B.level);
             p.convs.push_back(d);
+            continue;
+        }
+
+        if (ni[B.nodes[0]].kind == K_HOST) {     // call-out node (Runtime::registerNodeType): no device program, a HostDesc for the engine
+            NI& x = ni[B.nodes[0]];
+            Plan::HostDesc d{};
+            d.nodeId = x.n->id; d.rootId = seqRoots[B.seq]->id; d.outHbm = x.hbm; d.level = (uint32_t)B.level;
+            {
+                auto a = seqRoots[B.seq]->props.find("active");
+                d.active = a != seqRoots[B.seq]->props.end() && a->second.isBool() && a->second.b;
+            }
+            d.leaf = x.n->inlets.empty();
+            for (auto& in : x.n->inlets) {
+                auto it = idx.find(in.source);
+                if (it == idx.end() || in.channel != 0) d.inputs.push_back({0, 0u, 0.0f});
+                else if (ni[it->second].kind == K_CONST && !ni[it->second].elided) d.inputs.push_back({2, ni[it->second].n->rec, 0.0f});
+                else if (ni[it->second].elided && ni[it->second].n->op == OP_IN) d.inputs.push_back({3, ni[it->second].n->rec, 0.0f});
+                else d.inputs.push_back({1, ni[it->second].hbm, 0.0f});
+            }
+            I = Island{};
+            I.rootRec = seqRoots[B.seq]->rec; I.split = 0;
+            p.hosts.push_back(std::move(d));
             continue;
         }
 
@@ -967,10 +998,16 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         I.ldsRecs = (I.ldsNext + S * kWaves + 3u) & ~3u;
         I.ldsWords = (I.ldsRecs + I.numRecs * kRecDwords + 3u) & ~3u;
         p.maxLdsBytes = std::max(p.maxLdsBytes, I.ldsWords * 4u);
+        if (wantSpec && !statelessIsland && I.split == 1u) {
+            if (p.specText.size() < ib.size()) p.specText.resize(ib.size());
+            p.specText[ii] = emitSpecSource(I, tasks, members, operands, stageTab, bs);
+        }
         p.numTasks += I.numTasks; p.numMembers += (uint32_t)members.size(); p.numOperands += (uint32_t)operands.size();
     }
 
     // ---- 5. launch levels, roots, taps ------------------------------------------------------------------
+    p.islandLevel.resize(ib.size());
+    for (size_t i = 0; i < ib.size(); ++i) p.islandLevel[i] = (uint32_t)ib[i].level;
     p.levelOffsets.assign((size_t)numLevels + 1, 0);
     p.levelLdsBytes.assign((size_t)numLevels, 0);
     for (size_t i = 0; i < ib.size(); ++i) p.levelOffsets[(size_t)ib[i].level + 1] += p.islands[i].split;
@@ -1009,6 +1046,7 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     const uint32_t ldsLimit = 160u * 1024u - 1024u;
     for (uint32_t limit = 56; limit >= 4; limit /= 2) {
         PlanBuilder b(*this);
+        b.wantSpec = specialize != 0;
         plan = b.build(limit, (uint32_t)std::max(1, pipelineCopies));
         if (!plan) return nullptr;
         if (plan->maxLdsBytes <= ldsLimit) break;
@@ -1034,6 +1072,38 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     const size_t oTaps = place(p.taps.size() * sizeof(TapEntry));
     const size_t oConvs = place(p.convs.size() * sizeof(ConvDesc));
     const size_t oConvWork = place(p.convWork.size() * 4);
+    // ---- specialised kernels: group each level's islands by generated text, queue the shapes for compilation ----
+    {
+        const size_t L = p.levelOffsets.size() - 1;
+        p.restOffsets.assign(L + 1, 0);
+        std::vector<uint8_t> covered(p.islands.size(), 0);
+        for (size_t l = 0; l < L; ++l) {
+            std::map<std::string, std::vector<uint32_t>> byText;
+            for (uint32_t q = p.levelOffsets[l]; q < p.levelOffsets[l + 1]; ++q) {
+                const uint32_t isl = p.levelIslands[q] & 0xFFFFFFu;
+                if (isl < p.specText.size() && !p.specText[isl].empty() && !covered[isl]) byText[p.specText[isl]].push_back(isl);
+            }
+            for (auto& kv : byText) {
+                Plan::SpecShape sh;
+                sh.entry = Jit::get().request(kv.first, p.islands[kv.second[0]].ldsWords);
+                sh.level = (uint32_t)l; sh.listBegin = (uint32_t)p.specLists.size(); sh.count = (uint32_t)kv.second.size();
+                for (uint32_t isl : kv.second) { p.specLists.push_back(isl); covered[isl] = 1; }
+                p.shapes.push_back(std::move(sh));
+            }
+            for (uint32_t q = p.levelOffsets[l]; q < p.levelOffsets[l + 1]; ++q)
+                if (!covered[p.levelIslands[q] & 0xFFFFFFu]) p.restIslands.push_back(p.levelIslands[q]);
+            p.restOffsets[l + 1] = (uint32_t)p.restIslands.size();
+        }
+        p.specText.clear(); p.specText.shrink_to_fit();
+        st.specShapes = (uint32_t)p.shapes.size(); st.specIslands = (uint32_t)p.specLists.size();
+        if (specialize >= 2) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (auto& sh : p.shapes) (void)Jit::get().wait(sh.entry);
+            st.lastJitWaitMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+    }
+    const size_t oSpecLists = place(p.specLists.size() * 4);
+    const size_t oRest = place(p.restIslands.size() * 4);
     std::vector<uint8_t> host(std::max<size_t>(off, 16), 0);
     auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(host.data() + o, src, bytes); };
     put(oIslands, p.islands.data(), p.islands.size() * sizeof(Island));
@@ -1043,6 +1113,8 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     put(oTaps, p.taps.data(), p.taps.size() * sizeof(TapEntry));
     put(oConvs, p.convs.data(), p.convs.size() * sizeof(ConvDesc));
     put(oConvWork, p.convWork.data(), p.convWork.size() * 4);
+    put(oSpecLists, p.specLists.data(), p.specLists.size() * 4);
+    put(oRest, p.restIslands.data(), p.restIslands.size() * 4);
     if (dry) return plan;
     if (hipMalloc(&p.dev.ptr, host.size()) != hipSuccess) return nullptr;
     p.dev.bytes = host.size();
@@ -1055,6 +1127,8 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     p.view.taps = reinterpret_cast<const TapEntry*>(d + oTaps);
     p.view.convs = reinterpret_cast<const ConvDesc*>(d + oConvs);
     p.view.convWork = reinterpret_cast<const uint32_t*>(d + oConvWork);
+    p.dSpecLists = reinterpret_cast<const uint32_t*>(d + oSpecLists);
+    p.dRestIslands = reinterpret_cast<const uint32_t*>(d + oRest);
     p.view.numConvs = (uint32_t)p.convs.size();
     p.view.numRoots = (uint32_t)p.roots.size();
     p.view.numTaps = (uint32_t)p.taps.size();

@@ -54,6 +54,7 @@ class _Stats(C.Structure):
         ("num_islands", C.c_uint32), ("num_levels", C.c_uint32), ("num_tasks", C.c_uint32),
         ("num_nodes_in_plan", C.c_uint32), ("max_lds_bytes", C.c_uint32), ("num_hbm_buffers", C.c_uint32),
         ("graph_replays", C.c_uint64), ("graph_captures", C.c_uint64), ("batch_launches", C.c_uint64),
+        ("spec_launches", C.c_uint64), ("spec_shapes", C.c_uint32), ("spec_islands", C.c_uint32), ("last_jit_wait_ms", C.c_double),
     ]
 
 
@@ -124,6 +125,16 @@ class Runtime(CRuntime):
             return {"level_ms": [], "epilogue_ms": 0.0, "launch_sets": int(sets.value), "blocks": int(blocks.value)}
         vals = [float(buf[i]) for i in range(k)]
         return {"level_ms": vals[:-1], "epilogue_ms": vals[-1], "launch_sets": int(sets.value), "blocks": int(blocks.value)}
+
+    def spec_info(self, k: int = 0) -> Dict[str, Any]:
+        """The k-th specialised island shape of the newest plan: program text, compiler log, state, islands covered."""
+        f = self._lib.elemhip_spec_info
+        f.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
+        f.restype = C.c_int
+        src, log = C.create_string_buffer(1 << 20), C.create_string_buffer(1 << 18)
+        state, isl = C.c_int(0), C.c_uint32(0)
+        n = f(self._h, k, src, len(src), log, len(log), C.byref(state), C.byref(isl))
+        return {"shapes": n, "source": src.value.decode(), "log": log.value.decode(errors="replace"), "state": state.value, "islands": isl.value}
 
     def describe_plan(self) -> Dict[str, Any]:
         import json

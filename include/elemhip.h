@@ -33,6 +33,9 @@ typedef struct elemhip_stats {
     uint32_t num_islands, num_levels, num_tasks, num_nodes_in_plan, max_lds_bytes, num_hbm_buffers;
     uint64_t graph_replays, graph_captures;
     uint64_t batch_launches;      /* multi-block launch groups issued by elemhip_process_blocks */
+    uint64_t spec_launches;       /* launches of run-time specialised island kernels */
+    uint32_t spec_shapes, spec_islands;   /* distinct specialised island shapes / islands they cover in the current plan */
+    double   last_jit_wait_ms;    /* time the last commit waited for kernel compilation (option "specialize" = 2) */
 } elemhip_stats;
 
 /* Runtime(double sampleRate, int blockSize)                      runtime/elem/Runtime.h:44,157-166
@@ -80,6 +83,33 @@ size_t elemhip_last_gc(elemhip_t*, int32_t* prunedOut, size_t cap);
 /* void reset()                                                   Runtime.h:70,448-458 */
 void   elemhip_reset(elemhip_t*);
 
+/* int registerNodeType(std::string const& type, NodeFactoryFn&&)  Runtime.h:105-106,480-487 (code 4 when the name is taken)
+ * A custom node type whose instances run ON THE CPU (the reference's GraphNode plug-in interface, GraphNode.h:19-96): the
+ * engine renders everything upstream on the GPU, drains the stream, hands the node its input blocks on the host, calls
+ * process() and uploads the output block — a call-out per node and block, slow by construction, kept so that hosts with
+ * their own C++ nodes (wasm/Main.cpp:47-61 registers three this way) keep working. Plans containing such nodes render
+ * block by block (no multi-block launches, no hipGraph replay).
+ *   create       NodeFactoryFn(NodeId, sampleRate, blockSize)                          GraphNode.h:27
+ *   set_property GraphNode::setProperty(key, js::Value) with the value as JSON text    GraphNode.h:49; return a ReturnCode
+ *   process      GraphNode::process(BlockContext): planar inputs, ONE output channel   GraphNode.h:72, Types.h:91-101
+ *                (`sample_time` is what the reference's hosts pass as userData, `active` = BlockContext::active)
+ *   reset        GraphNode::reset                                                      GraphNode.h:86 (may be NULL) */
+typedef struct elemhip_node_type {
+    void* (*create)(int32_t node_id, double sample_rate, int block_size, void* user);
+    void  (*destroy)(void* node, void* user);
+    int   (*set_property)(void* node, const char* key, const char* json_value, void* user);
+    void  (*process)(void* node, const float* const* in, size_t n_in, float* out, size_t num_samples, int64_t sample_time, int active, void* user);
+    void  (*reset)(void* node, void* user);
+    void* user;
+} elemhip_node_type;
+int elemhip_register_node_type(elemhip_t*, const char* type, const elemhip_node_type* vt);
+
+/* js::Object snapshot()                                          Runtime.h:110,489-498
+ * {"<8-digit hex node id>": {property: value, ...}, ...} as JSON text; returns the bytes needed (including the NUL). */
+size_t elemhip_snapshot_json(elemhip_t*, char* buf, size_t cap);
+/* SharedResourceMap::KeyViewType getSharedResourceMapKeys()      Runtime.h:94 — a JSON array of names */
+size_t elemhip_shared_resource_keys_json(elemhip_t*, char* buf, size_t cap);
+
 /* ReturnCode::describe                                           Types.h:62-85 */
 const char* elemhip_describe(int code);
 int  elemhip_get_stats(elemhip_t*, elemhip_stats* out);
@@ -106,9 +136,14 @@ int  elemhip_trace_level(elemhip_t*, size_t nOut, uint32_t level, unsigned long 
  * deviceOrdinal == -1 at create time gives a "dry" handle that runs all host logic (instruction
  * decode, graph mutation, plan build, gc) without a GPU; it cannot render (process returns 101). */
 size_t elemhip_describe_plan(elemhip_t*, char* buf, size_t cap);
+/* Debug/test hook: program text, compiler log and state (0 compiling, 1 ready, -1 failed) of the k-th specialised
+ * island shape of the newest plan; returns the number of shapes or -1. */
+int  elemhip_spec_info(elemhip_t*, size_t k, char* src, size_t srcCap, char* log, size_t logCap, int* state, uint32_t* islands);
 /* Run the launches on a caller-owned hipStream_t (e.g. torch's current stream). */
 int  elemhip_set_stream(elemhip_t*, void* hipStream);
-/* Tunables: "use_graph" (0/1), "graph_blocks" (blocks per captured hipGraph). */
+/* Tunables: "use_graph" (0/1), "graph_blocks" (blocks per captured hipGraph), "batch_blocks" (blocks per multi-block
+ * launch), "specialize" (0 interpreter kernels only, 1 per-island-shape kernels compiled in the background and used once
+ * ready, 2 commit waits for them), "profile_launches", "pipeline_copies", "time_batch". */
 int  elemhip_set_option(elemhip_t*, const char* key, double value);
 
 #ifdef __cplusplus

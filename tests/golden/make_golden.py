@@ -5,6 +5,7 @@ Run in the authoring container only (needs /root/reference):  python tests/golde
 Sources (jest snapshot files of the reference, recorded through its wasm engine):
   js/packages/offline-renderer/__tests__/__snapshots__/{delays,tap,time,offline-renderer,sampleseq,maxhold,sparseq2,vfs}.test.js.snap
   js/packages/core/__tests__/__snapshots__/core.test.js.snap   (instruction batches with real int32 hashes)
+  js/packages/core/__tests__/__snapshots__/hashing.test.js.snap (the same with masked hashes: 69-node synth voice)
 Only Float32Array snapshots and instruction-batch snapshots are transcribed; the scenarios that
 produce them are restated in tests/test_oracle_golden.py / tests/test_reconciler.py.
 """
@@ -52,6 +53,12 @@ def main():
         except Exception:
             pass
     json.dump(batches, open(os.path.join(HERE, "core_instruction_batches.json"), "w"))
+    # hashing.test.js: the same batches with hashes replaced by first-seen ordinals (a 69-node synth voice, rendered twice)
+    hashless = {}
+    for key, body in parse_snap(f"{REF}/core/__tests__/__snapshots__/hashing.test.js.snap").items():
+        hashless[key] = js_value(body)
+    json.dump(hashless, open(os.path.join(HERE, "hashless_instruction_batches.json"), "w"))
+    print("hashless snapshots:", {k: len(v) for k, v in hashless.items()})
     print("audio snapshots:", {k: len(v) for k, v in audio.items()})
     print("batch snapshots:", list(batches))
 

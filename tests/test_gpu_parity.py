@@ -230,3 +230,14 @@ def test_event_relay(gpu_required):
             for key in ("min", "max", "data"):
                 if key in pb:
                     assert float(np.abs(np.asarray(pa[key], np.float64) - np.asarray(pb[key], np.float64)).max()) <= TOL, (key, pa, pb)
+
+
+def test_stranger_things_example(gpu_required):
+    """cli/examples/02_StrangerThings.js:10-31 (the reference's own example patch, also the 69-node voice of
+    hashing.test.js) rendered on both engines, two channels, 3 s of audio at the cli's sample rate."""
+    from test_reconciler import stranger_things_voice
+    hip, chk = _engines()
+    a, b = render_pair(hip, chk, lambda: [stranger_things_voice(), stranger_things_voice()], sample_rate=44100.0, blocks=260)
+    assert np.abs(b).max() > 0.05
+    scale = max(1.0, float(np.abs(b).max()))
+    assert float(np.abs(a - b).max()) <= TOL * scale

@@ -1,0 +1,160 @@
+"""Run-time specialised island kernels (elementary_amd/csrc/jit.cpp, codegen.cpp, island_spec.inc) vs the reference
+engine and vs the interpreter kernels. Every test forces `specialize = 2` (commit waits for the compiler), renders
+through elemhip_process_blocks (the only path that uses the specialised kernels) and checks that they actually ran.
+Tolerance 1e-6 absolute (x max|ref| when > 1); the interpreter and the specialised kernels share their op bodies, so
+everything that is not a libm transcendental is expected to be bit-identical between the two."""
+import numpy as np
+import pytest
+
+from elementary_amd import el, graphs
+from helpers import lcg_noise
+from cases import NODE_CASES, node_case_resources
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _checker(sr, bs):
+    import oracle
+    return oracle.RefRuntime(sr, bs) if oracle.have_ref() else oracle.PortRuntime(sr, bs)
+
+
+def _spec_runtime(sr, bs, batch=None, copies=None):
+    from elementary_amd.runtime import Runtime
+    rt = Runtime(sr, bs, device=0)
+    rt.set_option("specialize", 2)
+    if batch is not None:
+        rt.set_option("batch_blocks", batch)
+    if copies is not None:
+        rt.set_option("pipeline_copies", copies)
+    return rt
+
+
+def _render_blocks(rt, nb, n_out, x=None, block=512):
+    import torch
+    out = torch.zeros((nb, n_out, block), dtype=torch.float32, device="cuda")
+    if x is not None:
+        xin = torch.from_numpy(x).cuda()
+        torch.cuda.synchronize()
+        rt.process_blocks(nb, n_out, out_ptr=out.data_ptr(), in_ptr=xin.data_ptr(), num_inputs=x.shape[1])
+    else:
+        torch.cuda.synchronize()
+        rt.process_blocks(nb, n_out, out_ptr=out.data_ptr())
+    return out.cpu().numpy()
+
+
+def _assert_ran_specialised(rt):
+    st = rt.stats()
+    if st["spec_shapes"] > 0:
+        info = rt.spec_info(0)
+        assert info["state"] == 1, info["log"][:2000]
+        assert st["spec_launches"] > 0, st
+
+
+@pytest.mark.parametrize("name", sorted(NODE_CASES))
+def test_spec_node_case(gpu_required, name):
+    """Every node case: specialised multi-block launches (5 blocks per launch, 17 blocks) vs the reference engine block by
+    block, and vs the interpreter kernels of a second HIP engine."""
+    from elementary_amd.runtime import Runtime
+    roots_fn, n_in = NODE_CASES[name]
+    nb = 17
+    a, b, c = _spec_runtime(44100.0, 512, batch=5), Runtime(44100.0, 512), _checker(44100.0, 512)
+    b.set_option("specialize", 0)
+    for rt in (a, b, c):
+        for rname, data in node_case_resources().items():
+            assert rt.add_shared_resource(rname, data)
+    roots = roots_fn()
+    n_out = len(roots)
+    for rt in (a, b, c):
+        assert rt.render(*roots)["result"] == 0
+    x = np.stack([np.stack([lcg_noise(512, 1 + ch + 97 * k, 0.5) for ch in range(max(n_in, 1))]) for k in range(nb)])
+    got = _render_blocks(a, nb, n_out, x)
+    interp = np.stack([b.process(x[k], n_out, 512) for k in range(nb)])
+    ref = np.stack([c.process(x[k] if n_in else None, n_out, 512) for k in range(nb)])
+    _assert_ran_specialised(a)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.isfinite(got).all()
+    assert float(np.abs(got - ref).max()) <= TOL * scale, f"{name}: specialised vs reference {np.abs(got - ref).max():.3e}"
+    assert float(np.abs(got - interp).max()) <= TOL * scale, f"{name}: specialised vs interpreter {np.abs(got - interp).max():.3e}"
+
+
+def test_spec_c2_full_graph(gpu_required):
+    """BASELINE configs[1] at full size through the specialised kernels: 4107 nodes, 256 voices = one island shape, 200 blocks."""
+    a, c = _spec_runtime(graphs.C2_SAMPLE_RATE, 512), _checker(graphs.C2_SAMPLE_RATE, 512)
+    roots = graphs.c2_graph()
+    assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
+    st = a.stats()
+    assert st["spec_shapes"] == 1 and st["spec_islands"] == 256, st
+    got = _render_blocks(a, 200, 2)
+    ref = np.stack([c.process(None, 2, 512) for _ in range(200)])
+    _assert_ran_specialised(a)
+    err = float(np.abs(got - ref).max())
+    assert err <= TOL, f"C2 specialised: max abs err {err:.3e}, max|ref| {np.abs(ref).max():.3f}"
+
+
+def test_spec_c4_instances(gpu_required):
+    a, c = _spec_runtime(graphs.C4_SAMPLE_RATE, 512), _checker(graphs.C4_SAMPLE_RATE, 512)
+    roots = [graphs.c4_instance(k) for k in range(8)]
+    assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
+    got = _render_blocks(a, 60, 8)
+    ref = np.stack([c.process(None, 8, 512) for _ in range(60)])
+    _assert_ran_specialised(a)
+    assert float(np.abs(got - ref).max()) <= TOL
+
+
+@pytest.mark.parametrize("copies", [1, 3, 6])
+def test_spec_every_stateful_node_pipelined(gpu_required, copies):
+    """One graph with every stateful node type, host inputs and time-dependent nodes, through specialised launches with
+    1, 3 and 6 blocks in flight: equal to the interpreter's block-by-block rendering (same op bodies)."""
+    from elementary_amd.runtime import Runtime
+    X = el.in_({"channel": 0})
+
+    def roots():
+        v = el.lowpass(el.add(900, el.mul(700, el.cycle(2.0))), 1.5, el.add(el.blepsaw(110.0), el.mul(0.5, X)))
+        w = el.delay({"size": 3000}, el.add(1000.5, el.mul(300, el.cycle(0.5))), 0.4, el.pole(0.95, X))
+        z = el.mul(el.adsr(0.002, 0.01, 0.5, 0.02, el.train(9.0)), el.pinknoise({"seed": 3}))
+        t = el.add(el.mul(1e-5, el.time()), el.metro({"interval": 7.0}), el.sdelay({"size": 700}, X), el.z(X))
+        s = el.add(el.biquad(0.2, 0.3, 0.2, -0.5, 0.2, X), el.mm1p({"mode": "lowpass"}, el.prewarp(800.0), X),
+                   el.env(el.tau2pole(0.001), el.tau2pole(0.05), X), el.latch(el.train(60.0), X),
+                   el.seq({"seq": [1, 2, 3, 5.5], "hold": True}, el.train(200.0), 0), el.counter(el.train(50.0)),
+                   el.maxhold({"hold": 3.0}, el.abs(X), el.train(9.0)), el.accum(el.abs(X), el.train(20.0)),
+                   el.highshelf(4000, 0.7, -4.5, X), el.syncphasor(440.0, el.train(37.0)), el.bleptriangle(523.25))
+        return [el.tanh(el.add(v, w)), el.add(z, t), s]
+    nb = 53
+    x = np.stack([np.stack([lcg_noise(512, 7 + k, 0.5)]) for k in range(nb)])
+    a, b = _spec_runtime(48000.0, 512, batch=12, copies=copies), Runtime(48000.0, 512)
+    b.set_option("specialize", 0)
+    assert a.render(*roots())["result"] == 0 and b.render(*roots())["result"] == 0
+    got = _render_blocks(a, nb, 3, x)
+    ref = np.stack([b.process(x[k], 3, 512) for k in range(nb)])
+    _assert_ran_specialised(a)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(got - ref).max()) <= TOL * scale, float(np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("seed", range(0, 48, 3))
+def test_spec_random_graph(gpu_required, seed):
+    from test_gpu_fuzz import random_graph
+    nb, n_out = 22, min(3, 1 + seed % 5)
+    x = np.stack([np.stack([lcg_noise(512, 11 + 7 * k + ch, 0.5) for ch in range(2)]) for k in range(nb)])
+    a, c = _spec_runtime(48000.0, 512, batch=5 + seed % 7), _checker(48000.0, 512)
+    for rt in (a, c):
+        assert rt.render(*random_graph(seed, n_nodes=24 + 22 * (seed % 4), n_roots=1 + seed % 5)[:n_out])["result"] == 0
+    got = _render_blocks(a, nb, n_out, x)
+    ref = np.stack([c.process(x[k], n_out, 512) for k in range(nb)])
+    _assert_ran_specialised(a)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(got - ref).max()) <= TOL * scale, f"seed {seed}: {np.abs(got - ref).max():.3e}"
+
+
+def test_spec_falls_back_while_compiling(gpu_required):
+    """specialize = 1: the first launches may go through the interpreter kernels, later ones through the specialised kernel;
+    the stream of samples is the same either way (state lives in the node records, not in the kernel)."""
+    from elementary_amd.runtime import Runtime
+    a, c = Runtime(48000.0, 512, device=0), _checker(48000.0, 512)
+    a.set_option("specialize", 1)
+    roots = graphs.c2_graph(voices=16)
+    assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
+    got = np.concatenate([_render_blocks(a, 24, 2) for _ in range(12)])
+    ref = np.stack([c.process(None, 2, 512) for _ in range(24 * 12)])
+    assert float(np.abs(got - ref).max()) <= TOL

@@ -1,0 +1,62 @@
+"""Fill the on-disk kernel cache (elementary_amd/kcache/) with the specialised island kernels of the graphs the test
+suite and the benchmarks render, by building their plans on a dry engine (no GPU needed: hiprtc cross-compiles for
+gfx950). The cache travels with the tree; a miss only costs the compile at first use.
+Usage: python tools/warm_kcache.py [bench|tests|all]"""
+import os as _os, sys as _sys; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))); _sys.path[:0] = [_R, _os.path.join(_R, 'tests')]
+import sys
+import time
+
+import torch  # noqa: F401  (first: the GPU-side processes import torch before the engine, and hiprtc binds accordingly)
+
+from elementary_amd import el, graphs
+from elementary_amd.runtime import Runtime
+
+
+def warm(sr, bs, roots, resources=None, batch=None, copies=None):
+    rt = Runtime(sr, bs, device=-1)
+    rt.set_option("specialize", 2)
+    if copies is not None:
+        rt.set_option("pipeline_copies", copies)
+    for name, data in (resources or {}).items():
+        rt.add_shared_resource(name, data)
+    res = rt.render(*roots)
+    assert res["result"] == 0, res["result"]
+    st = rt.stats()
+    k, bad = 0, 0
+    while k < st["spec_shapes"]:
+        info = rt.spec_info(k)
+        if info["state"] != 1:
+            bad += 1
+            print(info["log"][:1500])
+        k += 1
+    return st["spec_shapes"], bad, st["last_jit_wait_ms"]
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    t0 = time.time()
+    shapes = bad = 0
+    jobs = []
+    if what in ("bench", "all"):
+        jobs.append(("c2", graphs.C2_SAMPLE_RATE, 512, graphs.c2_graph(voices=8), None, None))
+        jobs.append(("c4", graphs.C4_SAMPLE_RATE, 512, [graphs.c4_instance(k) for k in range(8)], None, None))
+        jobs.append(("c1", graphs.C1_SAMPLE_RATE, 512, graphs.c1_graph(), None, None))
+    if what in ("tests", "all"):
+        from cases import NODE_CASES, node_case_resources
+        from test_gpu_fuzz import random_graph
+        for name in sorted(NODE_CASES):
+            jobs.append((name, 44100.0, 512, NODE_CASES[name][0](), node_case_resources(), None))
+        for seed in range(0, 48, 3):
+            n_out = min(3, 1 + seed % 5)
+            jobs.append((f"fuzz{seed}", 48000.0, 512, random_graph(seed, n_nodes=24 + 22 * (seed % 4), n_roots=1 + seed % 5)[:n_out], None, None))
+        jobs.append(("c2x16", 48000.0, 512, graphs.c2_graph(voices=16), None, None))
+    for name, sr, bs, roots, res, copies in jobs:
+        s, b, ms = warm(sr, bs, roots, res, copies=copies)
+        shapes += s; bad += b
+        print(f"{name:28s} shapes {s}  failed {b}  waited {ms:8.0f} ms", flush=True)
+    print(f"{shapes} shapes, {bad} failed, {time.time() - t0:.1f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
