@@ -65,6 +65,7 @@ def c1(args):
     from elementary_amd import graphs
     from elementary_amd.runtime import Runtime
     rt = Runtime(44100.0, BLOCK, device=0)
+    rt.set_option("specialize", args.specialize)
     assert rt.render(*graphs.c1_graph())["result"] == 0
     g = _time_gpu(rt, 0, 2, args.blocks)
     cpu, kind = _cpu_engine(44100.0)
@@ -111,6 +112,7 @@ def c4(args):
     from elementary_amd.runtime import Runtime
     inst = args.instances
     rt = Runtime(graphs.C4_SAMPLE_RATE, BLOCK, device=0)
+    rt.set_option("specialize", args.specialize)
     roots = [graphs.c4_instance(k) for k in range(inst)]
     t0 = time.perf_counter()
     assert rt.render(*roots)["result"] == 0
@@ -125,53 +127,88 @@ def c4(args):
     return {"config": f"C4 {inst} independent offline render instances on one GPU (of 1024 over 8), sr 48000",
             "gpu_us_per_block_step": 1e6 * g, "gpu_instance_samples_per_s": inst * BLOCK / g,
             "cpu_us_per_block_step_1core": 1e6 * c_all, "cpu_kind": kind, "cpu_sample": f"{sub} instances x {m} blocks, scaled to {inst}",
-            "speedup_vs_1core": c_all / g, "launch_us": [1e3 * v for v in lv], "plan_build_ms": 1e3 * build,
+            "speedup_vs_1core": c_all / g, "launch_us": [1e3 * v for v in lv], "plan_build_ms": 1e3 * build, "specialize": args.specialize,
+            "spec_launches": rt.stats()["spec_launches"],
             "algorithmic_bytes_per_block_step": graphs.c4_algorithmic_bytes(inst)}
 
 
+def _c5_batches(voices, count):
+    """The instruction stream of config 5, generated ahead of the timed region (the reference's JS frontend is not part of
+    the path being measured): batch 0 mounts the 128-voice graph, every later batch replaces one voice the way the
+    reconciler does (new voice nodes, a new mix add and a new root per channel). Returns JSON texts + CREATE_NODE counts."""
+    from elementary_amd import el, graphs
+    from elementary_amd.reconciler import Renderer, batch_to_json
+    sent = []
+    r = Renderer(lambda b: sent.append(b) or 0)
+    gen = [0] * voices
+
+    def roots():
+        vs = [graphs.c2_voice(s + voices * gen[s]) for s in range(voices)]
+        return [el.add(*[vs[s] for s in range(voices) if s % 2 == ch]) for ch in range(2)]
+    r.render(*roots())
+    for b in range(count):
+        gen[(b * 37) % voices] += 1
+        r.render(*roots())
+    return [batch_to_json(b) for b in sent], [sum(1 for i in b if i[0] == 0) for b in sent], [len(b) for b in sent]
+
+
 def c5(args):
-    """Dynamic graph: 128 live C2 voices; each batch replaces one voice the way the reconciler does
-    (new voice nodes + new mix adds + new roots), gc() every 16 batches."""
+    """Dynamic graph (BASELINE configs[4]): a live 128-voice graph (~2060 nodes) renders as fast as it can
+    while a mutation stream PACED BY THE WALL CLOCK replaces one voice per batch, 28 batches per second (~1000 node adds
+    + as many removals per second); gc() every 16 batches. Reported: frames/s static and under mutation, commit -> first
+    block of the new graph (apply_instructions + the first block), plan rebuild, hipGraph re-capture; the reference
+    engine beside it under the same protocol."""
+    import torch
     from elementary_amd import graphs
     from elementary_amd.runtime import Runtime
-    voices = 128
-    rt = Runtime(graphs.C2_SAMPLE_RATE, BLOCK, device=0)
+    voices, rate = 128, 28.0
+    texts, creates, sizes = _c5_batches(voices, args.batches)
+    out = torch.empty((64, 2, BLOCK), dtype=torch.float32, device="cuda")
 
-    def roots_for(gen):
-        # voice slot s plays voice index s + 128 * (number of times it was replaced)
-        vs = [graphs.c2_voice(s + voices * gen[s]) for s in range(voices)]
-        from elementary_amd import el
-        return [el.add(*[vs[s] for s in range(voices) if s % 2 == ch]) for ch in range(2)]
-    gen = [0] * voices
-    assert rt.render(*roots_for(gen))["result"] == 0
-    static = _time_gpu(rt, 0, 2, 2048)
-    commit_ms, first_block_ms, nodes_added = [], [], []
-    t_start = time.perf_counter()
-    blocks = 0
-    for b in range(args.batches):
-        gen[b % voices] += 1
+    def drive(rt, render_chunk, seconds):
+        assert rt.apply_instructions_json(texts[0]) == 0
+        for _ in range(8):
+            render_chunk(64)                       # settle the root fades, warm the plan
         t0 = time.perf_counter()
-        res = rt.render(*roots_for(gen))
-        t1 = time.perf_counter()
-        assert res["result"] == 0
-        rt.process(None, 2, BLOCK)
-        t2 = time.perf_counter()
-        commit_ms.append(1e3 * (t1 - t0)); first_block_ms.append(1e3 * (t2 - t1)); nodes_added.append(res["nodesAdded"])
-        rt.process_blocks(32, 2)
-        blocks += 33
-        if b % 16 == 15:
-            rt.gc()
-    total = time.perf_counter() - t_start
-    commit_ms.sort(); first_block_ms.sort()
-    pct = lambda a, q: a[min(len(a) - 1, int(q * len(a)))]
+        n = 0
+        while time.perf_counter() - t0 < 1.0:
+            render_chunk(64); n += 64
+        static = n * BLOCK / (time.perf_counter() - t0)
+        lat, applied, frames = [], 0, 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            due = int((time.perf_counter() - t0) * rate)
+            if applied < min(due, len(texts) - 1):
+                applied += 1
+                ta = time.perf_counter()
+                assert rt.apply_instructions_json(texts[applied]) == 0
+                render_chunk(1)                    # the first block rendered by the new render sequence
+                lat.append(1e3 * (time.perf_counter() - ta))
+                frames += BLOCK
+                if applied % 16 == 0:
+                    rt.gc()
+            else:
+                render_chunk(64); frames += 64 * BLOCK
+        dt = time.perf_counter() - t0
+        lat.sort()
+        pct = lambda a, q: a[min(len(a) - 1, int(q * len(a)))] if a else None
+        return {"static_frames_per_s": static, "mutating_frames_per_s": frames / dt, "ratio": frames / dt / static, "batches_applied": applied,
+                "commit_to_first_block_ms_p50": pct(lat, 0.5), "commit_to_first_block_ms_p99": pct(lat, 0.99)}
+
+    rt = Runtime(graphs.C2_SAMPLE_RATE, BLOCK, device=0)
+    rt.set_option("specialize", args.specialize)
+    gpu = drive(rt, lambda k: rt.process_blocks(k, 2, out_ptr=out.data_ptr()), args.seconds)
     st = rt.stats()
-    return {"config": "C5 dynamic graph: 128 live voices (~2060 nodes), one voice replaced per batch, gc every 16",
-            "static_us_per_block": 1e6 * static, "batches": args.batches, "nodes_added_per_batch": sum(nodes_added) / len(nodes_added),
-            "render_call_ms_p50": pct(commit_ms, 0.5), "render_call_ms_p99": pct(commit_ms, 0.99),
-            "first_block_after_commit_ms_p50": pct(first_block_ms, 0.5), "first_block_after_commit_ms_p99": pct(first_block_ms, 0.99),
-            "plan_build_ms_last": st["last_plan_build_ms"], "frames_per_s_under_mutation": blocks * BLOCK / total,
-            "note": "render call = Python reconciler + JSON + apply_instructions (graph mutation + plan build + upload); "
-                    "33 blocks rendered per batch"}
+    cpu, kind = _cpu_engine(graphs.C2_SAMPLE_RATE)
+    ref = drive(cpu, lambda k: [cpu.process(None, 2, BLOCK) for _ in range(k)], min(args.seconds, 4.0))
+    return {"config": "C5 dynamic graph: 128 live voices (~2060 nodes), one voice replaced per batch, 28 batches per wall-clock second, gc every 16",
+            "instructions_per_batch": sum(sizes[1:]) / max(1, len(sizes) - 1), "nodes_created_per_batch": sum(creates[1:]) / max(1, len(creates) - 1),
+            "node_adds_per_second": rate * sum(creates[1:]) / max(1, len(creates) - 1),
+            "gpu": gpu, "plan_build_ms_last": st["last_plan_build_ms"], "hipgraph_capture_ms_last": st["last_graph_capture_ms"],
+            "hipgraph_captures": st["graph_captures"], "plans_built": st["plans_built"],
+            "cpu_reference": ref, "cpu_kind": kind,
+            "note": "instruction batches are generated before the timed region; commit -> first block = apply_instructions (graph "
+                    "mutation + full plan build + upload) + one block through the per-block launch path while the roots cross-fade"}
 
 
 def main():
@@ -182,7 +219,9 @@ def main():
     ap.add_argument("configs", nargs="*", default=["c1", "c3", "c4", "c5"])
     ap.add_argument("--blocks", type=int, default=2048)
     ap.add_argument("--instances", type=int, default=128)
-    ap.add_argument("--batches", type=int, default=64)
+    ap.add_argument("--batches", type=int, default=400)
+    ap.add_argument("--seconds", type=float, default=8.0)
+    ap.add_argument("--specialize", type=int, default=2)
     args = ap.parse_args()
     for name in args.configs:
         out = {"c1": c1, "c3": c3, "c4": c4, "c5": c5}[name](args)

@@ -156,7 +156,7 @@ int elemhip_get_stats(elemhip_t* h, elemhip_stats* out) {
     out->graph_replays = s.graphReplays; out->graph_captures = s.graphCaptures;
     out->batch_launches = s.batchLaunches;
     out->spec_launches = s.specLaunches; out->spec_shapes = s.specShapes; out->spec_islands = s.specIslands;
-    out->last_jit_wait_ms = s.lastJitWaitMs;
+    out->last_jit_wait_ms = s.lastJitWaitMs; out->last_graph_capture_ms = s.lastGraphCaptureMs;
     return elemhip::kOk;
 }
 

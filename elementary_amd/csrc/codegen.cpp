@@ -21,17 +21,27 @@ static std::string u(uint32_t v) {
     char b[32]; std::snprintf(b, sizeof b, "%uu", v); return b;
 }
 
+// Arena buffer indices differ between the instances of a shape: the text names position k of the island's arena table
+// (appended to its program blob, staged in LDS with it) instead of the index itself.
+static std::string arenaRef(const SpecProgram& sp, uint32_t abs, uint32_t tabWord) {
+    for (size_t k = 0; k < sp.hbmTab.size(); ++k) if (sp.hbmTab[k] == abs) return "UNI(ldsu(" + u(tabWord + (uint32_t)k) + "))";
+    return "0u";
+}
+
 // operand code -> expression of (c, off)
-static std::string opndExpr(uint32_t code, uint32_t opndIndex) {
+static std::string opndExpr(const SpecProgram& sp, uint32_t code, uint32_t tabWord) {
     const uint32_t kind = code & kOpKindMask, v = code & kOpValMask;
     if (kind == kOpLds)   return "((kOpLds | " + u(v) + ") + off)";
     if (kind == kOpConst) return "(kOpConst | " + u(v) + ")";
-    if (kind == kOpHbm)   return "UNI(ldsu(c.operands + " + u(opndIndex) + "))";   // arena index: differs per island instance
+    if (kind == kOpHbm)   return "(kOpHbm | (" + arenaRef(sp, v, tabWord) + " & kOpValMask))";   // (the mask lets the compiler see the kind bits)
     return "(uint32_t)kOpZero";
 }
 
-std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, const std::vector<Member>& members,
-                           const std::vector<uint32_t>& operands, const std::vector<uint32_t>& stageTab, uint32_t blockSize) {
+std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, const SpecProgram& sp,
+                           const std::vector<uint32_t>& stageTab, uint32_t blockSize) {
+    const std::vector<Member>& members = sp.members;
+    const std::vector<uint32_t>& operands = sp.operands;
+    const uint32_t tabWord = I.ldsProg + I.recOff + I.numRecs;   // LDS word of the staged arena table
     std::ostringstream o;
     const uint32_t S = I.numStages;
     uint32_t lastStage = S - 1u;
@@ -42,6 +52,7 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
         o << "struct T" << q << " {\n";
         o << "    static constexpr uint32_t opcode = " << t.opcode << "u, flags = " << (uint32_t)(t.flags & 0x3Fu) << "u, s0 = " << t.s0
           << "u, s1 = " << t.s1 << "u, count = " << t.count << "u;\n";
+        o << "    static constexpr bool gdirect = " << (sp.gdirect[q] ? "true" : "false") << ";\n";
         o << "    template <int K> static __device__ __forceinline__ Member member(const Ctx& c, uint32_t off) {\n        Member m;\n";
         for (uint32_t k = 0; k < t.count; ++k) {
             const uint32_t mi = t.first + k;
@@ -50,10 +61,14 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
             o << "        " << (k ? "else " : "") << "if constexpr (K == " << k << ") {\n";
             o << "            m.rec = " << u(m.rec) << "; m.opnd = " << u(m.opnd) << "; m.nin = " << u(m.nin) << ";\n";
             o << "            m.outLds = " << (m.outLds == kNone ? std::string("kNone") : u(m.outLds) + " + off") << ";\n";
-            o << "            m.outHbm = " << (m.outHbm == kNone ? std::string("kNone") : "UNI(ldsu(c.members + " + u(mi * 8u + 4u) + "))") << ";\n";
+            o << "            m.outHbm = " << (m.outHbm == kNone ? std::string("kNone") : arenaRef(sp, m.outHbm, tabWord)) << ";\n";
             o << "            m.scratch = " << (m.scratch == kNone ? std::string("kNone") : u(m.scratch) + " + off") << ";\n";
-            for (uint32_t j = 0; j < 6; ++j)
-                o << "            m.sops[" << j << "] = " << (j < nops ? opndExpr(operands[m.opnd + j], m.opnd + j) : std::string("(uint32_t)kOpZero")) << ";\n";
+            for (uint32_t j = 0; j < 6; ++j) {
+                std::string e = j < nops ? opndExpr(sp, operands[m.opnd + j], tabWord) : std::string("(uint32_t)kOpZero");
+                if (j == 5 && nops <= 5 && (sp.phaseOp[mi] & kOpKindMask) == kOpHbm) e = opndExpr(sp, sp.phaseOp[mi], tabWord);   // streamed oscillator phase
+                o << "            m.sops[" << j << "] = " << e << ";\n";
+            }
+            o << "            m.gdirect = " << (sp.gdirect[q] ? "1u" : "0u") << ";\n";
             o << "        }\n";
         }
         o << "        m.pad0_ = m.sops[0]; m.pad1_ = m.sops[1]; m.off = off;\n        return m;\n    }\n";
@@ -75,19 +90,23 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
             const uint32_t st = stages[stages.size() - 1 - (size_t)j];
             const uint32_t prev = stageTab[S + st];
             uint32_t ntasks = 0;
+            bool writes = false;     // the slot stores into arena buffers (read by other waves of the same launch, or by later launches)
             o << "template <> struct Slot<" << w << ", " << j << "> {\n";
             std::ostringstream body;
             for (uint32_t q = I.waveTask[w]; q < I.waveTask[w + 1]; ++q)
-                if (tasks[q].stage == st) { body << "        spec_task<T" << q << ">(c, off);\n"; ++ntasks; }
+                if (tasks[q].stage == st) {
+                    body << "        spec_task<T" << q << ">(c, off);\n"; ++ntasks;
+                    for (uint32_t k = 0; k < tasks[q].count; ++k) if (members[tasks[q].first + k].outHbm != kNone) writes = true;
+                }
             o << "    static constexpr uint32_t stage = " << st << "u, prev = " << u(prev) << ", prevT = " << (prev == kNone ? 0u : stageTab[prev])
-              << "u, ntasks = " << ntasks << "u;\n";
+              << "u, ntasks = " << ntasks << "u;\n    static constexpr bool writesStreams = " << (writes ? "true" : "false") << ";\n";
             o << "    static __device__ __forceinline__ void run(const Ctx& c, uint32_t off) {\n" << body.str() << "    }\n};\n";
         }
     }
     o << "struct P {\n    static constexpr uint32_t S = " << S << "u, D = " << I.copies << "u, slotArea = " << I.slotArea << "u, ldsProg = " << I.ldsProg
       << "u, memOff = " << I.memOff << "u, opndOff = " << I.opndOff << "u, cellOff = " << I.cellOff << "u, numCells = " << I.numCells
       << "u, recOff = " << I.recOff << "u, numRecs = " << I.numRecs << "u, progDwords = " << I.progDwords << "u, ldsCounters = " << I.ldsCounters
-      << "u, ldsRecs = " << I.ldsRecs << "u, lastStage = " << lastStage << "u, lastT = " << stageTab[lastStage] << "u, block = " << blockSize << "u;\n";
+      << "u, ldsRecs = " << I.ldsRecs << "u, specOpndOff = " << (I.recOff + I.numRecs + (uint32_t)sp.hbmTab.size()) << "u, lastStage = " << lastStage << "u, lastT = " << stageTab[lastStage] << "u, block = " << blockSize << "u;\n";
     o << "    static constexpr int waveSlots[8] = {";
     for (uint32_t w = 0; w < kWaves; ++w) o << (w ? ", " : "") << waveSlots[w];
     o << "};\n};\n} // namespace gen\n";

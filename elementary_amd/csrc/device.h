@@ -82,6 +82,7 @@ struct Member {
     // travel with it (already moved to the block's buffer set), `off` = LDS word offset of that buffer set
     uint32_t sops[6];
     uint32_t off;
+    uint32_t gdirect;    // recurrence member: the block goes straight to HBM arena buffer `outHbm` (no LDS copy of it exists)
 #endif
 };
 

@@ -1503,6 +1503,7 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
                 if (p.graphExec) { (void)hipGraphExecDestroy(p.graphExec); p.graphExec = nullptr; }
                 hipGraph_t graph = nullptr;
                 HIP_OK(hipStreamSynchronize(stream));
+                const auto tc0 = std::chrono::steady_clock::now();
                 HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
                 for (size_t b = 0; b < G; ++b) enqueueBlock(p);
                 HIP_OK(hipStreamEndCapture(stream, &graph));
@@ -1510,6 +1511,7 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
                 (void)hipGraphDestroy(graph);
                 p.graphBlocks = (int)G;
                 st.graphCaptures++;
+                st.lastGraphCaptureMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
             }
             HIP_OK(hipGraphLaunch(p.graphExec, stream));
             st.graphReplays++;

@@ -95,6 +95,7 @@ struct Stats {
     uint64_t specLaunches = 0;             // launches of run-time specialised island kernels
     uint32_t specShapes = 0, specIslands = 0;
     double   lastJitWaitMs = 0.0;
+    double   lastGraphCaptureMs = 0.0;     // capture + instantiate of the per-block hipGraph of the current plan
 };
 
 class Engine {
@@ -234,6 +235,15 @@ private:
     int  setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime);
     void setInRing(const float* ring, uint32_t blocks);
     std::shared_ptr<Plan> buildPlan();
+};
+
+// The specialised-kernel variant of one island's program (plan.cpp builds it, codegen.cpp turns it into text).
+struct SpecProgram {
+    std::vector<Member> members;           // same indexing as the interpreter's tables
+    std::vector<uint32_t> operands;
+    std::vector<uint8_t> gdirect;          // per task: a recurrence that streams its block straight to the arena
+    std::vector<uint32_t> phaseOp;         // per member: waveform tasks of streamed oscillators read the phase from here
+    std::vector<uint32_t> hbmTab;          // absolute arena indices named by the variant (appended to the island's blob)
 };
 
 // plan.cpp

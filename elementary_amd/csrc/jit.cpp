@@ -155,6 +155,15 @@ std::string Jit::fullSource(const std::string& generated, uint32_t ldsWords) {
     std::string s;
     s.reserve(sizeof(kSpecDeviceH) + sizeof(kSpecOpsInc) + sizeof(kSpecInc) + generated.size() + 256);
     s += "#define ELEMHIP_SPEC 1\n#define ELEMHIP_SPEC_LDS_WORDS " + std::to_string(ldsWords) + "\n";
+    if (const char* d = std::getenv("ELEMHIP_JIT_DEFINES")) {   // tuning experiments: "NAME=VALUE NAME2=VALUE2" -> #define lines (part of the cache key)
+        std::string t = d, tok;
+        for (size_t i = 0; i <= t.size(); ++i) {
+            if (i == t.size() || t[i] == ' ') {
+                if (!tok.empty()) { const size_t eq = tok.find('='); s += "#define " + (eq == std::string::npos ? tok + " 1" : tok.substr(0, eq) + " " + tok.substr(eq + 1)) + "\n"; }
+                tok.clear();
+            } else tok += t[i];
+        }
+    }
     // hiprtc has no host headers: the fixed-width names the sources use (same underlying types as <stdint.h> on this target)
     s += "typedef unsigned char uint8_t; typedef unsigned short uint16_t; typedef unsigned int uint32_t; typedef unsigned long uint64_t;\n"
          "typedef signed char int8_t; typedef short int16_t; typedef int int32_t; typedef long int64_t; typedef unsigned long uintptr_t;\n";

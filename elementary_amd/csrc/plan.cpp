@@ -78,8 +78,8 @@ bool blepSplit(uint16_t op) { return op == OP_BLEPSAW || op == OP_BLEPSQUARE; }
 uint32_t leafArityOfOp(uint16_t op);
 } // namespace
 uint32_t leafArityForCodegen(uint16_t op) { return leafArityOfOp(op); }
-std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, const std::vector<Member>& members,
-                           const std::vector<uint32_t>& operands, const std::vector<uint32_t>& stageTab, uint32_t blockSize);   // codegen.cpp
+std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, const SpecProgram& sp,
+                           const std::vector<uint32_t>& stageTab, uint32_t blockSize);   // codegen.cpp
 namespace {
 uint32_t leafArityOfOp(uint16_t op) {
     if (op == OP_SAW_SHAPE || op == OP_SQUARE_SHAPE) return 1;
@@ -584,6 +584,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         std::vector<int> taskWave;               // executing wave of tasks[i]
         std::vector<Member> members;
         std::vector<uint32_t> operands;
+        std::vector<int> memberNode;             // NI index of members[i] (-1: an import copy)
+        std::vector<int> operandSrc;             // operands[i]: NI index of the in-island producer, -2 - import index for an imported buffer, -1 otherwise
         std::vector<ConstCell> cells;
         // broadcast cells for const-like producers
         std::unordered_map<uint32_t, uint32_t> cellOf;   // rec -> lds word
@@ -607,6 +609,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         };
         auto makeMember = [&](NI& x) -> Member {
             Member m{};
+            memberNode.push_back((int)(&x - ni.data()));
             m.rec = localOf(x.n->rec);
             m.opnd = (uint32_t)operands.size();
             m.outLds = x.needLds ? x.lds : kNone;
@@ -616,20 +619,20 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 m.nin = kNone;
                 const uint32_t ar = std::min<uint32_t>(leafArity(x.n->op), kMaxHostIn);
                 for (uint32_t c = 0; c < ar; ++c) {
-                    if (x.kind == K_CHAIN) operands.push_back(kOpLds | imports[importFor(c)].lds);
-                    else operands.push_back(kOpHbm | c);
+                    if (x.kind == K_CHAIN) { operandSrc.push_back(-2 - importFor(c)); operands.push_back(kOpLds | imports[importFor(c)].lds); }
+                    else { operandSrc.push_back(-1); operands.push_back(kOpHbm | c); }
                 }
                 return m;
             }
             m.nin = (uint32_t)x.n->inlets.size();
             for (auto& in : x.n->inlets) {
                 auto it = idx.find(in.source);
-                if (it == idx.end() || in.channel != 0) { operands.push_back(kOpZero); continue; }
+                if (it == idx.end() || in.channel != 0) { operandSrc.push_back(-1); operands.push_back(kOpZero); continue; }
                 NI& s = ni[it->second];
-                if (s.kind == K_CONST) operands.push_back(kOpConst | cellFor(s.n));
-                else if (s.island == x.island) operands.push_back(kOpLds | s.lds);
-                else if (x.kind == K_CHAIN) operands.push_back(kOpLds | imports[importFor(s.hbm)].lds);
-                else operands.push_back(kOpHbm | s.hbm);
+                if (s.kind == K_CONST) { operandSrc.push_back(-1); operands.push_back(kOpConst | cellFor(s.n)); }
+                else if (s.island == x.island) { operandSrc.push_back(it->second); operands.push_back(kOpLds | s.lds); }
+                else if (x.kind == K_CHAIN) { operandSrc.push_back(-2 - importFor(s.hbm)); operands.push_back(kOpLds | imports[importFor(s.hbm)].lds); }
+                else { operandSrc.push_back(-1); operands.push_back(kOpHbm | s.hbm); }
             }
             return m;
         };
@@ -666,7 +669,9 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             for (auto& im : imports) {
                 Member m{};
                 m.rec = 0; m.opnd = (uint32_t)operands.size(); m.nin = 1; m.outLds = im.lds; m.outHbm = kNone; m.scratch = kNone;
+                operandSrc.push_back(-1);
                 operands.push_back(kOpHbm | im.hbm);
+                memberNode.push_back(-1);
                 members.push_back(m);
             }
             emitRanges(OP_COPY, 0, first, (uint32_t)imports.size(), {0, 1, 2, 3});
@@ -800,9 +805,14 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             for (size_t o : order) {
                 const Slot& sl = slots[o];
                 uint32_t& used = usedInStage[sl.stage];
+                // Waves w and w + 4 of the workgroup share a SIMD, and two busy waves on one SIMD slow each other once they mix
+                // memory instructions into their VALU stream (a lone-wave recurrence next to another recurrence: ~20 % slower
+                // than next to a light slot). Ties on the wave's own load go to the wave whose SIMD mate carries the least:
+                // the four heaviest slots land on four different SIMDs, the fifth joins the lightest of them.
                 int best = -1;
-                for (int w = 0; w < (int)kWaves; ++w) if (!((used >> w) & 1u) && (best < 0 || load[w] < load[best])) best = w;
-                if (best < 0) for (int w = 0; w < (int)kWaves; ++w) if (best < 0 || load[w] < load[best]) best = w;
+                auto better = [&](int w, int b) { return load[w] < load[b] || (load[w] == load[b] && load[w ^ 4] < load[b ^ 4]); };
+                for (int w = 0; w < (int)kWaves; ++w) if (!((used >> w) & 1u) && (best < 0 || better(w, best))) best = w;
+                if (best < 0) for (int w = 0; w < (int)kWaves; ++w) if (best < 0 || better(w, best)) best = w;
                 used |= 1u << best; load[best] += sl.cost;
                 remap[{sl.stage, sl.wave}] = best;
             }
@@ -952,6 +962,93 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             stageTab.insert(stageTab.end(), offs.begin(), offs.end());
             stageTab.insert(stageTab.end(), entries.begin(), entries.end());
         }
+        // ---- specialised-kernel variant of the program (codegen.cpp): recurrence streams through the HBM arena --------------
+        // On a lone wavefront every instruction costs ~4 cycles and an LDS access 12-50, so a specialised kernel moves the
+        // blocks a float recurrence reads and writes through L2 instead: inputs arrive by scalar loads (16 frames per
+        // instruction), outputs leave as lane-0 global stores. The interpreter program above is left as it is (same LDS
+        // layout); the variant only re-routes operands / outputs and names the arena buffers it needs extra.
+        SpecProgram sp;
+        const bool specIsland = wantSpec && !statelessIsland && bs % 64u == 0u;   // (vector loads of a 64-frame unit must stay inside their arena buffer)
+        if (specIsland) {
+            sp.members = members; sp.operands = operands;
+            sp.gdirect.assign(tasks.size(), 0);
+            std::unordered_map<int, uint32_t> streamOf;        // NI index -> arena buffer carrying the node's output
+            auto stream = [&](int k) -> uint32_t {
+                if (ni[k].exported) return ni[k].hbm;
+                auto it = streamOf.find(k);
+                if (it != streamOf.end()) return it->second;
+                const uint32_t b = p.numHbmBuffers++;
+                streamOf.emplace(k, b);
+                return b;
+            };
+            auto streamFamily = [&](const Task& t) {
+                switch (t.opcode) {
+                    case OP_PHASOR: case OP_SPHASOR: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_COUNTER: case OP_ACCUM:
+                    case OP_LATCH: case OP_MAXHOLD: return true;
+                    case OP_BLEPSAW: case OP_BLEPSQUARE: return (t.flags & 1u) != 0u;   // constant frequency: no in-place pre-pass
+                    default: return false;
+                }
+            };
+            std::unordered_map<int, uint32_t> phaseStream;      // split oscillator: arena buffer of its phase (recurrence -> waveform task)
+            std::unordered_set<int> streamed;                   // nodes whose output lives in the arena only (no LDS copy in the variant)
+            for (size_t q = 0; q < tasks.size(); ++q) {
+                const Task& t = tasks[q];
+                if (!streamFamily(t)) continue;
+                bool ok = true;
+                for (uint32_t k = 0; k < t.count; ++k) {
+                    const Member& m = members[t.first + k];
+                    if (m.nin == kNone || m.nin < leafArity(t.opcode) || memberNode[t.first + k] < 0) ok = false;
+                }
+                if (!ok) continue;
+                sp.gdirect[q] = 1;
+                for (uint32_t k = 0; k < t.count; ++k) {
+                    const uint32_t mi = t.first + k;
+                    const int x = memberNode[mi];
+                    const bool osc = blepSplit(t.opcode);
+                    uint32_t b;
+                    if (osc) { b = p.numHbmBuffers++; phaseStream.emplace(x, b); }
+                    else { b = stream(x); streamed.insert(x); }
+                    sp.members[mi].outHbm = b;
+                    for (uint32_t j = 0; j < members[mi].nin; ++j) {
+                        const uint32_t oi = members[mi].opnd + j;
+                        if ((operands[oi] & kOpKindMask) != kOpLds) continue;
+                        const int src = operandSrc[oi];
+                        if (src >= 0) sp.operands[oi] = kOpHbm | stream(src);
+                        else if (src <= -2) sp.operands[oi] = kOpHbm | imports[(size_t)(-2 - src)].hbm;
+                    }
+                }
+            }
+            // producers of streamed operands also write the arena; consumers of streamed nodes read it
+            for (size_t mi = 0; mi < members.size(); ++mi) {
+                const int x = memberNode[mi];
+                if (x < 0) continue;
+                auto it = streamOf.find(x);
+                if (it != streamOf.end() && sp.members[mi].outHbm == kNone) sp.members[mi].outHbm = it->second;
+            }
+            for (size_t oi = 0; oi < operands.size(); ++oi) {
+                const int src = operandSrc[oi];
+                if (src >= 0 && streamed.count(src) && (operands[oi] & kOpKindMask) == kOpLds) sp.operands[oi] = kOpHbm | stream(src);
+            }
+            // the waveform task of a streamed oscillator reads the phase from the arena (member operand slot 5)
+            sp.phaseOp.assign(members.size(), (uint32_t)kOpZero);
+            for (size_t q = 0; q < tasks.size(); ++q) {
+                if (tasks[q].opcode != OP_SAW_SHAPE && tasks[q].opcode != OP_SQUARE_SHAPE) continue;
+                for (uint32_t k = 0; k < tasks[q].count; ++k) {
+                    auto it = phaseStream.find(memberNode[tasks[q].first + k]);
+                    if (it != phaseStream.end()) sp.phaseOp[tasks[q].first + k] = kOpHbm | it->second;
+                }
+            }
+            // the oscillator's recurrence member and its waveform member are the same node: only the waveform member exports it
+            for (size_t q = 0; q < tasks.size(); ++q)
+                if (blepSplit(tasks[q].opcode) && !sp.gdirect[q])
+                    for (uint32_t k = 0; k < tasks[q].count; ++k) sp.members[tasks[q].first + k].outHbm = members[tasks[q].first + k].outHbm;
+            // arena table: every absolute arena index the variant names, in order of first appearance
+            auto ref = [&](uint32_t abs) { for (uint32_t v : sp.hbmTab) if (v == abs) return; sp.hbmTab.push_back(abs); };
+            for (const Member& m : sp.members) if (m.outHbm != kNone) ref(m.outHbm);
+            for (uint32_t o : sp.operands) if ((o & kOpKindMask) == kOpHbm) ref(o & kOpValMask);
+            for (uint32_t o : sp.phaseOp) if ((o & kOpKindMask) == kOpHbm) ref(o & kOpValMask);
+        }
+
         // pack the blob: copies x [tasks | members | operands] | cells | stage tables
         static_assert(sizeof(Task) == 32 && sizeof(Member) == 32 && sizeof(ConstCell) == 8, "program layout");
         I.progBegin = (uint32_t)p.prog.size();
@@ -968,7 +1065,9 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         I.schedOff = I.stageOff + schedRel;
         I.recOff = I.stageOff + (uint32_t)stageTab.size();
         I.numRecs = (uint32_t)recTable.size();
-        I.progDwords = I.recOff + I.numRecs;
+        // + the specialised variant's arena table and its operand table (same indexing as the interpreter's; wide fan-in ops
+        //   fetch operand codes from the staged table at run time)
+        I.progDwords = I.recOff + I.numRecs + (uint32_t)sp.hbmTab.size() + (uint32_t)sp.operands.size();
         p.prog.resize((size_t)I.progBegin + I.progDwords);
         for (uint32_t d = 0; d < copies; ++d) {
             const uint32_t off = d * slotArea;
@@ -989,6 +1088,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             if (!cells.empty()) std::memcpy(blob + I.cellOff, cells.data(), cells.size() * sizeof(ConstCell));
             std::memcpy(blob + I.stageOff, stageTab.data(), stageTab.size() * 4);
             if (!recTable.empty()) std::memcpy(blob + I.recOff, recTable.data(), recTable.size() * 4);
+            if (!sp.hbmTab.empty()) std::memcpy(blob + I.recOff + I.numRecs, sp.hbmTab.data(), sp.hbmTab.size() * 4);
+            if (!sp.operands.empty()) std::memcpy(blob + I.recOff + I.numRecs + sp.hbmTab.size(), sp.operands.data(), sp.operands.size() * 4);
         }
         while (p.prog.size() % 4) p.prog.push_back(0);   // keep every blob 16-byte aligned
         I.numStages = S;
@@ -998,9 +1099,9 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         I.ldsRecs = (I.ldsNext + S * kWaves + 3u) & ~3u;
         I.ldsWords = (I.ldsRecs + I.numRecs * kRecDwords + 3u) & ~3u;
         p.maxLdsBytes = std::max(p.maxLdsBytes, I.ldsWords * 4u);
-        if (wantSpec && !statelessIsland && I.split == 1u) {
+        if (specIsland && I.split == 1u) {
             if (p.specText.size() < ib.size()) p.specText.resize(ib.size());
-            p.specText[ii] = emitSpecSource(I, tasks, members, operands, stageTab, bs);
+            p.specText[ii] = emitSpecSource(I, tasks, sp, stageTab, bs);
         }
         p.numTasks += I.numTasks; p.numMembers += (uint32_t)members.size(); p.numOperands += (uint32_t)operands.size();
     }

@@ -36,6 +36,7 @@ typedef struct elemhip_stats {
     uint64_t spec_launches;       /* launches of run-time specialised island kernels */
     uint32_t spec_shapes, spec_islands;   /* distinct specialised island shapes / islands they cover in the current plan */
     double   last_jit_wait_ms;    /* time the last commit waited for kernel compilation (option "specialize" = 2) */
+    double   last_graph_capture_ms; /* hipGraph capture + instantiate of the current plan's per-block launch sequence */
 } elemhip_stats;
 
 /* Runtime(double sampleRate, int blockSize)                      runtime/elem/Runtime.h:44,157-166

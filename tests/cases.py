@@ -129,3 +129,18 @@ def sampleseq_scenario(make, block=32, sr=44100.0):
     assert set_seq({"duration": 300, "path": "/v/ramp"}) == 0
     run([100, 100 + block, 100 + 2 * block, 720, 0])
     return np.stack(ys)
+
+
+def every_stateful_roots():
+    """One graph with every stateful node type, host input 0 and the time-dependent nodes (pipelining tests)."""
+    X = el.in_({"channel": 0})
+    v = el.lowpass(el.add(900, el.mul(700, el.cycle(2.0))), 1.5, el.add(el.blepsaw(110.0), el.mul(0.5, X)))
+    w = el.delay({"size": 3000}, el.add(1000.5, el.mul(300, el.cycle(0.5))), 0.4, el.pole(0.95, X))
+    z = el.mul(el.adsr(0.002, 0.01, 0.5, 0.02, el.train(9.0)), el.pinknoise({"seed": 3}))
+    t = el.add(el.mul(1e-5, el.time()), el.metro({"interval": 7.0}), el.sdelay({"size": 700}, X), el.z(X))
+    s = el.add(el.biquad(0.2, 0.3, 0.2, -0.5, 0.2, X), el.mm1p({"mode": "lowpass"}, el.prewarp(800.0), X),
+               el.env(el.tau2pole(0.001), el.tau2pole(0.05), X), el.latch(el.train(60.0), X),
+               el.seq({"seq": [1, 2, 3, 5.5], "hold": True}, el.train(200.0), 0), el.counter(el.train(50.0)),
+               el.maxhold({"hold": 3.0}, el.abs(X), el.train(9.0)), el.accum(el.abs(X), el.train(20.0)),
+               el.highshelf(4000, 0.7, -4.5, X), el.syncphasor(440.0, el.train(37.0)), el.bleptriangle(523.25))
+    return [el.tanh(el.add(v, w)), el.add(z, t), s]

@@ -1,0 +1,129 @@
+"""Parity at the sizes BASELINE.json states for its configs, and the dynamic-graph stream of config 5:
+every output block and every gc() result of the HIP engine vs the reference engine. Tolerance 1e-6 absolute."""
+import numpy as np
+import pytest
+
+from elementary_amd import el, graphs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _checker(sr, bs):
+    import oracle
+    return oracle.RefRuntime(sr, bs) if oracle.have_ref() else oracle.PortRuntime(sr, bs)
+
+
+def _hip(sr, bs, specialize=0, **opts):
+    from elementary_amd.runtime import Runtime
+    rt = Runtime(sr, bs, device=0)
+    rt.set_option("specialize", specialize)
+    for k, v in opts.items():
+        rt.set_option(k, v)
+    return rt
+
+
+def _blocks(rt, nb, n_out, block=512):
+    import torch
+    out = torch.zeros((nb, n_out, block), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    rt.process_blocks(nb, n_out, out_ptr=out.data_ptr())
+    return out.cpu().numpy()
+
+
+def _voices_graph(ids, channels=2):
+    """The C2 mix (graphs.c2_graph) over an explicit list of voice ids."""
+    outs = []
+    for c in range(channels):
+        vs = [graphs.c2_voice(v) for k, v in enumerate(ids) if k % channels == c]
+        outs.append(el.add(*vs) if len(vs) > 1 else vs[0])
+    return outs
+
+
+def test_gc_timing_on_a_rendering_engine(gpu_required):
+    """gc.test.js:5-47 on the HIP engine WHILE IT RENDERS: the device-side root fades (mirrored on the host) decide when
+    the first graph's nodes become collectable — same blocks, same gc() results as the reference engine."""
+    logs = []
+    for mk in (lambda: _hip(44100.0, 512), lambda: _checker(44100.0, 512)):
+        rt = mk()
+        log = []
+        assert rt.render(el.mul(2, 3))["result"] == 0
+        early = sorted(rt.renderer._delegate.node_map.keys())
+        ys = [rt.process(None, 1, 512) for _ in range(10)]
+        log.append(("gc0", sorted(rt.gc())))
+        assert rt.render(el.mul(4, 5))["result"] == 0
+        ys += [rt.process(None, 1, 512) for _ in range(10)]
+        log.append(("gc1", sorted(rt.gc())))
+        assert rt.render(el.mul(6, 7))["result"] == 0
+        ys += [rt.process(None, 1, 512) for _ in range(10)]
+        pruned = sorted(rt.gc())
+        log.append(("gc2", pruned))
+        assert all(k not in rt.renderer._delegate.node_map for k in pruned)
+        logs.append((log, np.stack(ys), early))
+    (la, ya, early_a), (lb, yb, early_b) = logs
+    assert la == lb and early_a == early_b
+    assert lb[0][1] == [] and lb[1][1] == [] and lb[2][1] == early_b      # gc.test.js expectations
+    assert float(np.abs(ya - yb).max()) <= TOL
+
+
+@pytest.mark.parametrize("path", ["process", "process_blocks"])
+def test_c5_mutation_stream(gpu_required, path):
+    """BASELINE configs[4]: a live 128-voice graph (2060 nodes), one voice replaced per batch the way the reconciler does
+    it (new voice nodes, a new mix add and a new root per channel; the old root fades out over 20 ms), gc() every 16
+    batches. Every block and every pruned-id set must equal the reference engine's."""
+    a, c = _hip(graphs.C2_SAMPLE_RATE, 512, batch_blocks=4), _checker(graphs.C2_SAMPLE_RATE, 512)
+    ids = list(range(128))
+    nxt = 128
+    worst = 0.0
+    pruned_total = 0
+    for batch in range(41):
+        if batch:
+            ids[(batch * 37) % 128] = nxt
+            nxt += 1
+        roots = _voices_graph(ids)
+        ra, rc = a.render(*roots), c.render(*roots)
+        assert ra["result"] == 0 and rc["result"] == 0
+        assert ra["batch"] == rc["batch"]
+        nb = 1 + batch % 3                                   # 10-32 ms between batches: fades overlap the next mutation
+        ref = np.stack([c.process(None, 2, 512) for _ in range(nb)])
+        got = _blocks(a, nb, 2) if path == "process_blocks" else np.stack([a.process(None, 2, 512) for _ in range(nb)])
+        worst = max(worst, float(np.abs(got - ref).max()))
+        assert worst <= TOL, f"batch {batch}: {worst:.3e}"
+        if batch % 16 == 15:
+            pa, pc = sorted(a.gc()), sorted(c.gc())
+            assert pa == pc, (batch, len(pa), len(pc))
+            pruned_total += len(pa)
+    assert pruned_total > 100                                # replaced voices, old mix adds and old roots were reclaimed
+    # the stream settles: a last long stretch, then everything that is not in the live graph goes
+    ref = np.stack([c.process(None, 2, 512) for _ in range(8)])
+    got = _blocks(a, 8, 2) if path == "process_blocks" else np.stack([a.process(None, 2, 512) for _ in range(8)])
+    assert float(np.abs(got - ref).max()) <= TOL
+    assert sorted(a.gc()) == sorted(c.gc())
+
+
+@pytest.mark.parametrize("specialize", [0, 2])
+def test_c4_full_size(gpu_required, specialize):
+    """BASELINE configs[3], one GPU's share: 128 independent render instances x 375 blocks (4 s of audio), through the
+    offline entry point; the delay{size:24000} rings wrap 8 times."""
+    a, c = _hip(graphs.C4_SAMPLE_RATE, 512, specialize=specialize), _checker(graphs.C4_SAMPLE_RATE, 512)
+    roots = [graphs.c4_instance(k) for k in range(128)]
+    assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
+    got = _blocks(a, 375, 128)
+    ref = np.stack([c.process(None, 128, 512) for _ in range(375)])
+    if specialize:
+        assert a.stats()["spec_launches"] > 0
+    assert np.abs(ref).max() > 0.05
+    assert float(np.abs(got - ref).max()) <= TOL
+
+
+@pytest.mark.parametrize("specialize", [0, 2])
+def test_c2_soak_600_blocks(gpu_required, specialize):
+    """BASELINE configs[1] for 600 blocks (6.4 s): long enough for every envelope and oscillator phase to drift if a
+    recurrence were off by an ulp per block."""
+    a, c = _hip(graphs.C2_SAMPLE_RATE, 512, specialize=specialize), _checker(graphs.C2_SAMPLE_RATE, 512)
+    roots = graphs.c2_graph()
+    assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
+    got = np.concatenate([_blocks(a, 200, 2) for _ in range(3)])
+    ref = np.stack([c.process(None, 2, 512) for _ in range(600)])
+    err = float(np.abs(got - ref).max())
+    assert err <= TOL, f"{err:.3e}"

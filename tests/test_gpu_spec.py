@@ -107,19 +107,7 @@ def test_spec_every_stateful_node_pipelined(gpu_required, copies):
     """One graph with every stateful node type, host inputs and time-dependent nodes, through specialised launches with
     1, 3 and 6 blocks in flight: equal to the interpreter's block-by-block rendering (same op bodies)."""
     from elementary_amd.runtime import Runtime
-    X = el.in_({"channel": 0})
-
-    def roots():
-        v = el.lowpass(el.add(900, el.mul(700, el.cycle(2.0))), 1.5, el.add(el.blepsaw(110.0), el.mul(0.5, X)))
-        w = el.delay({"size": 3000}, el.add(1000.5, el.mul(300, el.cycle(0.5))), 0.4, el.pole(0.95, X))
-        z = el.mul(el.adsr(0.002, 0.01, 0.5, 0.02, el.train(9.0)), el.pinknoise({"seed": 3}))
-        t = el.add(el.mul(1e-5, el.time()), el.metro({"interval": 7.0}), el.sdelay({"size": 700}, X), el.z(X))
-        s = el.add(el.biquad(0.2, 0.3, 0.2, -0.5, 0.2, X), el.mm1p({"mode": "lowpass"}, el.prewarp(800.0), X),
-                   el.env(el.tau2pole(0.001), el.tau2pole(0.05), X), el.latch(el.train(60.0), X),
-                   el.seq({"seq": [1, 2, 3, 5.5], "hold": True}, el.train(200.0), 0), el.counter(el.train(50.0)),
-                   el.maxhold({"hold": 3.0}, el.abs(X), el.train(9.0)), el.accum(el.abs(X), el.train(20.0)),
-                   el.highshelf(4000, 0.7, -4.5, X), el.syncphasor(440.0, el.train(37.0)), el.bleptriangle(523.25))
-        return [el.tanh(el.add(v, w)), el.add(z, t), s]
+    from cases import every_stateful_roots as roots
     nb = 53
     x = np.stack([np.stack([lcg_noise(512, 7 + k, 0.5)]) for k in range(nb)])
     a, b = _spec_runtime(48000.0, 512, batch=12, copies=copies), Runtime(48000.0, 512)

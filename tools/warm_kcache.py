@@ -50,6 +50,9 @@ def main():
             n_out = min(3, 1 + seed % 5)
             jobs.append((f"fuzz{seed}", 48000.0, 512, random_graph(seed, n_nodes=24 + 22 * (seed % 4), n_roots=1 + seed % 5)[:n_out], None, None))
         jobs.append(("c2x16", 48000.0, 512, graphs.c2_graph(voices=16), None, None))
+        from cases import every_stateful_roots
+        for copies in (1, 3, 6):
+            jobs.append((f"stateful_d{copies}", 48000.0, 512, every_stateful_roots(), None, copies))
     for name, sr, bs, roots, res, copies in jobs:
         s, b, ms = warm(sr, bs, roots, res, copies=copies)
         shapes += s; bad += b
