@@ -6,7 +6,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 REPO=$PWD
-CMD="python $REPO/bench.py --no-cpu-baseline --steps 2048 --warmup 256"
+CMD="python $REPO/bench.py --no-cpu-baseline --steps 20 --warmup 5"
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $CMD > $OUT/prof_stats.log 2>&1)
@@ -14,4 +14,4 @@ mkdir -p $OUT
 (cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- $CMD > $OUT/prof_write.log 2>&1)
 tail -1 $OUT/prof_stats.log | cut -c1-300
 find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -name "*.csv" | head -20
-python profiles/summarize.py $OUT r01
+python profiles/summarize.py $OUT ${ROUND_TAG:-r02}

@@ -62,7 +62,7 @@ for ctr, d in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
         pmc[f"{k[0]}|grid={k[1][0]}x{k[1][1]}|{ctr}_dispatches"] = len(v)
 
 out = {"command": "rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE} --output-format csv -- "
-                  "python bench.py --no-cpu-baseline --steps 1024 --warmup 128",
+                  "python bench.py --no-cpu-baseline --steps 20 --warmup 5 (the driver-shaped run: 25 launch sets of 64 blocks)",
        "kernel_trace_per_dispatch": trace_summary, "pmc_per_dispatch": pmc}
 json.dump(out, open(os.path.join(dst, "c2_n1_rocprof_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
