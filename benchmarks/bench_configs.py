@@ -55,10 +55,16 @@ def _time_gpu(rt, n_in, n_out, blocks, xin=None):
             done += c
     run(chunk)
     torch.cuda.synchronize()
+    rt.set_option("profile_launches", 1)
     t0 = time.perf_counter()
     run(blocks)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / blocks
+    dt = (time.perf_counter() - t0) / blocks
+    prof = rt.launch_profile()
+    rt.set_option("profile_launches", 0)
+    _time_gpu.last_profile = {"level_us_per_block": [1e3 * x / max(1, prof["blocks"]) for x in prof["level_ms"]],
+                              "epilogue_us_per_block": 1e3 * prof["epilogue_ms"] / max(1, prof["blocks"]), "blocks": prof["blocks"]}
+    return dt
 
 
 def c1(args):
@@ -128,6 +134,7 @@ def c4(args):
             "gpu_us_per_block_step": 1e6 * g, "gpu_instance_samples_per_s": inst * BLOCK / g,
             "cpu_us_per_block_step_1core": 1e6 * c_all, "cpu_kind": kind, "cpu_sample": f"{sub} instances x {m} blocks, scaled to {inst}",
             "speedup_vs_1core": c_all / g, "launch_us": [1e3 * v for v in lv], "plan_build_ms": 1e3 * build, "specialize": args.specialize,
+            "launch_profile": getattr(_time_gpu, "last_profile", None),
             "spec_launches": rt.stats()["spec_launches"],
             "algorithmic_bytes_per_block_step": graphs.c4_algorithmic_bytes(inst)}
 
@@ -196,7 +203,7 @@ def c5(args):
                 "commit_to_first_block_ms_p50": pct(lat, 0.5), "commit_to_first_block_ms_p99": pct(lat, 0.99)}
 
     rt = Runtime(graphs.C2_SAMPLE_RATE, BLOCK, device=0)
-    rt.set_option("specialize", args.specialize)
+    rt.set_option("specialize", 1)   # a live graph never waits for a compiler: background mode (the product default)
     gpu = drive(rt, lambda k: rt.process_blocks(k, 2, out_ptr=out.data_ptr()), args.seconds)
     st = rt.stats()
     cpu, kind = _cpu_engine(graphs.C2_SAMPLE_RATE)
@@ -221,7 +228,7 @@ def main():
     ap.add_argument("--instances", type=int, default=128)
     ap.add_argument("--batches", type=int, default=400)
     ap.add_argument("--seconds", type=float, default=8.0)
-    ap.add_argument("--specialize", type=int, default=2)
+    ap.add_argument("--specialize", type=int, default=2, help="1 for c5 (background compilation, the product default) is set by c5 itself")
     args = ap.parse_args()
     for name in args.configs:
         out = {"c1": c1, "c3": c3, "c4": c4, "c5": c5}[name](args)

@@ -162,6 +162,9 @@ Engine::~Engine() {
     if (dHbm) (void)hipFree(dHbm);
     if (dOutRing) (void)hipFree(dOutRing);
     for (hipEvent_t e : profEvents) (void)hipEventDestroy(e);
+    for (hipEvent_t e : auxDone) (void)hipEventDestroy(e);
+    for (hipStream_t s2 : auxStreams) (void)hipStreamDestroy(s2);
+    if (forkEvent) (void)hipEventDestroy(forkEvent);
     if (hPatches) (void)hipHostFree(hPatches);
     if (hOut) (void)hipHostFree(hOut);
     if (hIn) (void)hipHostFree(hIn);
@@ -1400,31 +1403,67 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
     const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
     if (e <= b) return;
     bool spec = specialize != 0 && !p.shapes.empty();
-    std::vector<std::pair<hipFunction_t, const Plan::SpecShape*>> fns;
+    std::vector<std::pair<hipFunction_t, const Plan::SpecShape*>> fns;   // function null: the shape is not compiled (yet)
     if (spec) {
+        bool any = false;
         for (const Plan::SpecShape& sh : p.shapes) {
             if (sh.level != (uint32_t)l) continue;
             hipFunction_t fn = sh.entry->function(device);
-            if (!fn) { spec = false; break; }
+            any = any || fn != nullptr;
             fns.emplace_back(fn, &sh);
         }
-        if (fns.empty()) spec = false;
+        if (!any) spec = false;
     }
     if (!spec) { launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats); return; }
+    // The launches of one level are independent of each other (different islands): with more than one they go to side
+    // streams forked from / joined to the engine's stream, so two shapes of 64 islands each fill 128 CUs at once
+    // instead of 64 CUs twice.
+    const uint32_t rb = p.restOffsets[l], re = p.restOffsets[l + 1];
+    const size_t launches = fns.size() + (re > rb ? 1 : 0);
+    const bool fork = launches > 1;
+    if (fork) {
+        while (auxStreams.size() < launches - 1) {
+            hipStream_t s2 = nullptr; hipEvent_t ev = nullptr;
+            HIP_WARN(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            HIP_WARN(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            auxStreams.push_back(s2); auxDone.push_back(ev);
+        }
+        if (!forkEvent) HIP_WARN(hipEventCreateWithFlags(&forkEvent, hipEventDisableTiming));
+        HIP_WARN(hipEventRecord(forkEvent, stream));
+    }
+    size_t k = 0;
+    auto streamFor = [&](size_t idx) -> hipStream_t {
+        if (!fork || idx == 0) return stream;
+        hipStream_t s2 = auxStreams[idx - 1];
+        HIP_WARN(hipStreamWaitEvent(s2, forkEvent, 0));
+        return s2;
+    };
     for (auto& f : fns) {
+        hipStream_t st_ = streamFor(k++);
+        if (!f.first) {   // this shape's islands go through the interpreter kernel (their list has the levelIslands entry format)
+            PlanView pv = p.view;
+            pv.levelIslands = p.dSpecLists;
+            launch_level(st_, pv, dRecs, dHbm, dGlobals, dLcg, f.second->listBegin, f.second->count, p.levelLdsBytes[l], batch, arenaFloats);
+            continue;
+        }
         PlanView pv = p.view;
         uint32_t* recs = dRecs; float* hbm = dHbm; const Globals* g = dGlobals; const uint32_t* lcg = dLcg;
         const uint32_t* list = p.dSpecLists + f.second->listBegin;
         uint32_t bt = batch, af = arenaFloats;
         void* args[] = {&pv, &recs, &hbm, &g, &lcg, &list, &bt, &af};
-        HIP_WARN(hipModuleLaunchKernel(f.first, f.second->count, 1, 1, kThreads, 1, 1, 0, stream, args, nullptr));
+        HIP_WARN(hipModuleLaunchKernel(f.first, f.second->count, 1, 1, kThreads, 1, 1, 0, st_, args, nullptr));
         st.specLaunches++;
     }
-    const uint32_t rb = p.restOffsets[l], re = p.restOffsets[l + 1];
     if (re > rb) {
         PlanView pv = p.view;
         pv.levelIslands = p.dRestIslands;
-        launch_level(stream, pv, dRecs, dHbm, dGlobals, dLcg, rb, re - rb, p.levelLdsBytes[l], batch, arenaFloats);
+        launch_level(streamFor(k++), pv, dRecs, dHbm, dGlobals, dLcg, rb, re - rb, p.levelLdsBytes[l], batch, arenaFloats);
+    }
+    if (fork) {
+        for (size_t i = 1; i < launches; ++i) {
+            HIP_WARN(hipEventRecord(auxDone[i - 1], auxStreams[i - 1]));
+            HIP_WARN(hipStreamWaitEvent(stream, auxDone[i - 1], 0));
+        }
     }
 }
 

@@ -162,6 +162,8 @@ private:
     std::unordered_map<std::string, ResourcePtr> resources;
     std::unordered_map<std::string, std::unique_ptr<HostVTable>> hostTypes;
     std::vector<float> hostIn, hostOut;    // staging for call-out nodes
+    // generated text per island-program signature: 256 voices (and every re-plan of a live graph) format their text once
+    std::unordered_map<uint64_t, std::shared_ptr<const std::string>> specTextCache;
     int64_t curBlockTime = 0;              // sample time of the block being enqueued (call-out nodes get it as userData)
     bool shouldRebuild = false;
     bool rebuildOwed = false;              // a commit failed to build its plan: the next commit retries even without ACTIVATE_ROOTS
@@ -202,6 +204,9 @@ private:
     int  timeBatch = 1;
     int  specialize = 1;                   // 0: interpreter kernels only; 1: specialised kernels compiled in the background and used
                                            // once ready; 2: commit() waits for them (deterministic: tests, benchmarks)
+    std::vector<hipStream_t> auxStreams;   // side streams for the independent launches of one level (launchLevelBatch)
+    std::vector<hipEvent_t> auxDone;
+    hipEvent_t forkEvent = nullptr;
     bool profileLaunches = false;
     std::vector<double> profMs;            // per level + epilogue, summed over the launch sets profiled so far
     uint64_t profSets = 0, profBlocks = 0;
@@ -287,7 +292,7 @@ struct Plan {
     std::vector<uint32_t> specLists;           // island indices, shape-major
     std::vector<uint32_t> restIslands;         // per level: the levelIslands entries no shape covers (interpreter launch)
     std::vector<uint32_t> restOffsets;         // numLevels + 1
-    std::vector<std::string> specText;         // per island: generated text ("" = interpreter only), consumed by buildPlan
+    std::vector<std::shared_ptr<const std::string>> specText;   // per island: generated text (null = interpreter only), consumed by buildPlan
     const uint32_t* dSpecLists = nullptr;      // device copies (inside `dev`)
     const uint32_t* dRestIslands = nullptr;
     // captured launch sequence for multi-block offline rendering

@@ -171,12 +171,27 @@ std::string Jit::fullSource(const std::string& generated, uint32_t ldsWords) {
     return s;
 }
 
-std::shared_ptr<SpecEntry> Jit::request(const std::string& generated, uint32_t ldsWords) {
-    std::string src = fullSource(generated, ldsWords);
-    uint64_t h1 = fnv1a(impl->versionTag, 1469598103934665603ull), h2 = fnv1a(impl->versionTag, 0x9E3779B97F4A7C15ull);
+static std::string keyOf(const std::string& versionTag, const std::string& src) {
+    uint64_t h1 = fnv1a(versionTag, 1469598103934665603ull), h2 = fnv1a(versionTag, 0x9E3779B97F4A7C15ull);
     h1 = fnv1a(src, h1); h2 = fnv1a(src, h2 ^ 0xA5A5A5A5ull);
     char key[40];
     std::snprintf(key, sizeof key, "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
+    return key;
+}
+
+bool Jit::known(const std::string& generated, uint32_t ldsWords) {
+    const std::string key = keyOf(impl->versionTag, fullSource(generated, ldsWords));
+    {
+        std::lock_guard<std::mutex> l(impl->mu);
+        if (impl->entries.count(key)) return true;
+    }
+    struct stat st;
+    return ::stat((impl->cacheDir + "/" + key + ".hsaco").c_str(), &st) == 0;
+}
+
+std::shared_ptr<SpecEntry> Jit::request(const std::string& generated, uint32_t ldsWords) {
+    std::string src = fullSource(generated, ldsWords);
+    const std::string key = keyOf(impl->versionTag, src);
     std::lock_guard<std::mutex> l(impl->mu);
     auto it = impl->entries.find(key);
     if (it != impl->entries.end()) return it->second;

@@ -31,6 +31,7 @@ public:
     // queue `generated` (codegen.cpp text of one island shape) for compilation; identical text -> the same entry
     std::shared_ptr<SpecEntry> request(const std::string& generated, uint32_t ldsWords);
     int wait(const std::shared_ptr<SpecEntry>& e);   // blocks until compiled: 1 ready, -1 failed
+    bool known(const std::string& generated, uint32_t ldsWords);   // already requested in this process, or on disk
     static std::string fullSource(const std::string& generated, uint32_t ldsWords);
     void shutdownAtExit();
 private:

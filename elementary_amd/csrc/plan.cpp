@@ -1101,7 +1101,25 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         p.maxLdsBytes = std::max(p.maxLdsBytes, I.ldsWords * 4u);
         if (specIsland && I.split == 1u) {
             if (p.specText.size() < ib.size()) p.specText.resize(ib.size());
-            p.specText[ii] = emitSpecSource(I, tasks, sp, stageTab, bs);
+            // signature of everything the text is a function of (arena indices by their position in the island's arena table)
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](uint32_t v) { h ^= v; h *= 1099511628211ull; h ^= h >> 29; };
+            auto arenaPos = [&](uint32_t abs) { for (size_t k = 0; k < sp.hbmTab.size(); ++k) if (sp.hbmTab[k] == abs) return (uint32_t)k; return 0xFFFFu; };
+            const uint32_t* iw = reinterpret_cast<const uint32_t*>(&I);
+            for (size_t k = 0; k < sizeof(Island) / 4; ++k) if (k != offsetof(Island, progBegin) / 4 && k != offsetof(Island, rootRec) / 4) mix(iw[k]);
+            for (const Task& t : tasks) { const uint32_t* w = reinterpret_cast<const uint32_t*>(&t); for (int k = 0; k < 8; ++k) mix(k == 7 ? 0u : w[k]); }   // (t.outHbm: absolute, not part of the text)
+            for (const Member& m : sp.members) { mix(m.rec); mix(m.opnd); mix(m.nin); mix(m.outLds); mix(m.outHbm == kNone ? kNone : arenaPos(m.outHbm)); mix(m.scratch); }
+            for (uint32_t o : sp.operands) mix((o & kOpKindMask) == kOpHbm ? (kOpHbm | arenaPos(o & kOpValMask)) : o);
+            for (uint32_t o : sp.phaseOp) mix((o & kOpKindMask) == kOpHbm ? (kOpHbm | arenaPos(o & kOpValMask)) : o);
+            for (uint8_t g : sp.gdirect) mix(g);
+            for (uint32_t k = 0; k < 2 * S; ++k) mix(stageTab[k]);
+            mix(bs); mix((uint32_t)sp.hbmTab.size());
+            auto it = e.specTextCache.find(h);
+            if (it == e.specTextCache.end()) {
+                if (e.specTextCache.size() > 4096) e.specTextCache.clear();
+                it = e.specTextCache.emplace(h, std::make_shared<const std::string>(emitSpecSource(I, tasks, sp, stageTab, bs))).first;
+            }
+            p.specText[ii] = it->second;
         }
         p.numTasks += I.numTasks; p.numMembers += (uint32_t)members.size(); p.numOperands += (uint32_t)operands.size();
     }
@@ -1179,14 +1197,17 @@ std::shared_ptr<Plan> Engine::buildPlan() {
         p.restOffsets.assign(L + 1, 0);
         std::vector<uint8_t> covered(p.islands.size(), 0);
         for (size_t l = 0; l < L; ++l) {
-            std::map<std::string, std::vector<uint32_t>> byText;
+            std::map<const std::string*, std::vector<uint32_t>> byText;   // identical text = the same cached string object
             for (uint32_t q = p.levelOffsets[l]; q < p.levelOffsets[l + 1]; ++q) {
                 const uint32_t isl = p.levelIslands[q] & 0xFFFFFFu;
-                if (isl < p.specText.size() && !p.specText[isl].empty() && !covered[isl]) byText[p.specText[isl]].push_back(isl);
+                if (isl < p.specText.size() && p.specText[isl] && !covered[isl]) byText[p.specText[isl].get()].push_back(isl);
             }
             for (auto& kv : byText) {
+                // background mode: a shape only one island has (a voice that is fading out next to its replacement, a
+                // one-off graph) is not worth a compile of its own: it renders through the interpreter kernel
+                if (specialize == 1 && kv.second.size() < 2 && !Jit::get().known(*kv.first, p.islands[kv.second[0]].ldsWords)) continue;
                 Plan::SpecShape sh;
-                sh.entry = Jit::get().request(kv.first, p.islands[kv.second[0]].ldsWords);
+                sh.entry = Jit::get().request(*kv.first, p.islands[kv.second[0]].ldsWords);
                 sh.level = (uint32_t)l; sh.listBegin = (uint32_t)p.specLists.size(); sh.count = (uint32_t)kv.second.size();
                 for (uint32_t isl : kv.second) { p.specLists.push_back(isl); covered[isl] = 1; }
                 p.shapes.push_back(std::move(sh));
