@@ -59,6 +59,8 @@ enum Op : uint16_t {
     OP_TIME, OP_METRO, OP_CONVOLVE,
     OP_TABLE, OP_SEQ2, OP_SPARSEQ2, OP_SAMPLE,
     OP_METER, OP_SNAPSHOT, OP_SCOPE,              // event side-channel (Analyzers.h)
+    OP_MCSAMPLE,                                  // one output channel of mc.sample (mc/Sample.h); mc.table and
+                                                  // mc.sampleseq channels reuse the table / sampleseq ops (flag in the record)
     // plan pseudo-ops
     OP_COPY,          // out = in0 (import HBM->LDS, export LDS->HBM)
     OP_SVF_COEF,      // SVF coefficient pre-pass (a1,a2,a3 as double into the member's scratch), sample-parallel
@@ -255,6 +257,9 @@ enum : uint32_t {
     // state: change detector, current reader, two readers {target gain, gain, pos (double)}
     SMP_BUF = P0, SMP_LEN = P2, SMP_PENDING = P3, SMP_MODE = P4, SMP_START = P5, SMP_STOP = P6, SMP_ALPHA = P7,
     SMP_CHANGE = 8, SMP_CURRENT = 9, SMP_HAVE = 10, SMP_READER0 = 12, SMP_READER_DWORDS = 4,   // target, gain, pos lo, pos hi
+    // mc.sample channel (mc/Sample.h:17-291): params as `sample` (P7 unused); state: change detector, current reader, have-buffer,
+    // pending reset (Runtime::reset), two readers {target, gain, step, pos (double), start offset, stop offset, loop}, playback rate (double)
+    MCS_RESET = 11, MCS_READER0 = 12, MCS_READER_DWORDS = 8, MCS_RATE = 28,
     // seq2 (Seq2.h:35-166) shares seq's parameter layout; state: S0 edge count, S3/S4 change detectors, S5 have-sequence
     // convolve: device pointer to the conv:: state
     CONV_STATE = P0,
@@ -262,6 +267,8 @@ enum : uint32_t {
     SSQ_BUF = P0, SSQ_BUFLEN = P2, SSQ_BUFPENDING = P3, SSQ_SEQ = P4, SSQ_SEQLEN = P6, SSQ_SEQPENDING = P7,
     SSQ_DUR = 8, SSQ_RTDUR = 10, SSQ_PREV = 12, SSQ_NEXT = 13, SSQ_ACTIVE = 14, SSQ_FLAGS = 15,
     SSQ_READER0 = 16, SSQ_READER_DWORDS = 8,   // per reader: gain, target, step, position, startTime(2), bufferSize, -
+    // SSQ_FLAGS bit 2: the mc.sampleseq flavour (mc/SampleSeq.h): readers fade with elem::GainFade (helpers/GainFade.h) whose
+    // fade-in / fade-out steps sit in the spare dword 7 of reader 0 / reader 1
 };
 }
 

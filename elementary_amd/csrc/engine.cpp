@@ -56,7 +56,7 @@ static const std::unordered_map<std::string, uint16_t>& opTable() {
         {"pole", OP_POLE}, {"env", OP_ENV}, {"biquad", OP_BIQUAD}, {"prewarp", OP_PREWARP}, {"mm1p", OP_MM1P}, {"svf", OP_SVF}, {"svfshelf", OP_SVFSHELF},
         {"tapIn", OP_TAPIN}, {"tapOut", OP_TAPOUT},
         {"blepsaw", OP_BLEPSAW}, {"blepsquare", OP_BLEPSQUARE}, {"bleptriangle", OP_BLEPTRIANGLE},
-        {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2}, {"sample", OP_SAMPLE}, {"meter", OP_METER}, {"snapshot", OP_SNAPSHOT}, {"scope", OP_SCOPE},
+        {"mc.table", OP_TABLE}, {"mc.sample", OP_MCSAMPLE}, {"mc.sampleseq", OP_SAMPLESEQ}, {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2}, {"sample", OP_SAMPLE}, {"meter", OP_METER}, {"snapshot", OP_SNAPSHOT}, {"scope", OP_SCOPE},
     };
     return t;
 }
@@ -148,13 +148,13 @@ Engine::~Engine() {
     for (auto& kv : nodes) if (kv.second.hostInst && kv.second.hostVt && kv.second.hostVt->destroy) kv.second.hostVt->destroy(kv.second.hostInst, kv.second.hostVt->user);
     if (dry) {
         for (auto& kv : nodes) std::free(kv.second.ring.ptr);
-        for (auto& kv : resources) std::free(kv.second->dev.ptr);
+        for (auto& kv : resources) { std::free(kv.second->dev.ptr); for (DevBuf& d : kv.second->devCh) std::free(d.ptr); }
         return;
     }
     if (stream) (void)hipStreamSynchronize(stream);
     current.reset(); pending.reset();
     for (auto& kv : nodes) if (kv.second.ring.ptr) (void)hipFree(kv.second.ring.ptr);
-    for (auto& kv : resources) if (kv.second->dev.ptr) (void)hipFree(kv.second->dev.ptr);
+    for (auto& kv : resources) { if (kv.second->dev.ptr) (void)hipFree(kv.second->dev.ptr); for (DevBuf& d : kv.second->devCh) if (d.ptr) (void)hipFree(d.ptr); }
     freeDeferred();
     if (dRecs) (void)hipFree(dRecs);
     if (dGlobals) (void)hipFree(dGlobals);
@@ -229,6 +229,68 @@ void Engine::writeParam(Node& n, uint32_t dword, uint32_t value) {
     // a record that has not been uploaded yet travels whole; otherwise patch the one dword
     if (!freshFlag[n.rec])
         patches.push_back(Patch{0u, idx, value, 0u});
+    for (uint32_t cr : n.chanRecs) writeRec(cr, dword, value);   // a multi-output node: every channel's record (buffers are set per channel)
+}
+
+void Engine::writeRec(uint32_t rec, uint32_t dword, uint32_t value) {
+    const uint32_t idx = rec * kRecDwords + dword;
+    shadow[idx] = value;
+    if (!freshFlag[rec]) patches.push_back(Patch{0u, idx, value, 0u});
+}
+
+// Channel `ch` of a shared resource on the device (channel 0 is Resource::dev). A channel the resource does not have
+// reads as an empty buffer (AudioBufferResource.h:32-40).
+int Engine::ensureResourceChannelOnDevice(const ResourcePtr& r, uint32_t ch, const void** ptr, uint32_t* len) {
+    *ptr = nullptr; *len = 0;
+    if (!r || ch >= r->channels.size()) return kOk;
+    *len = (uint32_t)r->channels[ch].size();
+    if (ch == 0) { int rc = ensureResourceOnDevice(r); *ptr = r->dev.ptr; return rc; }
+    if (r->devCh.size() <= ch) r->devCh.resize(ch + 1);
+    DevBuf& d = r->devCh[ch];
+    if (!d.ptr) {
+        const size_t floats = std::max<size_t>(r->channels[ch].size(), (size_t)blockSize);
+        if (dry) { d.ptr = std::calloc(floats, sizeof(float)); std::memcpy(d.ptr, r->channels[ch].data(), r->channels[ch].size() * 4); }
+        else {
+            HIP_OK(hipMalloc(&d.ptr, floats * sizeof(float)));
+            HIP_OK(hipMemsetAsync(d.ptr, 0, floats * sizeof(float), stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            if (*len) HIP_OK(hipMemcpy(d.ptr, r->channels[ch].data(), (size_t)*len * sizeof(float), hipMemcpyHostToDevice));
+        }
+        d.bytes = floats * sizeof(float);
+    }
+    *ptr = d.ptr;
+    return kOk;
+}
+
+// mc.table (mc/Table.h:12-85): output channel j is TableNode's lookup (Table.h:35-71) into channel j of the resource
+void Engine::writeTableChannel(Node& n, uint32_t ch, uint32_t rec) {
+    const void* ptr = nullptr; uint32_t len = 0;
+    if (n.res) (void)ensureResourceChannelOnDevice(n.res, ch, &ptr, &len);
+    const uint64_t v = (uint64_t)reinterpret_cast<uintptr_t>(ptr);
+    writeRec(rec, rec::TBL_BUF, (uint32_t)(v & 0xFFFFFFFFu));
+    writeRec(rec, rec::TBL_BUF + 1, (uint32_t)(v >> 32));
+    writeRec(rec, rec::TBL_LEN, len);
+}
+
+// The record of output channel `ch` of a multi-output node. Every channel renders the node's algorithm on its own copy of
+// the state (the reference keeps ONE state and loops over the channels inside process(): reader positions and fades
+// evolve identically for every channel) and differs only in the resource channel it reads.
+uint32_t Engine::channelRec(Node& n, uint32_t ch) {
+    if (ch == 0 || !n.mc) return n.rec;
+    while (n.chanRecs.size() < ch) {
+        const uint32_t r = allocRec();
+        n.chanRecs.push_back(r);
+        // parameters and INITIAL state as the host last wrote them for channel 0 (pending-buffer flags included)
+        std::memcpy(shadow.data() + (size_t)r * kRecDwords, shadow.data() + (size_t)n.rec * kRecDwords, kRecDwords * 4);
+        writeChannelBuffer(n, (uint32_t)n.chanRecs.size(), r);
+    }
+    return n.chanRecs[ch - 1];
+}
+
+// buffer pointer / length of resource channel `ch` into record `rec` (table, mc.sample, mc.sampleseq share the slots P0-P2)
+void Engine::writeChannelBuffer(Node& n, uint32_t ch, uint32_t rec) {
+    static_assert(rec::TBL_BUF == rec::SMP_BUF && rec::TBL_BUF == rec::SSQ_BUF && rec::TBL_LEN == rec::SMP_LEN && rec::TBL_LEN == rec::SSQ_BUFLEN, "shared buffer slots");
+    writeTableChannel(n, ch, rec);
 }
 
 void Engine::writeParamPtr(Node& n, uint32_t dword, const void* p) {
@@ -355,6 +417,7 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
     if (nodes.find(id) != nodes.end()) return kNodeAlreadyExists;
     Node n;
     n.id = id; n.op = it->second; n.rec = allocRec();
+    n.mc = type.compare(0, 3, "mc.") == 0;
     uint32_t* r = shadow.data() + (size_t)n.rec * kRecDwords;
     switch (n.op) {
         case OP_CONST: r[rec::P0] = fbits(1.0f); break;                           // Core.h:166
@@ -381,7 +444,19 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
         case OP_SAMPLESEQ:                                                        // SampleSeq.h:66-68: fade step 0.02
             r[rec::SSQ_PREV] = r[rec::SSQ_NEXT] = 0xFFFFFFFFu;
             r[rec::SSQ_READER0 + 2] = fbits(0.02f); r[rec::SSQ_READER0 + rec::SSQ_READER_DWORDS + 2] = fbits(0.02f);
+            if (n.mc) {   // mc/SampleSeq.h:96: readers({MCBufferReader<float>(sr, 8.0), ...}) -> elem::GainFade(sr, 8 ms, 8 ms)
+                const double fs = (double)(float)sampleRate;
+                const float inS = (float)msToStep(fs, 8.0), outS = (float)((double)(-1.0f) * msToStep(fs, 8.0));
+                r[rec::SSQ_FLAGS] = 4u;
+                r[rec::SSQ_READER0 + 7] = fbits(inS); r[rec::SSQ_READER0 + rec::SSQ_READER_DWORDS + 7] = fbits(outS);
+                r[rec::SSQ_READER0 + 2] = fbits(inS); r[rec::SSQ_READER0 + rec::SSQ_READER_DWORDS + 2] = fbits(inS);   // updateCurrentStep at rest
+            }
             break;
+        case OP_MCSAMPLE: {                                                       // mc/Sample.h:162-164: playbackRate = 1.0
+            const double one = 1.0; uint64_t bits; std::memcpy(&bits, &one, 8);
+            r[rec::MCS_RATE] = (uint32_t)(bits & 0xFFFFFFFFu); r[rec::MCS_RATE + 1] = (uint32_t)(bits >> 32);
+            break;
+        }
         case OP_METRO: {                                                          // wasm/Metro.h:15
             const int64_t is = (int64_t)std::max(2.0, 1000.0 * 0.001 * sampleRate);
             r[rec::P0] = (uint32_t)((uint64_t)is & 0xFFFFFFFFu); r[rec::P1] = (uint32_t)((uint64_t)is >> 32);
@@ -599,6 +674,38 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
                 writeParam(n, key == "startOffset" ? rec::SMP_START : rec::SMP_STOP, (uint32_t)vi);
             }
             break;
+        case OP_MCSAMPLE:                                          // mc/Sample.h:22-76
+            if (key == "path") {
+                if (!v.isString()) return kInvalidPropertyType;
+                auto rit = resources.find(v.str);
+                if (rit == resources.end()) return kInvalidPropertyValue;
+                int rc = ensureResourceOnDevice(rit->second);
+                if (rc != kOk) return rc;
+                n.res = rit->second;
+                writeParamPtr(n, rec::SMP_BUF, n.res->dev.ptr);
+                writeParam(n, rec::SMP_LEN, (uint32_t)(n.res->channels.empty() ? 0 : n.res->channels[0].size()));
+                writeParam(n, rec::SMP_PENDING, 1u);
+                for (size_t c = 0; c < n.chanRecs.size(); ++c) writeChannelBuffer(n, (uint32_t)c + 1u, n.chanRecs[c]);
+            }
+            if (key == "mode") {
+                if (!v.isString()) return kInvalidPropertyType;
+                if (v.str == "trigger") writeParam(n, rec::SMP_MODE, 0u);
+                if (v.str == "gate") writeParam(n, rec::SMP_MODE, 1u);
+                if (v.str == "loop") writeParam(n, rec::SMP_MODE, 2u);
+            }
+            if (key == "startOffset" || key == "stopOffset") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                const int vi = (int)v.num;
+                if (vi < 0) return kInvalidPropertyValue;
+                writeParam(n, key == "startOffset" ? rec::SMP_START : rec::SMP_STOP, (uint32_t)vi);
+            }
+            if (key == "playbackRate") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                uint64_t bits; std::memcpy(&bits, &v.num, 8);
+                writeParam(n, rec::MCS_RATE, (uint32_t)(bits & 0xFFFFFFFFu));
+                writeParam(n, rec::MCS_RATE + 1, (uint32_t)(bits >> 32));
+            }
+            break;
         case OP_SCOPE:                                             // Analyzers.h:151-173
             if (key == "size") { if (!v.isNumber()) return kInvalidPropertyType; if (v.num < 256 || v.num > 8192) return kInvalidPropertyValue; }
             if (key == "channels") { if (!v.isNumber()) return kInvalidPropertyType; if (v.num < 0 || v.num > 4) return kInvalidPropertyValue; }
@@ -614,6 +721,7 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
                 n.res = rit->second;
                 writeParamPtr(n, rec::TBL_BUF, n.res->dev.ptr);
                 writeParam(n, rec::TBL_LEN, (uint32_t)(n.res->channels.empty() ? 0 : n.res->channels[0].size()));
+                for (size_t c = 0; c < n.chanRecs.size(); ++c) writeChannelBuffer(n, (uint32_t)c + 1u, n.chanRecs[c]);   // mc.table
             }
             break;
         case OP_SPARSEQ2:                                          // SparSeq2.h:20-54
@@ -669,6 +777,7 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
                 writeParamPtr(n, rec::SSQ_BUF, n.res->dev.ptr);
                 writeParam(n, rec::SSQ_BUFLEN, (uint32_t)(n.res->channels.empty() ? 0 : n.res->channels[0].size()));
                 writeParam(n, rec::SSQ_BUFPENDING, 1u);
+                for (size_t c = 0; c < n.chanRecs.size(); ++c) writeChannelBuffer(n, (uint32_t)c + 1u, n.chanRecs[c]);   // mc.sampleseq
             }
             if (key == "seq") {
                 if (!v.isArray()) return kInvalidPropertyType;
@@ -894,6 +1003,12 @@ size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
         patches.erase(std::remove_if(patches.begin(), patches.end(), [&](const Patch& p) { return p.kind != 2 && p.index >= lo && p.index < hi; }), patches.end());
         if (freshFlag[n.rec]) { freshRecs.erase(std::remove(freshRecs.begin(), freshRecs.end(), n.rec), freshRecs.end()); freshFlag[n.rec] = 0; }
         freeRecs.push_back(n.rec);
+        for (uint32_t cr : n.chanRecs) {
+            const uint32_t clo = cr * kRecDwords, chi = clo + kRecDwords;
+            patches.erase(std::remove_if(patches.begin(), patches.end(), [&](const Patch& p) { return p.kind != 2 && p.index >= clo && p.index < chi; }), patches.end());
+            if (freshFlag[cr]) { freshRecs.erase(std::remove(freshRecs.begin(), freshRecs.end(), cr), freshRecs.end()); freshFlag[cr] = 0; }
+            freeRecs.push_back(cr);
+        }
         nodes.erase(id);
     }
     std::sort(pruned.begin(), pruned.end());
@@ -924,6 +1039,8 @@ void Engine::reset() {
         if (n.op == OP_SAMPLE) {
             writeParamF(n, rec::SMP_READER0, 0.0f);
             writeParamF(n, rec::SMP_READER0 + rec::SMP_READER_DWORDS, 0.0f);
+        } else if (n.op == OP_MCSAMPLE) {
+            writeParam(n, rec::MCS_RESET, 1u);          // both readers noteOff() at the next block (mc/Sample.h:78-81)
         } else if (n.op == OP_HOST && n.hostVt && n.hostVt->reset) {
             n.hostVt->reset(n.hostInst, n.hostVt->user);
         }
@@ -991,6 +1108,7 @@ void Engine::pruneSharedResources() {   // SharedResource.h:94-102
     for (auto it = resources.begin(); it != resources.end();) {
         if (it->second.use_count() == 1) {
             if (it->second->dev.ptr) { if (dry) std::free(it->second->dev.ptr); else (void)hipFree(it->second->dev.ptr); }
+            for (DevBuf& d : it->second->devCh) if (d.ptr) { if (dry) std::free(d.ptr); else (void)hipFree(d.ptr); }
             it = resources.erase(it);
         } else ++it;
     }

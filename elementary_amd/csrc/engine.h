@@ -58,6 +58,7 @@ struct DevBuf {
 struct Resource {
     std::vector<std::vector<float>> channels;
     DevBuf dev;                 // channel 0, uploaded lazily
+    std::vector<DevBuf> devCh;  // channels >= 1 (multi-output nodes), uploaded lazily; devCh[0] unused
     bool isTap = false;         // created by getTapResource (mutable feedback buffer)
 };
 using ResourcePtr = std::shared_ptr<Resource>;
@@ -80,6 +81,8 @@ struct Node {
     ResourcePtr res;            // tap buffer / sample data held by the node
     uint32_t eventCount = 0;    // meter / snapshot: readouts already relayed by processQueuedEvents
     uint32_t convSlices = 1;    // convolve: helper slices its current impulse response wants (conv.hip)
+    bool mc = false;            // multi-output node (mc.*): one record per output channel, planned as one entry per channel
+    std::vector<uint32_t> chanRecs;   // records of output channels 1, 2, ... (allocated when a plan first needs them)
     void* hostInst = nullptr;   // OP_HOST: the instance its type's create() returned
     const HostVTable* hostVt = nullptr;
 };
@@ -218,6 +221,11 @@ private:
     uint32_t lastTimeBatch = 1;            // blocks per launch the last timeLaunches actually used                    // timeLaunches: blocks per timed launch
 
     uint32_t allocRec();
+    uint32_t channelRec(Node& n, uint32_t ch);           // record of output channel `ch` of a (multi-output) node
+    void writeRec(uint32_t rec, uint32_t dword, uint32_t value);
+    void writeTableChannel(Node& n, uint32_t ch, uint32_t rec);
+    void writeChannelBuffer(Node& n, uint32_t ch, uint32_t rec);
+    int  ensureResourceChannelOnDevice(const ResourcePtr& r, uint32_t ch, const void** ptr, uint32_t* len);
     void writeParam(Node& n, uint32_t dword, uint32_t value);
     void writeParamF(Node& n, uint32_t dword, float value) { uint32_t u; memcpy(&u, &value, 4); writeParam(n, dword, u); }
     void writeParamPtr(Node& n, uint32_t dword, const void* p);

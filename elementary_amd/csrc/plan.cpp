@@ -35,7 +35,7 @@ Kind kindOf(uint16_t op) {
         case OP_CONVOLVE: return K_CONV;   // always an island of its own, rendered by conv.hip
         case OP_HOST: return K_HOST;       // always an island of its own, rendered on the CPU between launch levels
         case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD:
-        case OP_ONCE: case OP_SEQ: case OP_SEQ2: case OP_SAMPLE: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
+        case OP_ONCE: case OP_SEQ: case OP_SEQ2: case OP_SAMPLE: case OP_MCSAMPLE: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
         case OP_SVFSHELF: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
             return K_CHAIN;
         default: return K_PAR;
@@ -48,7 +48,7 @@ uint32_t scratchSlots(uint16_t op) {
         case OP_SVFSHELF: return 10;  // a1,a2,a3,k,A
         case OP_DELAY: return 1;
         case OP_SAMPLESEQ: return 2;  // per-reader fade gains
-        case OP_SAMPLE: return 6;     // per reader: read index, fraction, gain (serial pass -> gather pass)
+        case OP_SAMPLE: case OP_MCSAMPLE: return 6;     // per reader: read index, fraction, gain (serial pass -> gather pass)
         default: return 0;
     }
 }
@@ -57,7 +57,7 @@ uint32_t scratchSlots(uint16_t op) {
 uint32_t leafArity(uint16_t op) {
     switch (op) {
         case OP_PHASOR: case OP_COUNTER: case OP_ONCE: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
-        case OP_Z: case OP_SDELAY: case OP_PREWARP: case OP_ROOT: case OP_TAPOUT: case OP_SAMPLESEQ: return 1;
+        case OP_Z: case OP_SDELAY: case OP_PREWARP: case OP_ROOT: case OP_TAPOUT: case OP_SAMPLESEQ: case OP_MCSAMPLE: return 1;
         case OP_SPHASOR: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_SEQ: case OP_SEQ2: case OP_SAMPLE: case OP_POLE: case OP_MM1P: case OP_SNAPSHOT: return 2;
         case OP_ENV: case OP_SVF: case OP_DELAY: return 3;
         case OP_SCOPE: return 4;
@@ -121,6 +121,8 @@ struct NI {                      // per-node planning info
     int lastUse = 0;             // last in-island consumer stage
     int fusedRoot = -1;          // convolve: NI index of the root whose gain this node applies itself (the root has no task)
     bool elided = false;         // `in` leaf read directly by convolvers / root folded into its convolver: never a task
+    uint32_t ch = 0;             // output channel of a multi-output node this entry renders
+    uint32_t rec = kNone;        // node record (a multi-output node has one per channel)
 };
 
 struct IslandBuild {
@@ -143,7 +145,11 @@ struct PlanBuilder {
     explicit PlanBuilder(Engine& eng) : e(eng) {}
 
     std::vector<NI> ni;
-    std::unordered_map<int32_t, int> idx;   // node id -> NI index
+    // (node id, output channel) -> NI index. Multi-output nodes (mc.*, GraphRenderSequence.h:15-24) are planned as one
+    // single-output entry per channel; every other node only has channel 0, so an inlet that names another channel of it
+    // finds nothing and reads as a missing input, like before.
+    std::unordered_map<int64_t, int> idx;
+    static int64_t K(int32_t id, uint32_t ch = 0) { return ((int64_t)id << 8) | (int64_t)(ch & 0xFFu); }
     std::vector<std::vector<int>> seqNodes; // per root sequence
     std::vector<Node*> seqRoots;
 
@@ -204,14 +210,21 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         seqRoots.push_back(sortedRoots[s]);
         seqNodes.emplace_back();
         for (int32_t id : order) {
-            NI x;
-            x.n = &e.nodes.at(id);
-            x.seq = (int)s;
-            x.pos = (int)ni.size();
-            x.kind = kindOf(x.n->op);
-            idx[id] = (int)ni.size();
-            seqNodes.back().push_back((int)ni.size());
-            ni.push_back(x);
+            Node& node = e.nodes.at(id);
+            uint32_t numOuts = 1;                       // getRequiredOutputChannels (GraphRenderSequence.h:15-24)
+            if (node.mc) for (auto& o : node.outlets) numOuts = std::max(numOuts, std::min<uint32_t>(o.channel + 1u, 16u));
+            for (uint32_t ch = 0; ch < numOuts; ++ch) {
+                NI x;
+                x.n = &node;
+                x.seq = (int)s;
+                x.pos = (int)ni.size();
+                x.kind = kindOf(node.op);
+                x.ch = ch;
+                x.rec = e.channelRec(node, ch);
+                idx[K(id, ch)] = (int)ni.size();
+                seqNodes.back().push_back((int)ni.size());
+                ni.push_back(x);
+            }
             p.nodeIds.insert(id);
         }
     }
@@ -225,7 +238,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         if (x.n->op != OP_IN || !x.n->inlets.empty()) continue;
         bool any = false, all = true;
         for (auto& o : x.n->outlets) {
-            auto it = idx.find(o.dest);
+            auto it = idx.find(K(o.dest));
             if (it == idx.end()) continue;
             any = true;
             if (ni[it->second].n->op != OP_CONVOLVE) all = false;
@@ -235,16 +248,16 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     for (size_t sq = 0; sq < seqRoots.size(); ++sq) {
         Node* r = seqRoots[sq];
         if (r->inlets.size() != 1 || r->inlets[0].channel != 0) continue;
-        auto it = idx.find(r->inlets[0].source);
+        auto it = idx.find(K(r->inlets[0].source));
         if (it == idx.end()) continue;
         NI& c = ni[it->second];
         if (c.kind != K_CONV || c.seq != (int)sq) continue;
         size_t consumers = 0;
-        for (auto& o : c.n->outlets) if (idx.count(o.dest)) ++consumers;
+        for (auto& o : c.n->outlets) if (idx.count(K(o.dest))) ++consumers;
         if (consumers != 1) continue;
-        NI& rn = ni[idx.at(r->id)];
+        NI& rn = ni[idx.at(K(r->id))];
         rn.kind = K_CONST; rn.elided = true;
-        c.fusedRoot = idx.at(r->id);
+        c.fusedRoot = idx.at(K(r->id));
     }
 
     // ---- 2. islands ---------------------------------------------------------------------------------
@@ -276,10 +289,10 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         const uint32_t w = 1 + scratchSlots(x.n->op);
         std::set<int> deps, foreign;
         for (auto& in : x.n->inlets) {
-            auto it = idx.find(in.source);
+            auto it = idx.find(K(in.source, in.channel));
             if (it == idx.end()) continue;
             NI& s = ni[it->second];
-            if (s.kind == K_CONST || in.channel != 0) continue;
+            if (s.kind == K_CONST) continue;
             if (s.seq != x.seq) { foreign.insert(rep(s.island)); continue; }
             deps.insert(rep(s.island));
         }
@@ -361,8 +374,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         NI& x = ni[k];
         if (x.kind == K_CONST) continue;
         for (auto& in : x.n->inlets) {
-            auto it = idx.find(in.source);
-            if (it == idx.end() || in.channel != 0) continue;
+            auto it = idx.find(K(in.source, in.channel));
+            if (it == idx.end()) continue;
             NI& s = ni[it->second];
             if (s.kind == K_CONST) continue;
             if (s.island == x.island) s.needLds = true;
@@ -418,8 +431,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             if (x.n->inlets.empty()) d.inKind = 3;                                      // leaf: host input 0
             else {
                 const Inlet& in = x.n->inlets[0];
-                auto it = idx.find(in.source);
-                if (it == idx.end() || in.channel != 0) d.inKind = 4;
+                auto it = idx.find(K(in.source, in.channel));
+                if (it == idx.end()) d.inKind = 4;
                 else if (ni[it->second].elided) { d.inKind = 5; d.inIdx = ni[it->second].n->rec; }   // host channel named by the `in` record
                 else if (ni[it->second].kind == K_CONST) { d.inKind = 2; d.inIdx = ni[it->second].n->rec; }
                 else { d.inKind = 1; d.inIdx = ni[it->second].hbm; }
@@ -441,8 +454,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             }
             d.leaf = x.n->inlets.empty();
             for (auto& in : x.n->inlets) {
-                auto it = idx.find(in.source);
-                if (it == idx.end() || in.channel != 0) d.inputs.push_back({0, 0u, 0.0f});
+                auto it = idx.find(K(in.source, in.channel));
+                if (it == idx.end()) d.inputs.push_back({0, 0u, 0.0f});
                 else if (ni[it->second].kind == K_CONST && !ni[it->second].elided) d.inputs.push_back({2, ni[it->second].n->rec, 0.0f});
                 else if (ni[it->second].elided && ni[it->second].n->op == OP_IN) d.inputs.push_back({3, ni[it->second].n->rec, 0.0f});
                 else d.inputs.push_back({1, ni[it->second].hbm, 0.0f});
@@ -468,8 +481,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             if (x.kind != K_CHAIN) continue;
             if (x.n->inlets.empty()) { if (leafArity(x.n->op) > 0) anyImport = true; continue; }
             for (auto& in : x.n->inlets) {
-                auto it = idx.find(in.source);
-                if (it == idx.end() || in.channel != 0) continue;
+                auto it = idx.find(K(in.source, in.channel));
+                if (it == idx.end()) continue;
                 NI& s = ni[it->second];
                 if (s.kind != K_CONST && s.island != x.island) anyImport = true;
             }
@@ -480,8 +493,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             NI& x = ni[k];
             int lv = base, sub = 0;
             for (auto& in : x.n->inlets) {
-                auto it = idx.find(in.source);
-                if (it == idx.end() || in.channel != 0) continue;
+                auto it = idx.find(K(in.source, in.channel));
+                if (it == idx.end()) continue;
                 NI& s = ni[it->second];
                 if (s.kind == K_CONST || s.island != x.island) continue;
                 // Sample-parallel ops are lane-local (lane l reads and writes only samples l + 64j of
@@ -508,8 +521,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         for (int k : B.nodes) {
             NI& x = ni[k];
             for (auto& in : x.n->inlets) {
-                auto it = idx.find(in.source);
-                if (it == idx.end() || in.channel != 0) continue;
+                auto it = idx.find(K(in.source, in.channel));
+                if (it == idx.end()) continue;
                 NI& s = ni[it->second];
                 if (s.kind == K_CONST) continue;
                 if (s.island == x.island) s.lastUse = std::max(s.lastUse, x.level);
@@ -610,7 +623,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         auto makeMember = [&](NI& x) -> Member {
             Member m{};
             memberNode.push_back((int)(&x - ni.data()));
-            m.rec = localOf(x.n->rec);
+            m.rec = localOf(x.rec);
             m.opnd = (uint32_t)operands.size();
             m.outLds = x.needLds ? x.lds : kNone;
             m.outHbm = x.exported ? x.hbm : kNone;
@@ -626,8 +639,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             }
             m.nin = (uint32_t)x.n->inlets.size();
             for (auto& in : x.n->inlets) {
-                auto it = idx.find(in.source);
-                if (it == idx.end() || in.channel != 0) { operandSrc.push_back(-1); operands.push_back(kOpZero); continue; }
+                auto it = idx.find(K(in.source, in.channel));
+                if (it == idx.end()) { operandSrc.push_back(-1); operands.push_back(kOpZero); continue; }
                 NI& s = ni[it->second];
                 if (s.kind == K_CONST) { operandSrc.push_back(-1); operands.push_back(kOpConst | cellFor(s.n)); }
                 else if (s.island == x.island) { operandSrc.push_back(it->second); operands.push_back(kOpLds | s.lds); }
@@ -704,8 +717,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             auto constMaskOf = [&](NI& x) -> uint32_t {
                 uint32_t mask = 0;
                 for (size_t q = 0; q < x.n->inlets.size() && q < 8; ++q) {
-                    auto it = idx.find(x.n->inlets[q].source);
-                    if (it == idx.end() || x.n->inlets[q].channel != 0) { mask |= 1u << q; continue; }   // zero operand
+                    auto it = idx.find(K(x.n->inlets[q].source, x.n->inlets[q].channel));
+                    if (it == idx.end()) { mask |= 1u << q; continue; }   // zero operand
                     if (ni[it->second].kind == K_CONST) mask |= 1u << q;
                 }
                 return mask;
@@ -1149,7 +1162,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     }
     for (size_t s = 0; s < seqRoots.size(); ++s) {
         Node* r = seqRoots[s];
-        NI& x = ni[idx.at(r->id)];
+        NI& x = ni[idx.at(K(r->id))];
         p.roots.push_back(RootEntry{r->rec, x.hbm});
         p.rootIds.push_back(r->id);
         for (int k : seqNodes[s]) if (ni[k].n->op == OP_TAPOUT) p.taps.push_back(TapEntry{ni[k].n->rec, r->rec});

@@ -10,7 +10,7 @@ reference does, e.g. ``cycle(f) = sin(mul(2π, phasor(f)))`` (lib/oscillators.ts
 from __future__ import annotations
 
 import math
-from typing import Any, Dict, Optional
+from typing import List, Any, Dict, Optional
 
 from .reconciler import ElemNode, NodeRepr, create_node, resolve, unpack  # noqa: F401
 
@@ -386,3 +386,30 @@ def compress(attack_ms: ElemNode, release_ms: ElemNode, threshold: ElemNode, rat
     gain = mul(adjusted, sub(threshold, env_db))
     clean = min(0, gain)
     return mul(xn, db2gain(clean))
+
+
+# ---- lib/mc.ts: multi-channel nodes; each returns one NodeRepr per output channel (nodeUtils unpack) --------------
+class mc:
+    @staticmethod
+    def _n(kind: str, props: Dict[str, Any], *children: ElemNode) -> List[NodeRepr]:
+        from .reconciler import unpack
+        p = dict(props)
+        channels = p.pop("channels", None)
+        if not isinstance(channels, (int, float)) or channels <= 0:
+            raise ValueError("Must provide a positive number channels prop")
+        return unpack(_n(kind, p, *children), int(channels))
+
+    @staticmethod
+    def table(props: Dict[str, Any], t: ElemNode) -> List[NodeRepr]:
+        """lib/mc.ts:91-107"""
+        return mc._n("mc.table", props, t)
+
+    @staticmethod
+    def sample(props: Dict[str, Any], gate: ElemNode) -> List[NodeRepr]:
+        """lib/mc.ts:12-34"""
+        return mc._n("mc.sample", props, gate)
+
+    @staticmethod
+    def sampleseq(props: Dict[str, Any], t: ElemNode) -> List[NodeRepr]:
+        """lib/mc.ts:36-56"""
+        return mc._n("mc.sampleseq", props, t)

@@ -86,13 +86,24 @@ NODE_CASES = {
                         el.sample({"path": "/t/ramp", "mode": "loop", "startOffset": 20, "stopOffset": 50}, el.train(5.0), 0.37),
                         el.sample({"path": "/t/five", "mode": "loop"}, el.train(300.0), 0.25),
                         el.sample({"path": "/t/ramp", "mode": "trigger", "startOffset": 10}, el.train(700.0), 2.0)], 1),
+    # multi-output nodes, one root per output channel (the port oracle has no mc nodes: reference only)
+    "mc": (lambda: el.mc.table({"path": "/t/stereo", "channels": 2}, el.add(0.5, X()))
+                   + el.mc.sample({"path": "/t/stereo", "channels": 2, "mode": "loop", "playbackRate": 0.75, "startOffset": 7}, el.train(9.0))
+                   + el.mc.sample({"path": "/t/stereo", "channels": 2, "mode": "gate"}, el.train(31.0))
+                   + el.mc.sampleseq({"path": "/t/stereo", "channels": 2, "duration": 300,
+                                      "seq": [{"time": 0, "value": 1}, {"time": 900, "value": 0}, {"time": 2000, "value": 1}, {"time": 5000, "value": 0}]},
+                                     el.counter(1)), 1),
 }
 
 # shared resources the cases above load (name -> channel-0 samples)
+REF_ONLY = {"mc"}      # cases the plain-C port oracle cannot render (checked against oracle/_ref only)
+
+
 def node_case_resources():
     import numpy as np
     return {"/t/ramp": (np.arange(300, dtype=np.float32) / 300.0 + 0.25).astype(np.float32),
-            "/t/five": np.asarray([1, 2, 3, 4, 5], np.float32), "/t/one": np.asarray([0.75], np.float32)}
+            "/t/five": np.asarray([1, 2, 3, 4, 5], np.float32), "/t/one": np.asarray([0.75], np.float32),
+            "/t/stereo": np.stack([np.arange(300, dtype=np.float32) / 300.0 + 0.25, np.cos(np.arange(300, dtype=np.float32) * 0.05)]).astype(np.float32)}
 
 
 

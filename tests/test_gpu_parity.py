@@ -30,12 +30,16 @@ def _engines():
     return hip, chk
 
 
-from cases import NODE_CASES, node_case_resources, sampleseq_scenario
+from cases import NODE_CASES, REF_ONLY, node_case_resources, sampleseq_scenario
 
 
 @pytest.mark.parametrize("name", sorted(NODE_CASES))
 def test_node_parity(gpu_required, name):
     roots_fn, n_in = NODE_CASES[name]
+    if name in REF_ONLY:
+        import oracle
+        if not oracle.have_ref():
+            pytest.skip("needs oracle/_ref")
     hip, chk = _engines()
     a, b = render_pair(hip, chk, roots_fn, sample_rate=44100.0, blocks=14, n_in=n_in, resources=node_case_resources())
     assert np.isfinite(a).all()

@@ -8,7 +8,7 @@ import pytest
 
 from elementary_amd import el, graphs
 from helpers import lcg_noise
-from cases import NODE_CASES, node_case_resources
+from cases import NODE_CASES, REF_ONLY, node_case_resources
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -57,6 +57,10 @@ def test_spec_node_case(gpu_required, name):
     block, and vs the interpreter kernels of a second HIP engine."""
     from elementary_amd.runtime import Runtime
     roots_fn, n_in = NODE_CASES[name]
+    if name in REF_ONLY:
+        import oracle
+        if not oracle.have_ref():
+            pytest.skip("needs oracle/_ref")
     nb = 17
     a, b, c = _spec_runtime(44100.0, 512, batch=5), Runtime(44100.0, 512), _checker(44100.0, 512)
     b.set_option("specialize", 0)

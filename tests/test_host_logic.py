@@ -173,3 +173,21 @@ def test_shared_resources_are_insert_only():
     assert rt.add_shared_resource("ir", np.zeros(16, dtype=np.float32)) is False
     rt.prune_shared_resources()
     assert rt.add_shared_resource("ir", np.zeros(16, dtype=np.float32)) is True   # pruned: nobody held it
+
+
+def test_multi_output_node_gets_one_plan_entry_per_channel():
+    """GraphRenderSequence.h:15-24: a node's output buffers = highest outlet channel + 1. mc.table unpacked to 3 channels
+    becomes three table lookups (one record each) feeding the add."""
+    import numpy as np
+    from elementary_amd import el
+    from elementary_amd.runtime import Runtime
+    rt = Runtime(44100.0, 512, device=-1)
+    assert rt.add_shared_resource("/v/stereo", np.asarray([[27, 27, 27], [15, 15, 15]], np.float32))
+    res = rt.render(el.add(*el.mc.table({"path": "/v/stereo", "channels": 3}, 0)))
+    assert res["result"] == 0
+    appends = [i for i in res["batch"] if i[0] == 2]
+    table_id = [i[1] for i in res["batch"] if i[0] == 0 and i[2] == "mc.table"][0]
+    assert sorted(i[3] for i in appends if i[2] == table_id) == [0, 1, 2]     # APPEND_CHILD carries the child's output channel
+    plan = rt.describe_plan()
+    assert plan["num_nodes"] == 4                                              # const, mc.table, add, root
+    assert plan["num_tasks"] >= 5                                              # 3 table lookups + add + root

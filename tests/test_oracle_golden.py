@@ -39,6 +39,7 @@ def core_factory(request):
     def same(got, want):      # the CPU engines reproduce the recorded float32 snapshots exactly
         assert got.tolist() == list(want)
     make.same = same
+    make.name = request.param[0]
     return make
 
 
@@ -259,3 +260,105 @@ def test_snapshot_and_named_meter_events(core_factory):
     assert len(snaps) == 3 and all(s["source"] == "s" for s in snaps)            # one rising edge every 128 frames
     make_vals = [s["data"] for s in snaps]
     assert make_vals == sorted(make_vals) and make_vals[0] >= 0.0
+
+
+def test_mc_table_snapshots(core_factory):
+    """mc.test.js:4-84: a multi-output node (numOuts = highest outlet channel + 1, GraphRenderSequence.h:15-24) unpacked to
+    2, 3 and 1 channels of a stereo resource, the gc() in between, and the first graph again."""
+    if getattr(core_factory, "name", "") == "port":
+        pytest.skip("the C++ restatement has no mc.* nodes")
+    stereo = np.asarray([[27, 27, 27], [15, 15, 15]], np.float32)
+    core = core_factory(num_input_channels=0, num_output_channels=1,
+                        virtual_file_system={"/v/ones": np.asarray([1, 1, 1], np.float32), "/v/stereo": stereo})
+    core.render(el.add(*el.mc.table({"path": "/v/stereo", "channels": 2}, 0)))
+    core.process([], [f32(5120)])
+    out = [f32(16)]
+    core.process([], out)
+    core_factory.same(out[0], GOLD["mc:mc table 1"])
+    core.render(el.add(*el.mc.table({"path": "/v/stereo", "channels": 3}, 0)))
+    for _ in range(101):
+        core.process([], out)
+    core_factory.same(out[0], GOLD["mc:mc table 2"])
+    core.render(el.add(*el.mc.table({"path": "/v/stereo", "channels": 1}, 0)))
+    for _ in range(101):
+        core.process([], out)
+    core_factory.same(out[0], GOLD["mc:mc table 3"])
+    assert sorted(core.gc()) == sorted([1611541315, 1811703364])     # the first graph's add and root (mc.test.js:70)
+    core.render(el.add(*el.mc.table({"path": "/v/stereo", "channels": 2}, 0)))
+    for _ in range(101):
+        core.process([], out)
+    core_factory.same(out[0], GOLD["mc:mc table 4"])
+
+
+def _skip_port(core_factory):
+    if getattr(core_factory, "name", "") == "port":
+        pytest.skip("the C++ restatement has no mc.* nodes")
+
+
+def test_mc_sampleseq_snapshots(core_factory):
+    """mc.test.js:86-140: mc.sampleseq over a stereo buffer, time held by a ref'd const, then a jump into the last event."""
+    _skip_port(core_factory)
+    stereo = np.stack([np.full(128, 27, np.float32), np.full(128, 15, np.float32)])
+    core = core_factory(num_input_channels=0, num_output_channels=1, virtual_file_system={"/v/stereo": stereo})
+    time, set_time = core.create_ref("const", {"value": 0}, [])
+    core.render(el.add(*el.mc.sampleseq({"path": "/v/stereo", "channels": 2, "duration": 128,
+                                         "seq": [{"time": 0, "value": 0}, {"time": 128, "value": 1}, {"time": 256, "value": 0}, {"time": 512, "value": 1}]}, time)))
+    core.process([], [f32(5120)])
+    out = [f32(32)]
+    core.process([], out)
+    core_factory.same(out[0], GOLD["mc:mc sampleseq 1"])
+    set_time({"value": 520})
+    for _ in range(10):
+        core.process([], out)
+    core_factory.same(out[0], GOLD["mc:mc sampleseq 2"])
+
+
+def test_mc_sample_gate_and_trigger(core_factory):
+    """mc.test.js:189-282: playback starts on the trigger with a 4 ms fade, settles at the sum of the channels; a gate
+    inside a block opens and closes the fade mid-block."""
+    _skip_port(core_factory)
+    stereo = np.stack([np.full(512, 27, np.float32), np.full(512, 15, np.float32)])
+    core = core_factory(num_input_channels=1, num_output_channels=1, block_size=32, virtual_file_system={"/v/stereo": stereo})
+    gate, set_gate = core.create_ref("const", {"value": 0}, [])
+    core.render(el.add(*el.mc.sample({"path": "/v/stereo", "channels": 2}, gate)))
+    inp, out = [f32(32)], [f32(32)]
+    for _ in range(1000):
+        core.process(inp, out)
+    core.process(inp, out)
+    assert np.array_equal(out[0], np.zeros(32, np.float32))
+    set_gate({"value": 1})
+    for _ in range(5):
+        core.process(inp, out)
+        assert (out[0][1:] >= 0).all() and (out[0][1:] < 42).all() and (np.diff(out[0]) > 0).all()
+    core.process(inp, out)
+    core.process(inp, out)
+    assert np.array_equal(out[0], np.full(32, 42, np.float32))
+    core.render(el.add(*el.mc.sample({"path": "/v/stereo", "channels": 2, "mode": "gate"}, el.in_({"channel": 0}))))
+    for _ in range(1000):
+        core.process(inp, out)
+    inp[0][8:16] = 1.0
+    core.process(inp, out)
+    assert np.array_equal(out[0][:8], np.zeros(8, np.float32))
+    assert (out[0][8:16] >= 0).all() and (out[0][8:16] < 42).all() and (np.diff(out[0][7:16]) >= 0).all()
+    assert (np.diff(out[0][16:24]) <= 0).all()
+    core_factory.keep = out[0].copy()
+
+
+def test_mc_sample_loop_snapshots(core_factory):
+    """mc.test.js:284-361 ("mc.sample again"): loop mode, playbackRate 2, start/stop offsets."""
+    _skip_port(core_factory)
+    ramp = np.asarray([1, 2, 3, 4, 5, 6, 7, 8], np.float32)
+    core = core_factory(num_input_channels=0, num_output_channels=1, block_size=32, virtual_file_system={"/v/stereo": np.stack([ramp, ramp])})
+    out = [f32(32)]
+    core.render(el.add(*el.mc.sample({"path": "/v/stereo", "channels": 2, "mode": "loop", "key": "test"}, 1)))
+    for _ in range(1000):
+        core.process([], out)
+    core_factory.same(out[0], GOLD["mc:mc.sample again 1"])
+    core.render(el.add(*el.mc.sample({"path": "/v/stereo", "channels": 2, "mode": "loop", "key": "test", "playbackRate": 2.0}, 1)))
+    core.process([], out)
+    core_factory.same(out[0], GOLD["mc:mc.sample again 2"])
+    core.render(el.add(*el.mc.sample({"path": "/v/stereo", "channels": 2, "mode": "loop", "key": "test2", "playbackRate": 2.0,
+                                      "startOffset": 1, "stopOffset": 1}, 1)))
+    for _ in range(1000):
+        core.process([], out)
+    core_factory.same(out[0], GOLD["mc:mc.sample again 3"])
