@@ -112,6 +112,7 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--voices", type=int, default=256)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra engine option (tuning experiments), repeatable")
     ap.add_argument("--specialize", type=int, default=2, choices=[0, 1, 2],
                     help="0: interpreter island kernels only; 2: per-island-shape kernels compiled at plan build (kcache/ on disk)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -150,6 +151,9 @@ def main() -> None:
     rt.set_option("graph_blocks", args.graph_blocks)
     rt.set_option("batch_blocks", B)
     rt.set_option("specialize", args.specialize)
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        rt.set_option(k, float(v))
     t0 = time.perf_counter()
     res = rt.render(*graphs.c2_graph(voices=my_voices, channels=2, first_voice=first))
     assert res["result"] == 0, res["result"]

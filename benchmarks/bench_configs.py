@@ -105,7 +105,18 @@ def c3(args):
     c, m = _time_cpu(cpu, ch, ch, x[:, :BLOCK].copy())
     alg = graphs.c3_algorithmic_bytes(ch)
     conv_us = 1e3 * (lv[1] if len(lv) > 2 else lv[0])    # the convolve launch (level 0 once `in` / root are folded into it)
+    wasm = None     # the reference's own engine (wasm build) timed in the authoring container: benchmarks/c3_wasm_baseline.js
+    try:
+        import json as _json, os as _os
+        w = _json.load(open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "profiles", "r02", "c3_wasm_reference_cpu.json")))
+        wasm = {k: w[k] for k in ("us_per_block_mean", "us_per_block_p50", "us_per_block_p99", "host_cpu", "measured_on")}
+    except Exception:
+        pass
     return {"config": "C3 8-channel convolution reverb, 96 000-tap IRs, sr 48000", "gpu_us_per_block": 1e6 * g,
+            "gpu_path": "elemhip_process_blocks: multi-block convolve kernels (fft / mac / finish per 64-block launch set)",
+            "gpu_launch_set_profile": getattr(_time_gpu, "last_profile", None), "batch_launches": rt.stats()["batch_launches"],
+            "single_block_launch_note": "launch_us / conv_kernel_us below time the block-at-a-time path (elemhip_process)",
+            "reference_wasm_cpu": wasm,
             "gpu_samples_per_s": BLOCK / g, "cpu_us_per_block": 1e6 * c, "cpu_kind": kind + " (plain radix-2 FFT, not Ooura)",
             "cpu_blocks_timed": m, "speedup": c / g, "launch_us": [1e3 * v for v in lv],
             "algorithmic_bytes_per_block": alg, "conv_kernel_us": conv_us,

@@ -263,11 +263,178 @@ void elemhip_convolve_kernel(PlanView pv, uint32_t* recs, float* hbm, const Glob
     else conv_helper(d, role - 1u, (gup)recs, g, A);
 }
 
+// ---- multi-block launches (elemhip_process_blocks) --------------------------------------------------------------------
+// With B whole 512-frame blocks in one launch set, every input block of the batch is known before the convolve level
+// starts (the levels in front of it rendered all B blocks), so nothing is left of the per-block latency path:
+//   K1  (node, j): spectrum of input block j -> Xnew[j]                                 (one forward FFT each, all parallel)
+//   K2  (node, j): Y_j = sum_p H_p X_{b0+j-p} over ALL partitions (new spectra from Xnew, older ones from the ring),
+//                  inverse FFT, head half -> the node's output buffer of block j, tail half -> tails[j + 1]
+//   K3  (node, j): out_j += tails[j] (tails[0] = the overlap carried in), folded root gain; last B (<= P) spectra go
+//                  into the ring, tails[B] becomes the carried overlap, the block counter advances by B.
+// Three launches per launch set instead of two per block. The helpers' pre-multiplied sums are not produced: the first
+// per-block call after a batch takes conv_main's own older_sum path once. The host only uses this path while every
+// call so far rendered whole 512-frame blocks (fill == 0, Engine::convAligned).
+// Scratch per node (floats): [0] b0 | 16 + Xnew[B][512] c2 | tails[B + 1][512]
+namespace {
+
+constexpr uint32_t kBatchHdr = 16;
+__device__ __forceinline__ size_t batch_scratch_floats(uint32_t maxBatch) { return kBatchHdr + (size_t)maxBatch * 1024u + (size_t)(maxBatch + 1u) * 512u; }
+
+struct BatchCtx {
+    State st; bool live; uint32_t inKind, inBuf; float cval; gfp scratch; gf2p xnew; gfp tails; float gain;
+};
+
+// decode shared by the three kernels; live == false: the node writes zeros (Convolve.h:70-71) or does nothing
+__device__ __forceinline__ bool batch_ctx(const ConvDesc& d, gup recs, const Globals* g, float* scratchAll, uint32_t convIdx, uint32_t maxBatch, BatchCtx& c) {
+    gcup r = (gcup)(recs + d.rec * kRecDwords);
+    const uint64_t sp = (uint64_t)r[rec::CONV_STATE] | ((uint64_t)r[rec::CONV_STATE + 1] << 32);
+    c.inKind = d.inKind; c.inBuf = d.inIdx;
+    if (c.inKind == 3u) { c.inKind = g->numIn > 0 ? 1u : 0u; c.inBuf = 0u; }
+    if (c.inKind == 5u) {
+        const uint32_t ch = ((gcup)recs)[d.inIdx * kRecDwords + rec::P0];
+        if (ch < g->numIn) { c.inKind = 1u; c.inBuf = ch; } else c.inKind = 4u;
+    }
+    c.cval = c.inKind == 2u ? __uint_as_float(((gcup)recs)[d.inIdx * kRecDwords + rec::P0]) : 0.0f;
+    c.gain = 1.0f;
+    if (d.fuseRootRec != kNone) c.gain = __uint_as_float(((gcup)recs)[d.fuseRootRec * kRecDwords + rec::ROOT_TARGET]);   // settled fades only (Engine::batchEligible)
+    c.scratch = (gfp)(scratchAll + (size_t)convIdx * batch_scratch_floats(maxBatch));
+    c.xnew = (gf2p)(c.scratch + kBatchHdr);
+    c.tails = c.scratch + kBatchHdr + (size_t)maxBatch * 1024u;
+    c.live = false;
+    if (sp == 0ull || c.inKind == 0u) return false;
+    c.st = state_of((gup)reinterpret_cast<uint32_t*>(sp));
+    if (c.st.P == 0u) return false;
+    c.live = true;
+    return true;
+}
+
+} // namespace
+
+__global__ __launch_bounds__(256)
+void elemhip_convolve_batch_fft(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
+                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch) {
+    __shared__ c2 A[conv::kFft], B[conv::kFft], W[conv::kFft];
+    const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, j = blockIdx.y, tid = threadIdx.x;
+    const ConvDesc d = pv.convs[convIdx];
+    if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
+    BatchCtx c;
+    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) return;
+    const uint32_t stride = g->blockStride;
+    gcfp in = (gcfp)(hbm + (size_t)j * arenaFloats + (size_t)(c.inKind == 1u ? c.inBuf : 0u) * stride);
+    for (uint32_t i = tid; i < conv::kFft; i += 256u) W[i] = kTwiddle[i];
+#pragma unroll
+    for (uint32_t q = 0; q < 2; ++q) {
+        const uint32_t i = tid + 256u * q;
+        A[i] = mk(c.inKind == 1u ? in[i] : c.cval, 0.0f);
+        A[i + 512u] = mk(0.0f, 0.0f);
+    }
+    __syncthreads();
+    fft1024(A, B, W, tid);
+#pragma unroll
+    for (uint32_t q = 0; q < 2; ++q) {
+        const uint32_t k = tid + 256u * q;
+        c.xnew[(size_t)j * 512u + k] = k == 0u ? mk(B[0].x, B[512].x) : B[k];
+    }
+    if (j == 0u) {   // what the later kernels must not read from state another workgroup of theirs rewrites
+        for (uint32_t i = tid; i < 512u; i += 256u) c.tails[i] = c.st.overlap[i];
+        if (tid == 0u) ((gup)c.scratch)[0] = c.st.hdr[conv::H_BLK];
+    }
+}
+
+__global__ __launch_bounds__(256)
+void elemhip_convolve_batch_mac(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
+                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch) {
+    __shared__ c2 A[conv::kFft], B[conv::kFft], W[conv::kFft];
+    const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, j = blockIdx.y, tid = threadIdx.x;
+    const ConvDesc d = pv.convs[convIdx];
+    if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
+    BatchCtx c;
+    const uint32_t stride = g->blockStride;
+    gfp out = (gfp)hbm + (size_t)j * arenaFloats + (size_t)d.outHbm * stride;
+    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) {
+        for (uint32_t i = tid; i < 512u; i += 256u) out[i] = 0.0f;
+        return;
+    }
+    for (uint32_t i = tid; i < conv::kFft; i += 256u) W[i] = kTwiddle[i];
+    const uint32_t P = c.st.P, b0 = c.st.hdr[conv::H_BLK], bm = (b0 + j) % P;
+    // bins 2 tid, 2 tid + 1: one 16-byte load per spectrum and partition
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) const f4* gcf4p;
+    gcf4p H4 = (gcf4p)c.st.H + tid, X4 = (gcf4p)c.st.X + tid, N4 = (gcf4p)c.xnew + tid;
+    c2 acc0 = mk(0.0f, 0.0f), acc1 = mk(0.0f, 0.0f);
+    auto src = [&](uint32_t p) -> f4 {   // X_{b0 + j - p}: a spectrum of this batch, or the ring
+        if (p <= j) return N4[(size_t)(j - p) * 256u];
+        const uint32_t slot = bm >= p ? bm - p : bm + P - p;
+        return X4[(size_t)slot * 256u];
+    };
+    uint32_t p = 0;
+    for (; p + 8u <= P; p += 8u) {
+        f4 h[8], x[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) { h[u] = H4[(size_t)(p + u) * 256u]; x[u] = src(p + u); }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            acc0 = cadd(acc0, smul(mk(h[u].x, h[u].y), mk(x[u].x, x[u].y), tid == 0u));
+            acc1 = cadd(acc1, cmul(mk(h[u].z, h[u].w), mk(x[u].z, x[u].w)));
+        }
+    }
+    for (; p < P; ++p) {
+        const f4 h = H4[(size_t)p * 256u], x = src(p);
+        acc0 = cadd(acc0, smul(mk(h.x, h.y), mk(x.x, x.y), tid == 0u));
+        acc1 = cadd(acc1, cmul(mk(h.z, h.w), mk(x.z, x.w)));
+    }
+    const uint32_t k0 = 2u * tid, k1 = k0 + 1u;
+    if (tid == 0u) { A[0] = mk(acc0.x, 0.0f); A[512] = mk(acc0.y, 0.0f); }
+    else { A[k0] = mk(acc0.x, -acc0.y); A[1024u - k0] = acc0; }
+    A[k1] = mk(acc1.x, -acc1.y); A[1024u - k1] = acc1;
+    __syncthreads();
+    fft1024(A, B, W, tid);
+    for (uint32_t i = tid; i < 512u; i += 256u) {
+        out[i] = B[i].x;
+        c.tails[(size_t)(j + 1u) * 512u + i] = B[512u + i].x;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void elemhip_convolve_batch_finish(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
+                                   uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch) {
+    const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, j = blockIdx.y, tid = threadIdx.x, batch = gridDim.y;
+    const ConvDesc d = pv.convs[convIdx];
+    if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
+    BatchCtx c;
+    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) return;
+    const uint32_t stride = g->blockStride, P = c.st.P, b0 = ((gcup)c.scratch)[0];
+    gfp out = (gfp)hbm + (size_t)j * arenaFloats + (size_t)d.outHbm * stride;
+    for (uint32_t i = tid; i < 512u; i += 256u) {
+        const float y = out[i] + c.tails[(size_t)j * 512u + i];
+        out[i] = d.fuseRootRec == kNone ? y : y * c.gain;
+    }
+    if (j + P >= batch)   // the newest min(B, P) spectra are the ones later blocks read
+        for (uint32_t k = tid; k < 512u; k += 256u) c.st.X[(size_t)((b0 + j) % P) * 512u + k] = c.xnew[(size_t)j * 512u + k];
+    if (j + 1u == batch) {
+        for (uint32_t i = tid; i < 512u; i += 256u) c.st.overlap[i] = c.tails[(size_t)batch * 512u + i];
+        if (tid == 0u) {
+            c.st.hdr[conv::H_BLK] = b0 + batch; c.st.hdr[conv::H_BLK_NEXT] = b0 + batch;
+            c.st.hdr[conv::H_FILL] = 0u; c.st.hdr[conv::H_FILL_NEXT] = 0u;
+        }
+    }
+}
+
 namespace elemhip {
 
 void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g,
                      uint32_t workBegin, uint32_t numWorkgroups) {
     hipLaunchKernelGGL(elemhip_convolve_kernel, dim3(numWorkgroups), dim3(256), 0, s, pv, recs, hbm, g, workBegin);
+}
+
+size_t convolve_batch_scratch_floats(uint32_t maxBatch) { return 16u + (size_t)maxBatch * 1024u + (size_t)(maxBatch + 1u) * 512u; }
+
+void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
+                           uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch) {
+    const dim3 grid(numNodes, batch), block(256);
+    hipLaunchKernelGGL(elemhip_convolve_batch_fft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
+    hipLaunchKernelGGL(elemhip_convolve_batch_mac, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
+    hipLaunchKernelGGL(elemhip_convolve_batch_finish, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
 }
 
 hipError_t upload_convolve_tables(const float* twiddleReIm /* 2 * 1024 floats */) {

@@ -159,6 +159,7 @@ Engine::~Engine() {
     if (dRecs) (void)hipFree(dRecs);
     if (dGlobals) (void)hipFree(dGlobals);
     if (dLcg) (void)hipFree(dLcg);
+    if (dConvScratch) (void)hipFree(dConvScratch);
     if (dHbm) (void)hipFree(dHbm);
     if (dOutRing) (void)hipFree(dOutRing);
     for (hipEvent_t e : profEvents) (void)hipEventDestroy(e);
@@ -848,11 +849,13 @@ int Engine::activateRoots(const std::vector<int32_t>& ids, bool malformedTail) {
     return kOk;
 }
 
-int Engine::commit() {   // Runtime.h:202-206
+// `renderLock` holds `mu` on entry and on return; buildPlan releases it while it plans (the render thread keeps
+// rendering the current plan meanwhile — the role of the reference's SPSC sequence queue, Runtime.h:207-216, 277-285).
+int Engine::commit(std::unique_lock<std::mutex>& renderLock) {   // Runtime.h:202-206
     if (shouldRebuild || rebuildOwed || (planStale && (current || pending))) {
         planStale = false;
         auto t0 = std::chrono::steady_clock::now();
-        auto p = buildPlan();
+        auto p = buildPlan(renderLock);
         // (not a reference code path: its buildRenderSequence cannot fail. The roots stay swapped as in the reference;
         // the rebuild stays owed so that the next commit retries instead of rendering the old sequence forever.)
         if (!p) { rebuildOwed = true; return kUnsupportedGraph; }
@@ -866,7 +869,8 @@ int Engine::commit() {   // Runtime.h:202-206
 }
 
 int Engine::apply(const Value& batch) {   // Runtime.h:170-218
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> control(ctl);
+    std::unique_lock<std::mutex> lock(mu);
     if (!dry && hipSetDevice(device) != hipSuccess) return kHipError;
     if (!batch.isArray()) return kInvalidInstructionFormat;
     shouldRebuild = false;   // a local in the reference: ACTIVATE_ROOTS and COMMIT must share a batch
@@ -902,7 +906,7 @@ int Engine::apply(const Value& batch) {   // Runtime.h:170-218
                 break;
             }
             case 5:   // COMMIT_UPDATES
-                res = commit();
+                res = commit(lock);
                 break;
             default: break;
         }
@@ -913,6 +917,7 @@ int Engine::apply(const Value& batch) {   // Runtime.h:170-218
 
 // ---- event relay ------------------------------------------------------------------------------------
 int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), void* user) {   // Runtime.h:437-446
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     if (dry || !current || !cb) return kOk;
     if (hipSetDevice(device) != hipSuccess) return kHipError;
@@ -976,6 +981,7 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
 
 // ---- gc / resources -------------------------------------------------------------------------------
 size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     if (!dry) (void)hipSetDevice(device);
     std::vector<int32_t> pruned;
@@ -1019,6 +1025,7 @@ size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
 }
 
 size_t Engine::lastGc(int32_t* out, size_t cap) {
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     size_t k = 0;
     for (int32_t id : lastPruned) { if (out && k < cap) out[k] = id; ++k; }
@@ -1026,6 +1033,7 @@ size_t Engine::lastGc(int32_t* out, size_t cap) {
 }
 
 bool Engine::hasNode(int32_t id) {
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     return nodes.find(id) != nodes.end();
 }
@@ -1033,6 +1041,7 @@ bool Engine::hasNode(int32_t id) {
 // Runtime::reset (Runtime.h:448-458) forwards to every node; of the built-ins only SampleNode reacts: both readers get
 // noteOff(), i.e. target gain 0 (Sample.h:78-81, 174-177). The reader state lives in the node record.
 void Engine::reset() {
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     for (auto& kv : nodes) {
         Node& n = kv.second;
@@ -1048,6 +1057,7 @@ void Engine::reset() {
 }
 
 int Engine::registerNodeType(const std::string& type, const HostVTable& vt) {   // Runtime.h:480-487
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     if (hostTypes.count(type) || opTable().count(type)) return kNodeTypeAlreadyExists;
     if (!vt.process) return kInvalidInstructionFormat;
@@ -1061,6 +1071,7 @@ static std::string idToHex(int32_t id) {   // Types.h:16-27
 }
 
 std::string Engine::snapshotJson() {   // Runtime.h:489-498: { nodeIdToHex(id): node.getProperties() }
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     std::map<std::string, const Node*> sorted;
     for (auto& kv : nodes) sorted.emplace(idToHex(kv.first), &kv.second);
@@ -1083,6 +1094,7 @@ std::string Engine::snapshotJson() {   // Runtime.h:489-498: { nodeIdToHex(id): 
 }
 
 std::string Engine::sharedResourceKeysJson() {   // SharedResourceMap::keys (SharedResource.h)
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     std::vector<std::string> keys;
     for (auto& kv : resources) keys.push_back(kv.first);
@@ -1094,6 +1106,7 @@ std::string Engine::sharedResourceKeysJson() {   // SharedResourceMap::keys (Sha
 }
 
 bool Engine::addSharedResource(const std::string& name, const float* const* ch, size_t nCh, size_t nSamples) {
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     if (resources.count(name)) return false;                 // insert-only (SharedResource.h:61-63)
     auto r = std::make_shared<Resource>();
@@ -1103,6 +1116,7 @@ bool Engine::addSharedResource(const std::string& name, const float* const* ch, 
 }
 
 void Engine::pruneSharedResources() {   // SharedResource.h:94-102
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     if (!dry) (void)hipSetDevice(device);
     for (auto it = resources.begin(); it != resources.end();) {
@@ -1115,9 +1129,12 @@ void Engine::pruneSharedResources() {   // SharedResource.h:94-102
 }
 
 int Engine::setOption(const std::string& key, double value) {
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
     if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(64, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
+    if (key == "debug_build_delay_ms") { debugBuildDelayMs = std::max(0, (int)value); return kOk; }   // tests: stretches the unlocked part of a plan build
+    if (key == "stateless_rows") { statelessRows = (uint32_t)std::max(1, std::min(64, (int)value)); return kOk; }   // gridDim.y of a multi-block launch: blocks that stateless islands render side by side
     if (key == "pipeline_copies") { pipelineCopies = std::max(1, std::min(6, (int)value)); planStale = true; return kOk; }   // next commit re-plans
     if (key == "specialize") { specialize = std::max(0, std::min(2, (int)value)); planStale = true; return kOk; }   // next commit re-plans
     if (key == "profile_launches") {
@@ -1297,6 +1314,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     if (hipSetDevice(device) != hipSuccess) return kHipError;
     if (n > (size_t)blockSize) return kBlockTooLarge;
     if (nIn > kMaxHostIn || nOut > kMaxOut) return kTooManyChannels;
+    if (n != conv::kBlock) convAligned = false;   // a convolver's input block may now be partly filled at a call boundary
     int rc = swapInPending();
     if (rc != kOk) return rc;
     if (!current) return kOk;   // no render sequence yet: outputs untouched (Runtime.h:287-289)
@@ -1373,7 +1391,7 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
     for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -kHipError;
     std::vector<double> acc(L + 2, 0.0);
     // timeBatch > 1: time the multi-block launches elemhip_process_blocks issues (msOut = per LAUNCH of `batch` blocks)
-    const uint32_t batch = (timeBatch > 1 && batchEligible(p, nOut)) ? (uint32_t)timeBatch : 1u;
+    const uint32_t batch = (timeBatch > 1 && p.convs.empty() && batchEligible(p, nOut)) ? (uint32_t)timeBatch : 1u;
     const uint32_t arenaFloats = batch > 1 ? p.numHbmBuffers * (uint32_t)blockSize : 0u;
     if (batch > 1) {
         rc = ensureHbm((size_t)p.numHbmBuffers * batch); if (rc != kOk) return -rc;
@@ -1384,7 +1402,7 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
         for (size_t l = 0; l < L; ++l) {
             const uint32_t lb = p.levelOffsets[l], le = p.levelOffsets[l + 1];
             (void)hipEventRecord(ev[2 * l], stream);
-            if (le > lb) { if (batch > 1) launchLevelBatch(p, l, batch, arenaFloats); else launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l], batch, arenaFloats); }
+            if (le > lb) { if (batch > 1) launchLevelBatch(p, l, batch, arenaFloats); else launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l], batch, arenaFloats, statelessRows); }
             if (p.convLevelOffsets[l + 1] > p.convLevelOffsets[l])
                 launch_convolve(stream, p.view, dRecs, dHbm, dGlobals, p.convLevelOffsets[l], p.convLevelOffsets[l + 1] - p.convLevelOffsets[l]);
             (void)hipEventRecord(ev[2 * l + 1], stream);
@@ -1434,7 +1452,7 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
     rc = flushPending();
     if (rc != kOk) return rc;
     const uint64_t tp = (uint64_t)reinterpret_cast<uintptr_t>(dTrace);
-    const uint32_t batch = (timeBatch > 1 && batchEligible(p, nOut)) ? (uint32_t)timeBatch : 1u;
+    const uint32_t batch = (timeBatch > 1 && p.convs.empty() && batchEligible(p, nOut)) ? (uint32_t)timeBatch : 1u;
     const uint32_t arenaFloats = batch > 1 ? p.numHbmBuffers * (uint32_t)blockSize : 0u;
     if (batch > 1) {
         rc = ensureHbm((size_t)p.numHbmBuffers * batch); if (rc != kOk) return rc;
@@ -1444,7 +1462,7 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
         const uint32_t lb = p.levelOffsets[l], le = p.levelOffsets[l + 1];
         const uint64_t v = (l == level) ? tp : 0;
         HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(dGlobals) + offsetof(Globals, trace), &v, 8, hipMemcpyHostToDevice, stream));
-        if (le > lb) { if (batch > 1) launchLevelBatch(p, l, batch, arenaFloats); else launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l], batch, arenaFloats); }
+        if (le > lb) { if (batch > 1) launchLevelBatch(p, l, batch, arenaFloats); else launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lb, le - lb, p.levelLdsBytes[l], batch, arenaFloats, statelessRows); }
     }
     const uint64_t zero = 0;
     HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(dGlobals) + offsetof(Globals, trace), &zero, 8, hipMemcpyHostToDevice, stream));
@@ -1462,7 +1480,10 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
 // A multi-block launch carries no per-block root/tap/convolver bookkeeping: it is used only while every
 // running root's fade is settled (Core.h:28-31) and the plan has neither taps nor convolvers.
 bool Engine::batchEligible(const Plan& p, size_t nOut) const {
-    if (!p.taps.empty() || !p.convs.empty() || !p.hosts.empty()) return false;
+    if (!p.taps.empty() || !p.hosts.empty()) return false;
+    // convolvers: the multi-block kernels (conv.hip) assume every node's 512-frame input block is empty at the start of a
+    // launch set, i.e. that every call so far rendered whole 512-frame blocks
+    if (!p.convs.empty() && !(convAligned && blockSize == (int)conv::kBlock)) return false;
     for (int32_t id : p.rootIds) {
         auto it = nodes.find(id);
         if (it == nodes.end()) return false;
@@ -1494,6 +1515,7 @@ void Engine::profCollect() {
 
 // debug / tests: program text and compile state of the k-th specialised shape of the newest plan
 int Engine::specInfo(size_t k, std::string* source, std::string* log, int* state, uint32_t* islands) {
+    std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     const std::shared_ptr<Plan> pl = pending ? pending : current;
     if (!pl || k >= pl->shapes.size()) return -1;
@@ -1532,7 +1554,7 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         }
         if (!any) spec = false;
     }
-    if (!spec) { launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats); return; }
+    if (!spec) { launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats, statelessRows); return; }
     // The launches of one level are independent of each other (different islands): with more than one they go to side
     // streams forked from / joined to the engine's stream, so two shapes of 64 islands each fill 128 CUs at once
     // instead of 64 CUs twice.
@@ -1561,7 +1583,7 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         if (!f.first) {   // this shape's islands go through the interpreter kernel (their list has the levelIslands entry format)
             PlanView pv = p.view;
             pv.levelIslands = p.dSpecLists;
-            launch_level(st_, pv, dRecs, dHbm, dGlobals, dLcg, f.second->listBegin, f.second->count, p.levelLdsBytes[l], batch, arenaFloats);
+            launch_level(st_, pv, dRecs, dHbm, dGlobals, dLcg, f.second->listBegin, f.second->count, p.levelLdsBytes[l], batch, arenaFloats, statelessRows);
             continue;
         }
         PlanView pv = p.view;
@@ -1575,7 +1597,7 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
     if (re > rb) {
         PlanView pv = p.view;
         pv.levelIslands = p.dRestIslands;
-        launch_level(streamFor(k++), pv, dRecs, dHbm, dGlobals, dLcg, rb, re - rb, p.levelLdsBytes[l], batch, arenaFloats);
+        launch_level(streamFor(k++), pv, dRecs, dHbm, dGlobals, dLcg, rb, re - rb, p.levelLdsBytes[l], batch, arenaFloats, statelessRows);
     }
     if (fork) {
         for (size_t i = 1; i < launches; ++i) {
@@ -1585,15 +1607,24 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
     }
 }
 
+// the convolve nodes of level l over a whole launch set: three launches (conv.hip, "multi-block launches")
+void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32_t arenaFloats) {
+    const uint32_t cb = p.convLevelOffsets[l], ce = p.convLevelOffsets[l + 1];
+    uint32_t mains = 0;
+    while (cb + mains < ce && (p.convWork[cb + mains] >> 16) == 0u) ++mains;   // main entries lead a level's work list
+    if (mains) launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks);
+}
+
 void Engine::enqueueBatch(const Plan& p, uint32_t batch) {
     const uint32_t arenaFloats = p.numHbmBuffers * (uint32_t)blockSize;
     const size_t L = p.levelOffsets.size() - 1;
     const bool prof = profileLaunches;
     for (size_t l = 0; l < L; ++l) {
         const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
-        if (e <= b) continue;
+        if (e <= b && p.convLevelOffsets[l + 1] <= p.convLevelOffsets[l]) continue;
         if (prof) (void)hipEventRecord(profEvent(), stream);
         launchLevelBatch(p, l, batch, arenaFloats);
+        launchConvolveBatch(p, l, batch, arenaFloats);
         if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)l); }
     }
     if (prof) (void)hipEventRecord(profEvent(), stream);
@@ -1627,6 +1658,16 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             if (rc != kOk) return rc;
             rc = ensureOutRing(std::max<size_t>(nOut, 1) * bs * (size_t)batchBlocks);
             if (rc != kOk) return rc;
+            if (!p.convs.empty()) {
+                const size_t need = p.convs.size() * convolve_batch_scratch_floats((uint32_t)batchBlocks);
+                if (need > convScratchFloats) {
+                    HIP_OK(hipStreamSynchronize(stream));
+                    if (dConvScratch) (void)hipFree(dConvScratch);
+                    dConvScratch = nullptr; convScratchFloats = 0;
+                    HIP_OK(hipMalloc(&dConvScratch, need * sizeof(float)));
+                    convScratchFloats = need;
+                }
+            }
             setInRing(nullptr, 0);
             hGlobals.blockSlot = 0;
             if (haveIn)   // host inputs of block b -> arena buffers 0..nIn-1 of block b's arena

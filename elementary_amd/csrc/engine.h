@@ -112,7 +112,7 @@ public:
     int appendChild(int32_t parent, int32_t child, int32_t channel);
     int setProperty(int32_t id, const std::string& key, const Value& v);
     int activateRoots(const std::vector<int32_t>& ids, bool malformedTail = false);
-    int commit();
+    int commit(std::unique_lock<std::mutex>& renderLock);
 
     // one block, host buffers (Runtime::process)
     int process(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime);
@@ -157,6 +157,10 @@ private:
     int device;
     hipStream_t stream = nullptr;
     bool ownStream = false;
+    // Two locks. `ctl` serialises the control plane (applyInstructions, gc, resources, options, snapshots ...) and owns
+    // the node table's structure; `mu` guards what the render calls touch (current / pending plan, patch list, record
+    // shadow, device buffers, stream). Order: ctl, then mu. process* take `mu` only; a commit drops `mu` while it plans.
+    std::mutex ctl;
     std::mutex mu;
     Stats st;
 
@@ -204,6 +208,9 @@ private:
     int  graphBlocks = 8;
     int  batchBlocks = 64;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)
     int  pipelineCopies = 6;               // blocks a stateful island keeps in flight inside a multi-block launch
+    bool convAligned = true;               // every process call so far rendered whole 512-frame blocks (conv.hip batch path)
+    float* dConvScratch = nullptr; size_t convScratchFloats = 0;
+    uint32_t statelessRows = 16;           // gridDim.y of a multi-block launch: blocks that stateless islands render side by side
     int  timeBatch = 1;
     int  specialize = 1;                   // 0: interpreter kernels only; 1: specialised kernels compiled in the background and used
                                            // once ready; 2: commit() waits for them (deterministic: tests, benchmarks)
@@ -242,12 +249,14 @@ private:
     void enqueueBlock(const Plan& p);
     int  renderHostNodes(const Plan& p, size_t level);   // call-out nodes of one launch level (synchronises the stream)
     void enqueueBatch(const Plan& p, uint32_t batch);
+    void launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32_t arenaFloats);
     void launchLevelBatch(const Plan& p, size_t level, uint32_t batch, uint32_t arenaFloats);   // specialised kernels when ready, else the interpreter
     bool batchEligible(const Plan& p, size_t nOut) const;
     void mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn);
     int  setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime);
     void setInRing(const float* ring, uint32_t blocks);
-    std::shared_ptr<Plan> buildPlan();
+    std::shared_ptr<Plan> buildPlan(std::unique_lock<std::mutex>& renderLock);
+    int debugBuildDelayMs = 0;
 };
 
 // The specialised-kernel variant of one island's program (plan.cpp builds it, codegen.cpp turns it into text).

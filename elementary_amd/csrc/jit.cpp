@@ -47,12 +47,13 @@ struct Jit::Impl {
     std::deque<std::shared_ptr<SpecEntry>> queue;
     std::vector<std::thread> workers;
     bool stop = false;
-    bool warmed = false;            // the compiler library has been loaded (first, throw-away compile) and the exit hook is in place
+    static Impl* exitHookTarget;
     bool joined = false;
     std::string cacheDir;
     std::string versionTag;
 
     Impl() {
+        exitHookTarget = this;
         const char* env = std::getenv("ELEMHIP_KCACHE");
         cacheDir = env && env[0] ? env : libraryDir() + "/kcache";
         int maj = 0, min = 0;
@@ -60,13 +61,17 @@ struct Jit::Impl {
         versionTag = "hiprtc" + std::to_string(maj) + "." + std::to_string(min) + ";gfx950;-O3;-ffp-contract=off;v1";
         unsigned n = 2;
         if (const char* t = std::getenv("ELEMHIP_JIT_THREADS")) n = (unsigned)std::max(1, std::atoi(t));
-        for (unsigned i = 0; i < n; ++i) workers.emplace_back([this, i] { run(i == 0); });
+        // The compiler library (comgr) is loaded lazily by the first hiprtc compile and registers its static destructors
+        // then. Do that first compile here, on the calling thread (~45 ms, once per process), and register the exit hook
+        // right after it: the hook then runs BEFORE those destructors whenever the process exits, however early.
+        warmUp();
+        for (unsigned i = 0; i < n; ++i) workers.emplace_back([this] { run(); });
     }
     ~Impl() { shutdown(); }
 
     // Stop taking work and wait for the compile in flight. Runs from an atexit hook registered AFTER the compiler library
-    // (comgr, loaded lazily by the first hiprtc compile) has registered its own static destructors, hence before them:
-    // a worker still inside the compiler while its globals are torn down crashes the exiting process.
+    // has registered its own static destructors (see the constructor), hence before them: a worker still inside the
+    // compiler while its globals are torn down crashes the exiting process.
     void shutdown() {
         {
             std::lock_guard<std::mutex> l(mu);
@@ -84,14 +89,10 @@ struct Jit::Impl {
             (void)hiprtcCompileProgram(prog, 1, opts);
             (void)hiprtcDestroyProgram(&prog);
         }
-        std::atexit([] { Jit::get().shutdownAtExit(); });
-        { std::lock_guard<std::mutex> l(mu); warmed = true; }
-        cv.notify_all();
+        std::atexit([] { if (Impl* i = exitHookTarget) i->shutdown(); });
     }
 
-    void run(bool first) {
-        if (first) warmUp();
-        else { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return stop || warmed; }); }
+    void run() {
         for (;;) {
             std::shared_ptr<SpecEntry> e;
             {
@@ -145,6 +146,8 @@ struct Jit::Impl {
         e.state.store(1, std::memory_order_release);
     }
 };
+
+Jit::Impl* Jit::Impl::exitHookTarget = nullptr;
 
 Jit& Jit::get() { static Jit* j = new Jit; return *j; }   // never destroyed: the exit hook (warmUp) stops the workers
 Jit::Jit() : impl(new Impl) {}

@@ -7,7 +7,8 @@ namespace elemhip {
 
 hipError_t configure_kernels(uint32_t maxLdsBytes);
 void launch_level(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, const uint32_t* lcg,
-                  uint32_t levelBegin, uint32_t numIslands, uint32_t ldsBytes, uint32_t batch = 1, uint32_t arenaFloats = 0);
+                  uint32_t levelBegin, uint32_t numIslands, uint32_t ldsBytes, uint32_t batch = 1, uint32_t arenaFloats = 0,
+                  uint32_t statelessRows = 8);
 void launch_epilogue_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, const float* hbm, Globals* g, float* outRing,
                            uint32_t batch, uint32_t arenaFloats);
 void launch_epilogue(hipStream_t s, const PlanView& pv, uint32_t* recs, const float* hbm, Globals* g, float* outRing);
@@ -16,6 +17,9 @@ void launch_level_rt(hipStream_t s, const PlanView& pv, uint32_t* recs, float* h
                      uint32_t levelBegin, uint32_t numIslands, uint32_t ldsBytes);
 void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g,
                      uint32_t workBegin, uint32_t numWorkgroups);
+size_t convolve_batch_scratch_floats(uint32_t maxBatch);   // per convolve node
+void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
+                           uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch);
 hipError_t upload_convolve_tables(const float* twiddleReIm);
 void launch_patches(hipStream_t s, const Patch* patches, uint32_t count, uint32_t* recs, uint32_t* globals);
 

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <functional>
 #include <numeric>
@@ -220,7 +221,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 x.pos = (int)ni.size();
                 x.kind = kindOf(node.op);
                 x.ch = ch;
-                x.rec = e.channelRec(node, ch);
+                if (ch == 0 || !node.mc) x.rec = node.rec;
+                else { std::lock_guard<std::mutex> render(e.mu); x.rec = e.channelRec(node, ch); }   // (build runs without `mu`)
                 idx[K(id, ch)] = (int)ni.size();
                 seqNodes.back().push_back((int)ni.size());
                 ni.push_back(x);
@@ -1173,7 +1175,15 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
 
 static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-std::shared_ptr<Plan> Engine::buildPlan() {
+std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock) {
+    // Planning reads the node table (structure owned by `ctl`, which the caller holds) and writes only the new Plan:
+    // it runs WITHOUT the render lock, so process* calls keep rendering the current plan while a commit is planned.
+    struct Relock {
+        std::unique_lock<std::mutex>& l;
+        explicit Relock(std::unique_lock<std::mutex>& l_) : l(l_) { l.unlock(); }
+        ~Relock() { if (!l.owns_lock()) l.lock(); }
+    } relock(renderLock);
+    if (debugBuildDelayMs > 0) std::this_thread::sleep_for(std::chrono::milliseconds(debugBuildDelayMs));
     std::shared_ptr<Plan> plan;
     const uint32_t ldsLimit = 160u * 1024u - 1024u;
     for (uint32_t limit = 56; limit >= 4; limit /= 2) {
@@ -1187,13 +1197,6 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     if (!plan) { std::fprintf(stderr, "[elemhip] plan: could not fit islands into LDS\n"); return nullptr; }
     Plan& p = *plan;
 
-    // root records learn whether fade.process() runs on them (Core.h:74-77)
-    for (int32_t id : p.rootIds) {
-        Node& r = nodes.at(id);
-        const uint32_t has = r.inlets.empty() ? 0u : 1u;
-        if (shadow[r.rec * kRecDwords + rec::ROOT_HASIN] != has) writeParam(r, rec::ROOT_HASIN, has);
-    }
-
     // pack + upload the tables
     size_t off = 0;
     auto place = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
@@ -1205,6 +1208,7 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     const size_t oConvs = place(p.convs.size() * sizeof(ConvDesc));
     const size_t oConvWork = place(p.convWork.size() * 4);
     // ---- specialised kernels: group each level's islands by generated text, queue the shapes for compilation ----
+    double jitWaitMs = -1.0;
     {
         const size_t L = p.levelOffsets.size() - 1;
         p.restOffsets.assign(L + 1, 0);
@@ -1230,11 +1234,10 @@ std::shared_ptr<Plan> Engine::buildPlan() {
             p.restOffsets[l + 1] = (uint32_t)p.restIslands.size();
         }
         p.specText.clear(); p.specText.shrink_to_fit();
-        st.specShapes = (uint32_t)p.shapes.size(); st.specIslands = (uint32_t)p.specLists.size();
         if (specialize >= 2) {
             const auto t0 = std::chrono::steady_clock::now();
             for (auto& sh : p.shapes) (void)Jit::get().wait(sh.entry);
-            st.lastJitWaitMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            jitWaitMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     }
     const size_t oSpecLists = place(p.specLists.size() * 4);
@@ -1250,6 +1253,16 @@ std::shared_ptr<Plan> Engine::buildPlan() {
     put(oConvWork, p.convWork.data(), p.convWork.size() * 4);
     put(oSpecLists, p.specLists.data(), p.specLists.size() * 4);
     put(oRest, p.restIslands.data(), p.restIslands.size() * 4);
+
+    renderLock.lock();   // ---- from here on: render-side state ----
+    st.specShapes = (uint32_t)p.shapes.size(); st.specIslands = (uint32_t)p.specLists.size();
+    if (jitWaitMs >= 0.0) st.lastJitWaitMs = jitWaitMs;
+    // root records learn whether fade.process() runs on them (Core.h:74-77)
+    for (int32_t id : p.rootIds) {
+        Node& r = nodes.at(id);
+        const uint32_t has = r.inlets.empty() ? 0u : 1u;
+        if (shadow[r.rec * kRecDwords + rec::ROOT_HASIN] != has) writeParam(r, rec::ROOT_HASIN, has);
+    }
     if (dry) return plan;
     if (hipMalloc(&p.dev.ptr, host.size()) != hipSuccess) return nullptr;
     p.dev.bytes = host.size();

@@ -127,3 +127,59 @@ def test_c2_soak_600_blocks(gpu_required, specialize):
     ref = np.stack([c.process(None, 2, 512) for _ in range(600)])
     err = float(np.abs(got - ref).max())
     assert err <= TOL, f"{err:.3e}"
+
+
+def test_rendering_continues_while_a_commit_is_planned(gpu_required):
+    """The render thread keeps producing blocks of the CURRENT sequence while another thread's applyInstructions builds the
+    next plan (the reference's SPSC hand-over, Runtime.h:207-216 / 277-285). With the build stretched to 0.6 s the stream
+    must be what the reference's audio thread would see: the instructions in front of COMMIT_UPDATES take effect at once
+    (the replaced root starts its fade-out on the old sequence, Runtime.h:368-433), the new sequence arrives later and
+    its root fades in from there. The reference engine is driven through the same timeline single-threaded: the batch
+    without its commit first, `[ACTIVATE_ROOTS (same ids), COMMIT_UPDATES]` at the block where the HIP stream switches
+    (two reference engines in lock-step find that block). No process call made meanwhile waits for the build."""
+    import threading, time
+    from elementary_amd.runtime import Runtime
+    sr = 48000.0
+    old = [el.mul(0.5, el.cycle(220.0)), el.mul(0.25, el.cycle(331.0))]
+    new = [el.mul(0.5, el.cycle(220.0)), el.mul(0.3, graphs.c2_voice(3))]
+    a, c1, c2 = _hip(sr, 512), _checker(sr, 512), _checker(sr, 512)
+    scribe = Runtime(sr, 512, device=-1)          # same reconciler history: yields the batch `a.render(*new)` will send
+    for rt in (a, c1, c2, scribe):
+        assert rt.render(*old)["result"] == 0
+    batch = scribe.render(*new)["batch"]
+    assert batch[-1] == [5] and batch[-2][0] == 4
+    early, late = batch[:-1], [batch[-2], [5]]
+    for _ in range(4):
+        got, ref = a.process(None, 2, 512), c1.process(None, 2, 512)
+        c2.process(None, 2, 512)
+        assert float(np.abs(got - ref).max()) <= TOL
+    a.set_option("debug_build_delay_ms", 600)
+    done = {}
+
+    def commit():
+        done["rc"] = a.render(*new)["result"]
+
+    th = threading.Thread(target=commit)
+    th.start()
+    time.sleep(0.15)                              # the commit is inside its (unlocked) build: its early instructions are in
+    assert c1.apply_instructions(early) == 0 and c2.apply_instructions(early) == 0
+    worst, during, switched = 0.0, 0, False
+    while during < 100000:                        # (~80 us per block: the 0.6 s build spans several thousand blocks)
+        t0 = time.perf_counter()
+        got = a.process(None, 2, 512)
+        dt = time.perf_counter() - t0
+        if float(np.abs(got - c1.process(None, 2, 512)).max()) <= TOL:      # still the old sequence
+            c2.process(None, 2, 512)
+            worst = max(worst, dt)
+            during += 1
+            continue
+        assert c2.apply_instructions(late) == 0                             # the new sequence arrived in front of this block
+        assert float(np.abs(got - c2.process(None, 2, 512)).max()) <= TOL
+        switched = True
+        break
+    th.join()
+    assert done["rc"] == 0 and switched
+    assert during >= 20 and worst < 0.1, (during, worst)
+    for k in range(12):      # the new root's fade-in, then the settled new graph
+        got, ref = a.process(None, 2, 512), c2.process(None, 2, 512)
+        assert float(np.abs(got - ref).max()) <= TOL, k

@@ -191,3 +191,36 @@ def test_multi_output_node_gets_one_plan_entry_per_channel():
     plan = rt.describe_plan()
     assert plan["num_nodes"] == 4                                              # const, mc.table, add, root
     assert plan["num_tasks"] >= 5                                              # 3 table lookups + add + root
+
+
+def test_process_does_not_wait_for_a_plan_build():
+    """Runtime.h:207-216, 277-285: the reference hands a finished render sequence to the audio thread through an SPSC
+    queue, so `process` never waits for `buildRenderSequence`. Here a commit drops the render lock while it plans: with
+    the unlocked part of the build stretched to 0.5 s, `process` calls from another thread return at once (a dry handle
+    answers 101 after taking the render lock), and the commit still lands."""
+    import threading, time
+    rt = dry(48000.0)
+    assert rt.render(el.cycle(440.0))["result"] == 0
+    rt.set_option("debug_build_delay_ms", 500)
+    done = {}
+
+    def commit():
+        t0 = time.perf_counter()
+        done["rc"] = rt.render(el.mul(0.5, el.cycle(220.0)), el.cycle(330.0))["result"]
+        done["s"] = time.perf_counter() - t0
+
+    th = threading.Thread(target=commit)
+    th.start()
+    time.sleep(0.1)     # the commit is inside its build now
+    worst, calls = 0.0, 0
+    while th.is_alive() and calls < 200:
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="101"):
+            rt.process(None, 1, 512)
+        worst = max(worst, time.perf_counter() - t0)
+        calls += 1
+        time.sleep(0.002)
+    th.join()
+    assert done["rc"] == 0 and done["s"] >= 0.5
+    assert calls >= 20 and worst < 0.1, (calls, worst)
+    assert rt.describe_plan()["num_roots"] == 2
