@@ -101,8 +101,92 @@ def cpu_baseline_multicore(single_ms_per_block: float, target_seconds: float = 8
             "ms_per_block": 1e3 * dt / blocks}
 
 
+def main_c4(args) -> None:
+    """BASELINE configs[3] (C4): `--instances` independent offline render jobs per GPU (1024 over 8 GPUs = 128 per GPU).
+    SURVEY.md 8(e): the unit of sharding is the whole render job, so ranks share nothing — no data-path collective, each
+    job's output stays in its rank's HBM; weak scaling by construction. Same timing protocol as the headline workload."""
+    import torch
+    import torch.distributed as dist
+
+    from elementary_amd import graphs
+    from elementary_amd.runtime import Runtime
+
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    inst, B = args.instances, max(1, min(64, args.batch_blocks))
+    rt = Runtime(graphs.C4_SAMPLE_RATE, BLOCK, device=local)
+    rt.set_option("batch_blocks", B)
+    rt.set_option("specialize", args.specialize)
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        rt.set_option(k, float(v))
+    t0 = time.perf_counter()
+    assert rt.render(*[graphs.c4_instance(inst * rank + k) for k in range(inst)])["result"] == 0
+    build_ms = 1e3 * (time.perf_counter() - t0)
+    spc = max(1, args.steps_per_call)
+    out = torch.zeros((spc * B, inst, BLOCK), dtype=torch.float32, device="cuda")
+
+    def run(steps: int) -> None:
+        done = 0
+        while done < steps:
+            c = min(spc, steps - done)
+            rt.process_blocks(c * B, inst, out_ptr=out.data_ptr())
+            done += c
+
+    run(args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    rt.set_option("profile_launches", 1)
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = rt.launch_profile()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        blocks = args.steps * B
+        alg = graphs.c4_algorithmic_bytes(inst)                  # per block-step of one rank
+        us = 1e6 * dt / blocks
+        sets = max(1, prof["launch_sets"])
+        stats = rt.stats()
+        print(json.dumps({
+            "metric": "instance-samples/sec, independent offline render instances (BASELINE configs[3])",
+            "value": world * inst * BLOCK * blocks / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3] (C4): {inst} independent render instances per GPU ({inst * world} in all), "
+                                   "each cycle -> biquad -> tanh, sr 48000, blockSize 512; one step = one launch set of "
+                                   f"{B} blocks of every instance", "instances_per_gpu": inst, "instances_total": inst * world,
+                       "blocks_per_step": B, "islands": stats["num_islands"], "launch_levels": stats["num_levels"],
+                       "collectives": "none (jobs are independent; outputs stay on their rank)"},
+            "us_per_block_step": us, "plan_build_ms": build_ms,
+            "roofline": {"bound": "hbm", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_block_step": alg,
+                         "launch_us_per_step": [1e3 * x / sets for x in prof["level_ms"]],
+                         "note": "bound by the biquad recurrence of one instance per workgroup (a lone wave), not by bytes"},
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
+                    help="c2 = the headline 256-voice synth (BASELINE configs[1]); c4 = independent render instances (configs[3])")
+    ap.add_argument("--instances", type=int, default=128, help="--workload c4: render instances per GPU")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64, help="timed steps; one step = one launch set of --batch-blocks blocks")
     ap.add_argument("--warmup", type=int, default=8, help="untimed steps")
@@ -118,6 +202,8 @@ def main() -> None:
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every rank renders --voices voices; strong = the --voices-voice graph is split over the ranks")
     args = ap.parse_args()
+    if args.workload == "c4":
+        return main_c4(args)
 
     import torch
     import torch.distributed as dist

@@ -68,7 +68,7 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
                 if (j == 5 && nops <= 5 && (sp.phaseOp[mi] & kOpKindMask) == kOpHbm) e = opndExpr(sp, sp.phaseOp[mi], tabWord);   // streamed oscillator phase
                 o << "            m.sops[" << j << "] = " << e << ";\n";
             }
-            o << "            m.gdirect = " << (sp.gdirect[q] ? "1u" : "0u") << ";\n";
+            o << "            m.gdirect = " << (sp.gdirect[q] ? "1u" : "0u") << "; m.cnt = " << t.count << "u;\n";
             o << "        }\n";
         }
         o << "        m.pad0_ = m.sops[0]; m.pad1_ = m.sops[1]; m.off = off;\n        return m;\n    }\n";

@@ -85,6 +85,7 @@ struct Member {
     uint32_t sops[6];
     uint32_t off;
     uint32_t gdirect;    // recurrence member: the block goes straight to HBM arena buffer `outHbm` (no LDS copy of it exists)
+    uint32_t cnt;        // members of the task (lanes >= cnt mirror the last member's arithmetic but skip its memory traffic)
 #endif
 };
 

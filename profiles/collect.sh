@@ -12,6 +12,8 @@ mkdir -p $OUT
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $CMD > $OUT/prof_stats.log 2>&1)
 (cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- $CMD > $OUT/prof_fetch.log 2>&1)
 (cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- $CMD > $OUT/prof_write.log 2>&1)
+# BASELINE configs[2] (C3) through the multi-block convolve kernels: per-kernel durations only
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c3 -- python $REPO/benchmarks/bench_configs.py c3 > $OUT/prof_c3.log 2>&1)
 tail -1 $OUT/prof_stats.log | cut -c1-300
 find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -name "*.csv" | head -20
 python profiles/summarize.py $OUT ${ROUND_TAG:-r02}

@@ -61,6 +61,16 @@ for ctr, d in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
         pmc[f"{k[0]}|grid={k[1][0]}x{k[1][1]}|{ctr}_KB_mean"] = sum(v) / len(v)
         pmc[f"{k[0]}|grid={k[1][0]}x{k[1][1]}|{ctr}_dispatches"] = len(v)
 
+# 3. C3 kernel stats (multi-block convolve kernels)
+c3 = first("prof_c3/**/*kernel_stats.csv")
+if c3:
+    rows = list(csv.DictReader(open(c3)))
+    with open(os.path.join(dst, "c3_n1_kernel_stats.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(rows)
+    print("c3 kernel stats:", [(r.get("Name", "")[:40], r.get("Calls"), r.get("AverageNs")) for r in rows[:8]])
+
 out = {"command": "rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE} --output-format csv -- "
                   "python bench.py --no-cpu-baseline --steps 20 --warmup 5 (the driver-shaped run: 25 launch sets of 64 blocks)",
        "kernel_trace_per_dispatch": trace_summary, "pmc_per_dispatch": pmc}
