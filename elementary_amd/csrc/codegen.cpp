@@ -91,15 +91,18 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
             const uint32_t prev = stageTab[S + st];
             uint32_t ntasks = 0;
             bool writes = false;     // the slot stores into arena buffers (read by other waves of the same launch, or by later launches)
+            bool allDirect = true;   // ... and every task of it is a streamed recurrence (its block goes straight to the arena)
             o << "template <> struct Slot<" << w << ", " << j << "> {\n";
             std::ostringstream body;
             for (uint32_t q = I.waveTask[w]; q < I.waveTask[w + 1]; ++q)
                 if (tasks[q].stage == st) {
                     body << "        spec_task<T" << q << ">(c, off);\n"; ++ntasks;
+                    if (!sp.gdirect[q]) allDirect = false;
                     for (uint32_t k = 0; k < tasks[q].count; ++k) if (members[tasks[q].first + k].outHbm != kNone) writes = true;
                 }
             o << "    static constexpr uint32_t stage = " << st << "u, prev = " << u(prev) << ", prevT = " << (prev == kNone ? 0u : stageTab[prev])
-              << "u, ntasks = " << ntasks << "u;\n    static constexpr bool writesStreams = " << (writes ? "true" : "false") << ";\n";
+              << "u, ntasks = " << ntasks << "u;\n    static constexpr bool writesStreams = " << (writes ? "true" : "false")
+              << ", deferPublish = " << (writes && allDirect ? "true" : "false") << ";\n";
             o << "    static __device__ __forceinline__ void run(const Ctx& c, uint32_t off) {\n" << body.str() << "    }\n};\n";
         }
     }

@@ -210,7 +210,8 @@ private:
     int  pipelineCopies = 6;               // blocks a stateful island keeps in flight inside a multi-block launch
     bool convAligned = true;               // every process call so far rendered whole 512-frame blocks (conv.hip batch path)
     float* dConvScratch = nullptr; size_t convScratchFloats = 0;
-    uint32_t statelessRows = 16;           // gridDim.y of a multi-block launch: blocks that stateless islands render side by side
+    uint32_t mixerSplit = 2;               // workgroups a mixer island is cut into (plan.cpp; each renders blockSize / split frames on 8 / split waves)
+    uint32_t statelessRows = 64;           // gridDim.y of a multi-block launch: blocks that stateless islands render side by side
     int  timeBatch = 1;
     int  specialize = 1;                   // 0: interpreter kernels only; 1: specialised kernels compiled in the background and used
                                            // once ready; 2: commit() waits for them (deterministic: tests, benchmarks)

@@ -653,6 +653,19 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             return m;
         };
 
+        // A pure sample-parallel island that streams many arena buffers (a mixer: no imports, its children are read
+        // straight from HBM by the reduce) is bound by memory round trips, not by issue: its stages are cut into 64-frame
+        // runs over ALL eight waves, so one workgroup keeps 8 x 64 child loads in flight.
+        bool mixerLike = false;
+        if (statelessIsland && imports.empty() && bs >= 128) {
+            size_t direct = 0;
+            for (int k : B.nodes)
+                for (auto& in : ni[k].n->inlets) {
+                    auto it = idx.find(K(in.source, in.channel));
+                    if (it != idx.end() && ni[it->second].kind != K_CONST && ni[it->second].island != ni[k].island) direct++;
+                }
+            mixerLike = direct >= 8;
+        }
         // ---- tasks, stage by stage ----
         // A sample-parallel task covers 64*V frames with V in {1,2,4,8} (lane l owns V consecutive
         // frames). The block is cut into 64-frame units handed out as power-of-two runs.
@@ -781,7 +794,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             // there is always other work for the other waves) a stage's ops therefore run unsplit on ONE wave
             // unless their cost says otherwise (below).
             std::vector<int> parWaves = freeWaves;
-            if (parWaves.size() > 4) parWaves.resize(4);   // a finer split only multiplies per-task overhead
+            if (parWaves.size() > 4 && !mixerLike) parWaves.resize(4);   // a finer split only multiplies per-task overhead
             if (copies > 1) {
                 // split a stage's sample-parallel work so that one part is about as long as a serial recurrence
                 // (~12 k cycles): light stages run unsplit, a filter-coefficient pre-pass on two waves. A finer split
@@ -885,15 +898,11 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 if (ok) t.flags |= (uint8_t)kTaskOwnsWave;
             }
         }
-        // a pure sample-parallel island that streams many HBM buffers (a mixer) runs as several
-        // workgroups, each rendering a slice of the block
-        {
-            bool pure = true;
-            size_t hbmReads = 0;
-            for (int k : B.nodes) if (ni[k].kind != K_PAR) pure = false;
-            for (uint32_t o : operands) if ((o & kOpKindMask) == kOpHbm) hbmReads++;
-            I.split = (pure && imports.empty() && hbmReads >= 8 && bs >= 128) ? std::min<uint32_t>(8, bs / 64) : 1;
-        }
+        // (A mixer used to run as 8 workgroups, each rendering a 64-frame slice with ONE active wave; the slices are now the
+        // eight waves of one workgroup — same latency for a single block, and a multi-block launch gives every block its own
+        // workgroup. Level 1 of C2: 48 -> 22 us per launch set. `mixer_split` = 2 keeps two workgroups of four active waves: the
+        // single-block launch stays at 13 us where one workgroup of eight needs 21.)
+        I.split = mixerLike ? std::max(1u, std::min(e.mixerSplit, bs / 64u)) : 1u;
         // stage tables: tasks per stage, previous non-empty stage, per-wave first task of each stage
         const uint32_t S = (uint32_t)maxStage + 1;
         std::vector<uint32_t> stageTab(2 * S + kWaves * (S + 1) + copies + 1, 0u);
@@ -1210,6 +1219,7 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     const size_t oConvWork = place(p.convWork.size() * 4);
     // ---- specialised kernels: group each level's islands by generated text, queue the shapes for compilation ----
     double jitWaitMs = -1.0;
+    if (!p.taps.empty() || !p.hosts.empty()) p.specText.clear();   // such plans never render through launch sets (Engine::batchEligible)
     {
         const size_t L = p.levelOffsets.size() - 1;
         p.restOffsets.assign(L + 1, 0);

@@ -45,7 +45,7 @@ def _render_blocks(rt, nb, n_out, x=None, block=512):
 
 def _assert_ran_specialised(rt):
     st = rt.stats()
-    if st["spec_shapes"] > 0:
+    if st["spec_shapes"] > 0 and st["batch_launches"] > 0:
         info = rt.spec_info(0)
         assert info["state"] == 1, info["log"][:2000]
         assert st["spec_launches"] > 0, st

@@ -82,15 +82,15 @@ def test_return_codes_match_reference():
 
 
 def test_plan_shape_for_the_benchmark_graph():
-    """C2: one island per voice (all 13 ops fused behind LDS), the two 128-input mixers as split
-    islands on the second launch level."""
+    """C2: one island per voice (all 13 ops fused behind LDS), the two 128-input mixers as islands on the second launch
+    level, each cut into eight 64-frame runs over the waves of its two workgroups."""
     rt = dry(graphs.C2_SAMPLE_RATE)
     res = rt.render(*graphs.c2_graph())
     assert res["result"] == 0 and res["nodesAdded"] == 4107
     p = rt.describe_plan()
     assert p["num_nodes"] == 4107 and p["num_roots"] == 2 and p["num_levels"] == 2
     assert p["level_sizes"][0] == 256               # 256 voice workgroups
-    assert p["level_sizes"][1] == 16                # 2 mixers x 8 slices
+    assert p["level_sizes"][1] == 4                 # 2 mixers x 2 workgroups (4 active waves each)
     assert p["max_lds_bytes"] < 150 * 1024          # 6 pipelined buffer sets per voice island
     assert p["islands"][0]["copies"] == 6 and p["islands"][0]["stateless"] == 0
     assert p["num_hbm_buffers"] == 32 + 256 + 2     # host inputs + voice exports + roots

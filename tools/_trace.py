@@ -29,8 +29,10 @@ if which in ("pipe32", "c2pipe", "c4pipe", "c1pipe"):
     assert rt.render(*roots)["result"] == 0
     rt.process_blocks(8, nout); rt.set_option("time_batch", 32)
     buf = (C.c_ulonglong * (8*192))()
+    level = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # launch level to trace (its first workgroup)
+    rt.set_option("specialize", 0)
     for _ in range(3):
-        rc = lib.elemhip_trace_level(rt._h, nout, 0, buf, 8*192); assert rc == 0, rc
+        rc = lib.elemhip_trace_level(rt._h, nout, level, buf, 8*192); assert rc == 0, rc
     base = min(buf[w*192+1] for w in range(8) if buf[w*192+1])
     for w in range(8):
         o = w*192; nt = buf[o]
