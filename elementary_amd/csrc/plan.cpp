@@ -846,9 +846,30 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 remap[{sl.stage, sl.wave}] = best;
             }
             for (size_t q = 0; q < tasks.size(); ++q) taskWave[q] = remap.at({(int)tasks[q].stage, taskWave[q]});
-            // (Program waves w and w + 4 share a SIMD. Which slots end up paired moves the C2 block rate by +-2.5 % — six pairings
-            // measured, recurrence next to recurrence, next to sample-parallel work, next to the scan — with no rule that
-            // holds across them, so the LPT numbering stays as it falls.)
+            // Program waves w and w + 4 share a SIMD, and a wave loses issue slots to its mate for about half the mate's busy
+            // time (specialised C2 voice, tools/spec_trace.py: a recurrence wave alone on its SIMD 7.3-8.8 k cycles per block,
+            // 9.4-10.8 k next to a sample-parallel wave of 3.7-5.2 k). Recurrence waves bound the block rate, so each gets a
+            // SIMD of its own as far as SIMDs go, the heaviest of them next to the lightest sample-parallel wave.
+            {
+                bool serial[kWaves] = {};
+                for (size_t q = 0; q < tasks.size(); ++q) if (kindOf(tasks[q].opcode) == K_CHAIN) serial[taskWave[q]] = true;
+                std::vector<int> ser, par;
+                for (int w = 0; w < (int)kWaves; ++w) (serial[w] ? ser : par).push_back(w);
+                std::stable_sort(ser.begin(), ser.end(), [&](int a, int b) { return load[a] > load[b]; });
+                std::stable_sort(par.begin(), par.end(), [&](int a, int b) { return load[a] < load[b]; });
+                if (ser.size() <= 4 && !ser.empty()) {
+                    int renum[kWaves];
+                    std::vector<int> rest;                       // waves still to place, mates first
+                    size_t pi = 0;
+                    for (size_t k = 0; k < ser.size(); ++k) { renum[ser[k]] = (int)k; if (pi < par.size()) renum[par[pi++]] = (int)k + 4; }
+                    int freeIdx[kWaves]; int nf = 0;
+                    bool taken[kWaves] = {};
+                    for (size_t k = 0; k < ser.size(); ++k) { taken[k] = true; if (k < par.size()) taken[k + 4] = true; }
+                    for (int w = 0; w < (int)kWaves; ++w) if (!taken[w]) freeIdx[nf++] = w;
+                    for (int f = 0; pi < par.size() && f < nf; ++f) renum[par[pi++]] = freeIdx[f];
+                    for (size_t q = 0; q < tasks.size(); ++q) taskWave[q] = renum[taskWave[q]];
+                }
+            }
         }
         {   // per-wave task lists: sort by (wave, stage), keep emission order inside a (wave, stage)
             std::vector<size_t> order(tasks.size());

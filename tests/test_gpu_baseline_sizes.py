@@ -163,6 +163,8 @@ def test_rendering_continues_while_a_commit_is_planned(gpu_required):
     th.start()
     time.sleep(0.15)                              # the commit is inside its (unlocked) build: its early instructions are in
     assert c1.apply_instructions(early) == 0 and c2.apply_instructions(early) == 0
+    import gc
+    gc.collect(); gc.disable()      # (a full collection of the test session's heap takes longer than the latency bound below)
     worst, during, switched = 0.0, 0, False
     while during < 100000:                        # (~80 us per block: the 0.6 s build spans several thousand blocks)
         t0 = time.perf_counter()
@@ -178,6 +180,7 @@ def test_rendering_continues_while_a_commit_is_planned(gpu_required):
         switched = True
         break
     th.join()
+    gc.enable()
     assert done["rc"] == 0 and switched
     assert during >= 20 and worst < 0.1, (during, worst)
     for k in range(12):      # the new root's fade-in, then the settled new graph

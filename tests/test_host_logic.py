@@ -212,15 +212,22 @@ def test_process_does_not_wait_for_a_plan_build():
     th = threading.Thread(target=commit)
     th.start()
     time.sleep(0.1)     # the commit is inside its build now
+    import gc
+    gc.collect(); gc.disable()      # (a generation-2 collection of the test session's heap takes longer than the bound below)
     worst, calls = 0.0, 0
     while th.is_alive() and calls < 200:
         t0 = time.perf_counter()
-        with pytest.raises(RuntimeError, match="101"):
+        try:
             rt.process(None, 1, 512)
+            code = None
+        except RuntimeError as e:      # (not pytest.raises: its traceback capture costs more than the call being timed)
+            code = str(e)
         worst = max(worst, time.perf_counter() - t0)
+        assert code is not None and "101" in code
         calls += 1
         time.sleep(0.002)
     th.join()
+    gc.enable()
     assert done["rc"] == 0 and done["s"] >= 0.5
     assert calls >= 20 and worst < 0.1, (calls, worst)
     assert rt.describe_plan()["num_roots"] == 2
