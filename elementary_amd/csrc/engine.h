@@ -68,6 +68,7 @@ struct Outlet { int32_t dest; uint32_t channel; };
 
 struct Node {
     int32_t id = 0;
+    uint32_t planVisited = 0, planOnStack = 0;   // plan-build scratch (PlanBuilder::traverse): epoch marks instead of hash sets
     uint16_t op = OP_INVALID;
     uint32_t rec = kNone;
     std::vector<Inlet> inlets;
@@ -171,6 +172,8 @@ private:
     std::vector<float> hostIn, hostOut;    // staging for call-out nodes
     // generated text per island-program signature: 256 voices (and every re-plan of a live graph) format their text once
     std::unordered_map<uint64_t, std::shared_ptr<const std::string>> specTextCache;
+    std::unordered_map<const std::string*, std::string> specKeyCache;
+    uint32_t planEpoch = 0;                // PlanBuilder::traverse marks   // text object (owned by specTextCache) -> kernel cache key
     int64_t curBlockTime = 0;              // sample time of the block being enqueued (call-out nodes get it as userData)
     bool shouldRebuild = false;
     bool rebuildOwed = false;              // a commit failed to build its plan: the next commit retries even without ACTIVATE_ROOTS

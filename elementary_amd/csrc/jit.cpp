@@ -182,8 +182,9 @@ static std::string keyOf(const std::string& versionTag, const std::string& src) 
     return key;
 }
 
-bool Jit::known(const std::string& generated, uint32_t ldsWords) {
-    const std::string key = keyOf(impl->versionTag, fullSource(generated, ldsWords));
+std::string Jit::keyFor(const std::string& generated, uint32_t ldsWords) { return keyOf(impl->versionTag, fullSource(generated, ldsWords)); }
+
+bool Jit::knownKey(const std::string& key) {
     {
         std::lock_guard<std::mutex> l(impl->mu);
         if (impl->entries.count(key)) return true;
@@ -191,10 +192,15 @@ bool Jit::known(const std::string& generated, uint32_t ldsWords) {
     struct stat st;
     return ::stat((impl->cacheDir + "/" + key + ".hsaco").c_str(), &st) == 0;
 }
+bool Jit::known(const std::string& generated, uint32_t ldsWords) { return knownKey(keyFor(generated, ldsWords)); }
 
-std::shared_ptr<SpecEntry> Jit::request(const std::string& generated, uint32_t ldsWords) {
+std::shared_ptr<SpecEntry> Jit::requestKey(const std::string& key, const std::string& generated, uint32_t ldsWords) {
+    {
+        std::lock_guard<std::mutex> l(impl->mu);
+        auto it = impl->entries.find(key);
+        if (it != impl->entries.end()) return it->second;
+    }
     std::string src = fullSource(generated, ldsWords);
-    const std::string key = keyOf(impl->versionTag, src);
     std::lock_guard<std::mutex> l(impl->mu);
     auto it = impl->entries.find(key);
     if (it != impl->entries.end()) return it->second;
@@ -205,6 +211,7 @@ std::shared_ptr<SpecEntry> Jit::request(const std::string& generated, uint32_t l
     impl->cv.notify_one();
     return e;
 }
+std::shared_ptr<SpecEntry> Jit::request(const std::string& generated, uint32_t ldsWords) { return requestKey(keyFor(generated, ldsWords), generated, ldsWords); }
 
 int Jit::wait(const std::shared_ptr<SpecEntry>& e) {
     std::unique_lock<std::mutex> l(impl->mu);

@@ -32,6 +32,11 @@ public:
     std::shared_ptr<SpecEntry> request(const std::string& generated, uint32_t ldsWords);
     int wait(const std::shared_ptr<SpecEntry>& e);   // blocks until compiled: 1 ready, -1 failed
     bool known(const std::string& generated, uint32_t ldsWords);   // already requested in this process, or on disk
+    // the cache key of a shape (hashing the ~170 KB program text costs 0.3 ms: callers that see the same text object again
+    // keep the key) and the two calls above by key; `request` builds the program text only for a key it has not seen
+    std::string keyFor(const std::string& generated, uint32_t ldsWords);
+    bool knownKey(const std::string& key);
+    std::shared_ptr<SpecEntry> requestKey(const std::string& key, const std::string& generated, uint32_t ldsWords);
     static std::string fullSource(const std::string& generated, uint32_t ldsWords);
     void shutdownAtExit();
 private:

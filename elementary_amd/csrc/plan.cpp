@@ -155,26 +155,26 @@ struct PlanBuilder {
     std::vector<std::vector<int>> seqNodes; // per root sequence
     std::vector<Node*> seqRoots;
 
-    void traverse(std::unordered_set<int32_t>& visited, std::vector<int32_t>& order, int32_t id) {
-        // iterative DFS post-order, children in inlet order (Runtime.h:502-518)
-        struct Frame { int32_t id; size_t next; };
-        if (visited.count(id)) return;
+    void traverse(uint32_t epoch, std::vector<Node*>& order, Node* root) {
+        // iterative DFS post-order, children in inlet order (Runtime.h:502-518); visited / on-stack are epoch marks in the nodes
+        struct Frame { Node* n; size_t next; };
+        if (root->planVisited == epoch) return;
         std::vector<Frame> st;
-        std::unordered_set<int32_t> onStack;
-        st.push_back({id, 0});
-        onStack.insert(id);
+        st.push_back({root, 0});
+        root->planOnStack = epoch;
         while (!st.empty()) {
             Frame& f = st.back();
-            Node& n = e.nodes.at(f.id);
+            Node& n = *f.n;
             if (f.next < n.inlets.size()) {
                 const int32_t c = n.inlets[f.next++].source;
-                if (visited.count(c) || onStack.count(c) || !e.nodes.count(c)) continue;
-                st.push_back({c, 0});
-                onStack.insert(c);
+                auto it = e.nodes.find(c);
+                if (it == e.nodes.end() || it->second.planVisited == epoch || it->second.planOnStack == epoch) continue;
+                it->second.planOnStack = epoch;
+                st.push_back({&it->second, 0});
             } else {
-                order.push_back(f.id);
-                visited.insert(f.id);
-                onStack.erase(f.id);
+                order.push_back(f.n);
+                n.planVisited = epoch;
+                n.planOnStack = 0;
                 st.pop_back();
             }
         }
@@ -190,6 +190,14 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     Plan& p = *plan;
     const uint32_t bs = (uint32_t)e.blockSize;
 
+    static const bool planTiming = std::getenv("ELEMHIP_PLAN_TIMING") != nullptr;   // phase times of a build on stderr
+    auto tPhase = std::chrono::steady_clock::now();
+    auto phase = [&](const char* name) {
+        if (!planTiming) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[elemhip] plan %-18s %7.3f ms\n", name, std::chrono::duration<double, std::milli>(now - tPhase).count());
+        tPhase = now;
+    };
     // ---- 1. render order ---------------------------------------------------------------------
     std::vector<Node*> sortedRoots;   // std::list push_front/push_back in Runtime.h:544-559
     {
@@ -205,14 +213,16 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         sortedRoots = front;
         sortedRoots.insert(sortedRoots.end(), back.begin(), back.end());
     }
-    std::unordered_set<int32_t> visited;
+    if (++e.planEpoch == 0u) { for (auto& kv : e.nodes) kv.second.planVisited = kv.second.planOnStack = 0u; e.planEpoch = 1u; }
+    const uint32_t epoch = e.planEpoch;
     for (size_t s = 0; s < sortedRoots.size(); ++s) {
-        std::vector<int32_t> order;
-        traverse(visited, order, sortedRoots[s]->id);
+        std::vector<Node*> order;
+        traverse(epoch, order, sortedRoots[s]);
         seqRoots.push_back(sortedRoots[s]);
         seqNodes.emplace_back();
-        for (int32_t id : order) {
-            Node& node = e.nodes.at(id);
+        for (Node* np : order) {
+            Node& node = *np;
+            const int32_t id = node.id;
             uint32_t numOuts = 1;                       // getRequiredOutputChannels (GraphRenderSequence.h:15-24)
             if (node.mc) for (auto& o : node.outlets) numOuts = std::max(numOuts, std::min<uint32_t>(o.channel + 1u, 16u));
             for (uint32_t ch = 0; ch < numOuts; ++ch) {
@@ -263,6 +273,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         c.fusedRoot = idx.at(K(r->id));
     }
 
+    phase("render order");
     // ---- 2. islands ---------------------------------------------------------------------------------
     UF uf;
     std::vector<uint32_t> weight;            // per island representative
@@ -418,6 +429,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         p.numHbmBuffers = next;
     }
 
+    phase("islands");
     // ---- 3/4. per-island schedule, LDS allocation, task emission -------------------------------------
     p.islands.resize(ib.size());
     std::vector<int> convLevel;              // launch level of p.convs[i]
@@ -1162,7 +1174,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             mix(bs); mix((uint32_t)sp.hbmTab.size());
             auto it = e.specTextCache.find(h);
             if (it == e.specTextCache.end()) {
-                if (e.specTextCache.size() > 4096) e.specTextCache.clear();
+                if (e.specTextCache.size() > 4096) { e.specTextCache.clear(); e.specKeyCache.clear(); }
                 it = e.specTextCache.emplace(h, std::make_shared<const std::string>(emitSpecSource(I, tasks, sp, stageTab, bs))).first;
             }
             p.specText[ii] = it->second;
@@ -1170,6 +1182,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         p.numTasks += I.numTasks; p.numMembers += (uint32_t)members.size(); p.numOperands += (uint32_t)operands.size();
     }
 
+    phase("island programs");
     // ---- 5. launch levels, roots, taps ------------------------------------------------------------------
     p.islandLevel.resize(ib.size());
     for (size_t i = 0; i < ib.size(); ++i) p.islandLevel[i] = (uint32_t)ib[i].level;
@@ -1201,6 +1214,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         for (int k : seqNodes[s]) if (ni[k].n->op == OP_TAPOUT) p.taps.push_back(TapEntry{ni[k].n->rec, r->rec});
         for (int k : seqNodes[s]) if (ni[k].n->op == OP_METER || ni[k].n->op == OP_SNAPSHOT || ni[k].n->op == OP_SCOPE) p.eventNodes.push_back({ni[k].n->id, r->id});
     }
+    phase("levels, roots");
     return plan;
 }
 
@@ -1254,9 +1268,12 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
             for (auto& kv : byText) {
                 // background mode: a shape only one island has (a voice that is fading out next to its replacement, a
                 // one-off graph) is not worth a compile of its own: it renders through the interpreter kernel
-                if (specialize == 1 && kv.second.size() < 2 && !Jit::get().known(*kv.first, p.islands[kv.second[0]].ldsWords)) continue;
+                const uint32_t ldsW = p.islands[kv.second[0]].ldsWords;
+                auto kc = specKeyCache.find(kv.first);
+                if (kc == specKeyCache.end()) kc = specKeyCache.emplace(kv.first, Jit::get().keyFor(*kv.first, ldsW)).first;
+                if (specialize == 1 && kv.second.size() < 2 && !Jit::get().knownKey(kc->second)) continue;
                 Plan::SpecShape sh;
-                sh.entry = Jit::get().request(*kv.first, p.islands[kv.second[0]].ldsWords);
+                sh.entry = Jit::get().requestKey(kc->second, *kv.first, ldsW);
                 sh.level = (uint32_t)l; sh.listBegin = (uint32_t)p.specLists.size(); sh.count = (uint32_t)kv.second.size();
                 for (uint32_t isl : kv.second) { p.specLists.push_back(isl); covered[isl] = 1; }
                 p.shapes.push_back(std::move(sh));
@@ -1286,6 +1303,7 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     put(oSpecLists, p.specLists.data(), p.specLists.size() * 4);
     put(oRest, p.restIslands.data(), p.restIslands.size() * 4);
 
+    if (std::getenv("ELEMHIP_PLAN_TIMING")) std::fprintf(stderr, "[elemhip] plan shapes + pack done\n");
     renderLock.lock();   // ---- from here on: render-side state ----
     st.specShapes = (uint32_t)p.shapes.size(); st.specIslands = (uint32_t)p.specLists.size();
     if (jitWaitMs >= 0.0) st.lastJitWaitMs = jitWaitMs;
