@@ -13,6 +13,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -59,7 +60,7 @@ struct Jit::Impl {
         int maj = 0, min = 0;
         (void)hiprtcVersion(&maj, &min);
         versionTag = "hiprtc" + std::to_string(maj) + "." + std::to_string(min) + ";gfx950;-O3;-ffp-contract=off;v1";
-        unsigned n = 2;
+        unsigned n = std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 4u));   // a plan of a new graph brings several shapes at once
         if (const char* t = std::getenv("ELEMHIP_JIT_THREADS")) n = (unsigned)std::max(1, std::atoi(t));
         // The compiler library (comgr) is loaded lazily by the first hiprtc compile and registers its static destructors
         // then. Do that first compile here, on the calling thread (~45 ms, once per process), and register the exit hook
