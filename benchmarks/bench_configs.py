@@ -213,16 +213,71 @@ def c5(args):
         return {"static_frames_per_s": static, "mutating_frames_per_s": frames / dt, "ratio": frames / dt / static, "batches_applied": applied,
                 "commit_to_first_block_ms_p50": pct(lat, 0.5), "commit_to_first_block_ms_p99": pct(lat, 0.99)}
 
+    def drive_two_threads(rt, seconds):
+        """The realtime shape of config 5: a render thread calls process() block after block (synchronous, through host
+        buffers) while a control thread applies the mutation stream at `rate` batches per second. Reported: the render
+        call's latency distribution without and with the commits running (the engine plans outside the render lock, so the
+        two should agree), and how long a commit call takes on the control thread."""
+        import threading
+        assert rt.apply_instructions_json(texts[0]) == 0
+        for _ in range(64):
+            rt.process(None, 2, BLOCK)
+
+        def render_for(sec, stop=None):
+            lat = []
+            t_end = time.perf_counter() + sec
+            while time.perf_counter() < t_end and not (stop and stop.is_set()):
+                t0 = time.perf_counter()
+                rt.process(None, 2, BLOCK)
+                lat.append(1e6 * (time.perf_counter() - t0))
+            lat.sort()
+            return lat
+        quiet = render_for(1.0)
+        commits, done = [], threading.Event()
+
+        def control():
+            t0 = time.perf_counter()
+            k = 0
+            while time.perf_counter() - t0 < seconds and k < len(texts) - 1:
+                due = int((time.perf_counter() - t0) * rate)
+                if k < due:
+                    k += 1
+                    ta = time.perf_counter()
+                    assert rt.apply_instructions_json(texts[k]) == 0
+                    commits.append(1e3 * (time.perf_counter() - ta))
+                    if k % 16 == 0:
+                        rt.gc()
+                else:
+                    time.sleep(0.002)
+            done.set()
+        th = threading.Thread(target=control)
+        import gc as _gc
+        _gc.collect(); _gc.disable()
+        th.start()
+        busy = render_for(seconds + 1.0, stop=done)
+        th.join()
+        _gc.enable()
+        commits.sort()
+        pct = lambda a, q: a[min(len(a) - 1, int(q * len(a)))] if a else None
+        return {"render_call_us_quiet": {"p50": pct(quiet, 0.5), "p99": pct(quiet, 0.99), "max": quiet[-1] if quiet else None, "calls": len(quiet)},
+                "render_call_us_while_committing": {"p50": pct(busy, 0.5), "p99": pct(busy, 0.99), "max": busy[-1] if busy else None, "calls": len(busy)},
+                "commit_call_ms": {"p50": pct(commits, 0.5), "p99": pct(commits, 0.99), "count": len(commits)},
+                "note": "render thread: synchronous elemhip_process of one 512-frame block (launch + D2H + sync); control thread: "
+                        "apply_instructions at 28 batches per second + gc every 16; one Python process (the GIL is released inside both calls)"}
+
     rt = Runtime(graphs.C2_SAMPLE_RATE, BLOCK, device=0)
     rt.set_option("specialize", 1)   # a live graph never waits for a compiler: background mode (the product default)
     gpu = drive(rt, lambda k: rt.process_blocks(k, 2, out_ptr=out.data_ptr()), args.seconds)
     st = rt.stats()
+    rt2 = Runtime(graphs.C2_SAMPLE_RATE, BLOCK, device=0)
+    rt2.set_option("specialize", 1)
+    threaded = drive_two_threads(rt2, min(args.seconds, 6.0))
     cpu, kind = _cpu_engine(graphs.C2_SAMPLE_RATE)
     ref = drive(cpu, lambda k: [cpu.process(None, 2, BLOCK) for _ in range(k)], min(args.seconds, 4.0))
     return {"config": "C5 dynamic graph: 128 live voices (~2060 nodes), one voice replaced per batch, 28 batches per wall-clock second, gc every 16",
             "instructions_per_batch": sum(sizes[1:]) / max(1, len(sizes) - 1), "nodes_created_per_batch": sum(creates[1:]) / max(1, len(creates) - 1),
             "node_adds_per_second": rate * sum(creates[1:]) / max(1, len(creates) - 1),
-            "gpu": gpu, "plan_build_ms_last": st["last_plan_build_ms"], "hipgraph_capture_ms_last": st["last_graph_capture_ms"],
+            "gpu": gpu, "gpu_two_threads": threaded, "plan_build_ms_last": st["last_plan_build_ms"], "hipgraph_capture_ms_last": st["last_graph_capture_ms"],
             "hipgraph_captures": st["graph_captures"], "plans_built": st["plans_built"],
             "cpu_reference": ref, "cpu_kind": kind,
             "note": "instruction batches are generated before the timed region; commit -> first block = apply_instructions (graph "
