@@ -935,7 +935,13 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         // eight waves of one workgroup — same latency for a single block, and a multi-block launch gives every block its own
         // workgroup. Level 1 of C2: 48 -> 22 us per launch set. `mixer_split` = 2 keeps two workgroups of four active waves: the
         // single-block launch stays at 13 us where one workgroup of eight needs 21.)
-        I.split = mixerLike ? std::max(1u, std::min(e.mixerSplit, bs / 64u)) : 1u;
+        I.split = 1u;
+        if (mixerLike) {   // slices must be whole 64-frame units: the largest divisor of the block's unit count within the option
+            const uint32_t units = bs / 64u;
+            uint32_t parts = bs % 64u == 0u ? std::max(1u, std::min(e.mixerSplit, units)) : 1u;
+            while (parts > 1u && units % parts != 0u) --parts;
+            I.split = parts;
+        }
         // stage tables: tasks per stage, previous non-empty stage, per-wave first task of each stage
         const uint32_t S = (uint32_t)maxStage + 1;
         std::vector<uint32_t> stageTab(2 * S + kWaves * (S + 1) + copies + 1, 0u);

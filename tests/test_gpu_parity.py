@@ -245,3 +245,23 @@ def test_stranger_things_example(gpu_required):
     assert np.abs(b).max() > 0.05
     scale = max(1.0, float(np.abs(b).max()))
     assert float(np.abs(a - b).max()) <= TOL * scale
+
+
+@pytest.mark.parametrize("bs", [37, 100, 192, 300, 448, 500])
+def test_block_sizes_with_mixers(gpu_required, bs):
+    """Block sizes that are not powers of two, with mixer islands in the plan (16 C2 voices: two 8-input mixers, cut into
+    64-frame runs over the waves of one or more workgroups): block at a time and through launch sets vs the reference."""
+    import torch
+    hip, chk = _engines()
+    a, b, c = hip(48000.0, bs), hip(48000.0, bs), chk(48000.0, bs)
+    roots = graphs.c2_graph(voices=16)
+    for rt in (a, b, c):
+        assert rt.render(*roots)["result"] == 0
+    nb = 24
+    ref = np.stack([c.process(None, 2, bs) for _ in range(nb)])
+    one = np.stack([a.process(None, 2, bs) for _ in range(nb)])
+    out = torch.zeros((nb, 2, bs), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    b.set_option("batch_blocks", 7)
+    b.process_blocks(nb, 2, out_ptr=out.data_ptr())
+    assert float(np.abs(one - ref).max()) <= TOL and float(np.abs(out.cpu().numpy() - ref).max()) <= TOL

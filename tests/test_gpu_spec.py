@@ -150,3 +150,21 @@ def test_spec_falls_back_while_compiling(gpu_required):
     got = np.concatenate([_render_blocks(a, 24, 2) for _ in range(12)])
     ref = np.stack([c.process(None, 2, 512) for _ in range(24 * 12)])
     assert float(np.abs(got - ref).max()) <= TOL
+
+
+@pytest.mark.parametrize("bs", [64, 192, 256])
+def test_spec_other_block_sizes(gpu_required, bs):
+    """Specialised kernels at block sizes other than 512 (multiples of 64: the unit of their vector accesses): the
+    recurrence loops pick their prefetch depth from the block length, the stage ranges shrink with it. 16 C2 voices and the
+    every-stateful-node graph, 40 blocks each, vs the reference engine."""
+    from cases import every_stateful_roots
+    for roots_fn, n_out, n_in in ((lambda: graphs.c2_graph(voices=16), 2, 0), (every_stateful_roots, 3, 1)):
+        a, c = _spec_runtime(48000.0, bs, batch=16), _checker(48000.0, bs)
+        assert a.render(*roots_fn())["result"] == 0 and c.render(*roots_fn())["result"] == 0
+        nb = 40
+        x = np.stack([np.stack([lcg_noise(bs, 7 + k, 0.5)]) for k in range(nb)]) if n_in else None
+        got = _render_blocks(a, nb, n_out, x, block=bs)
+        ref = np.stack([c.process(x[k] if n_in else None, n_out, bs) for k in range(nb)])
+        _assert_ran_specialised(a)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(got - ref).max()) <= TOL * scale, (bs, float(np.abs(got - ref).max()))

@@ -51,6 +51,9 @@ def main():
             jobs.append((f"fuzz{seed}", 48000.0, 512, random_graph(seed, n_nodes=24 + 22 * (seed % 4), n_roots=1 + seed % 5)[:n_out], None, None))
         jobs.append(("c2x16", 48000.0, 512, graphs.c2_graph(voices=16), None, None))
         from cases import every_stateful_roots
+        for bs in (64, 192, 256):                      # tests/test_gpu_spec.py::test_spec_other_block_sizes
+            jobs.append((f"c2x16_bs{bs}", 48000.0, bs, graphs.c2_graph(voices=16), None, None))
+            jobs.append((f"stateful_bs{bs}", 48000.0, bs, every_stateful_roots(), None, None))
         for copies in (1, 3, 6):
             jobs.append((f"stateful_d{copies}", 48000.0, 512, every_stateful_roots(), None, copies))
     for name, sr, bs, roots, res, copies in jobs:
