@@ -2,8 +2,8 @@
 """bench.py — BASELINE.json's headline metric on its 1-GPU configuration (configs[1], "C2"):
 audio samples/sec for the 4107-node / 256-voice subtractive-synth graph at blockSize 512.
 
-A *step* is one pass of the hot path over one batch: ONE LAUNCH SET = 256 consecutive 512-frame blocks of
-that graph (131 072 output frames = 2.7 s of audio; --batch-blocks) rendered by the HIP engine through the offline entry point
+A *step* is one pass of the hot path over one batch: ONE LAUNCH SET = 1024 consecutive 512-frame blocks of
+that graph (524 288 output frames = 10.9 s of audio; --batch-blocks) rendered by the HIP engine through the offline entry point
 (``elemhip_process_blocks``: one multi-block kernel launch per island level, outputs resident in HBM).
 ``--steps K --warmup W`` therefore renders W + K full launch sets whatever K is, and the roofline
 figures are computed from the K timed steps themselves (wall clock for the headline fraction, HIP
@@ -119,7 +119,7 @@ def main_c4(args) -> None:
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    inst, B = args.instances, max(1, min(256, args.batch_blocks))
+    inst, B = args.instances, max(1, min(1024, args.batch_blocks))
     rt = Runtime(graphs.C4_SAMPLE_RATE, BLOCK, device=local)
     rt.set_option("batch_blocks", B)
     rt.set_option("specialize", args.specialize)
@@ -190,8 +190,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64, help="timed steps; one step = one launch set of --batch-blocks blocks")
     ap.add_argument("--warmup", type=int, default=8, help="untimed steps")
-    ap.add_argument("--batch-blocks", type=int, default=256, help="512-frame blocks per step (= per multi-block launch set)")
-    ap.add_argument("--steps-per-call", type=int, default=4, help="steps per elemhip_process_blocks call")
+    ap.add_argument("--batch-blocks", type=int, default=1024, help="512-frame blocks per step (= per multi-block launch set)")
+    ap.add_argument("--steps-per-call", type=int, default=1, help="steps per elemhip_process_blocks call")
     ap.add_argument("--graph-blocks", type=int, default=8, help="blocks per captured hipGraph (per-block launch path)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -231,7 +231,7 @@ def main() -> None:
     else:
         first, my_voices = args.voices * rank, args.voices
         total_voices = args.voices * world
-    B = max(1, min(256, args.batch_blocks))         # blocks per step
+    B = max(1, min(1024, args.batch_blocks))        # blocks per step
     rt = Runtime(graphs.C2_SAMPLE_RATE, BLOCK, device=local)
     rt.set_option("use_graph", 0 if args.no_graph else 1)
     rt.set_option("graph_blocks", args.graph_blocks)

@@ -1132,7 +1132,7 @@ int Engine::setOption(const std::string& key, double value) {
     std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
-    if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(256, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
+    if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(1024, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
     if (key == "debug_build_delay_ms") { debugBuildDelayMs = std::max(0, (int)value); return kOk; }   // tests: stretches the unlocked part of a plan build
     if (key == "mixer_split") { const int v = (int)value; mixerSplit = (v == 2 || v == 4 || v == 8) ? (uint32_t)v : 1u; planStale = true; return kOk; }
     if (key == "stateless_rows") { statelessRows = (uint32_t)std::max(1, std::min(64, (int)value)); return kOk; }   // gridDim.y of a multi-block launch: blocks that stateless islands render side by side

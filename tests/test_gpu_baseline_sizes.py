@@ -188,14 +188,14 @@ def test_rendering_continues_while_a_commit_is_planned(gpu_required):
         assert float(np.abs(got - ref).max()) <= TOL, k
 
 
-@pytest.mark.parametrize("batch,rows,split,spec", [(256, 64, 2, 2), (128, 16, 1, 0), (64, 8, 8, 2), (7, 3, 4, 0)])
+@pytest.mark.parametrize("batch,rows,split,spec", [(1024, 64, 2, 2), (256, 64, 2, 2), (128, 16, 1, 0), (64, 8, 8, 2), (7, 3, 4, 0)])
 def test_launch_set_geometry_options(gpu_required, batch, rows, split, spec):
-    """Blocks per launch set (up to 256), grid rows of stateless islands and workgroups per mixer only change how the
+    """Blocks per launch set (up to 1024), grid rows of stateless islands and workgroups per mixer only change how the
     work is laid out: 300 blocks of a 48-voice C2 graph equal the reference engine's for every setting."""
     a, c = _hip(graphs.C2_SAMPLE_RATE, 512, specialize=spec, batch_blocks=batch, stateless_rows=rows, mixer_split=split), _checker(graphs.C2_SAMPLE_RATE, 512)
     roots = graphs.c2_graph(voices=48)
     assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
     got = _blocks(a, 300, 2)
     ref = np.stack([c.process(None, 2, 512) for _ in range(300)])
-    assert a.stats()["batch_launches"] >= 300 // batch
+    assert a.stats()["batch_launches"] >= max(1, 300 // batch)
     assert float(np.abs(got - ref).max()) <= TOL
