@@ -3,15 +3,19 @@
 audio samples/sec for the 4107-node / 256-voice subtractive-synth graph at blockSize 512.
 
 A *step* is one pass of the hot path over one batch: ONE LAUNCH SET = 1024 consecutive 512-frame blocks of
-that graph (524 288 output frames = 10.9 s of audio; --batch-blocks) rendered by the HIP engine through the offline entry point
-(``elemhip_process_blocks``: one multi-block kernel launch per island level, outputs resident in HBM).
-``--steps K --warmup W`` therefore renders W + K full launch sets whatever K is, and the roofline
-figures are computed from the K timed steps themselves (wall clock for the headline fraction, HIP
-event pairs recorded inside the timed region for the dominant kernel).  With N > 1 GPUs the voices
-shard over the ranks with no data-path collective; the per-rank output buses are sum-reduced to
-rank 0 over RCCL inside the timed region.  ``--scaling weak`` (default): every rank
-renders its own 256-voice graph, ``value`` = frames of all N graphs / max-over-ranks wall time;
-``--scaling strong``: the ONE 256-voice graph is split over the ranks, ``value`` = its frames / time.
+that graph (524 288 output frames = 10.9 s of audio; --batch-blocks) rendered by the HIP engine through the offline
+entry point and DELIVERED TO HOST MEMORY, where the reference's own callers receive their samples
+(``elemhip_process_blocks_host``: planar host arrays, launch sets staged through pinned double buffers, the D2H of
+set k overlapped with the rendering of set k + 1).  ``--steps K --warmup W`` renders W + K full launch sets whatever K
+is; the roofline figures are computed from the K timed steps themselves (wall clock for the headline fraction, HIP
+event pairs recorded inside the timed region for the dominant kernel).  After the timed region the output is CHECKED:
+the head of the stream against the reference engine on one host core, the last blocks of the last timed step against
+the reference engine advanced to the same block on all host cores (``parity_max_abs_err``).  The device-resident
+rate (``elemhip_process_blocks``, outputs left in HBM) is measured right after and reported as a sub-field.
+With N > 1 GPUs the voices shard over the ranks with no data-path collective; the per-rank output buses are
+sum-reduced to rank 0 over RCCL inside the timed region and rank 0 copies the reduced bus to pinned
+host memory.  ``--scaling weak`` (default): every rank renders its own 256-voice graph, ``value`` = frames of all N
+graphs / max-over-ranks wall time; ``--scaling strong``: the ONE 256-voice graph is split over the ranks.
 
 Launch (N > 1):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
                  --master-port P bench.py --gpus N --steps K --warmup W
@@ -32,10 +36,11 @@ HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/
 BLOCK = 512
 
 
-def cpu_baseline(target_seconds: float = 15.0):
+def cpu_baseline(target_seconds: float = 15.0, keep_blocks: int = 0):
     """Reference engine (oracle/_ref, -O3 -march=x86-64-v3 -ffp-contract=off) on ONE host core,
-    same graph, cli/Benchmark.cpp protocol (warm-up then timed process() calls, steady clock)."""
-    import numpy as np  # noqa: F401
+    same graph, cli/Benchmark.cpp protocol (warm-up then timed process() calls, steady clock).
+    The first `keep_blocks` blocks of its output stream are kept (``head``, [2, frames]) for the parity check."""
+    import numpy as np
     import oracle
     from elementary_amd import graphs
 
@@ -48,42 +53,57 @@ def cpu_baseline(target_seconds: float = 15.0):
     else:
         return None
     assert rt.render(*graphs.c2_graph())["result"] == 0
+    head = []
+
+    def step():
+        y = rt.process(None, 2, BLOCK)
+        if len(head) < keep_blocks:
+            head.append(y)
+
     for _ in range(8):
-        rt.process(None, 2, BLOCK)
+        step()
     t0 = time.perf_counter()
     for _ in range(50):
-        rt.process(None, 2, BLOCK)
+        step()
     per = (time.perf_counter() - t0) / 50
     m = int(max(200, min(4000, target_seconds / per)))
     t0 = time.perf_counter()
     for _ in range(m):
-        rt.process(None, 2, BLOCK)
+        step()
     dt = time.perf_counter() - t0
     return {
         "value": BLOCK * m / dt, "unit": "samples/s", "cores": 1, "kind": kind,
         "sample": f"{m} blocks of {BLOCK} frames of the same 4107-node C2 graph, 1 thread, after 58 warm-up blocks",
         "ms_per_block": 1e3 * dt / m,
+        "head": np.concatenate(head, axis=1) if head else None,
     }
 
 
 def _mc_worker(args):
-    first, count, blocks = args
+    first, count, blocks, tail = args
+    import numpy as np
     import oracle
     from elementary_amd import graphs
     rt = oracle.RefRuntime(graphs.C2_SAMPLE_RATE, BLOCK, bench_build=os.path.exists(oracle.REF_BENCH_SO))
     assert rt.render(*graphs.c2_graph(voices=count, channels=2, first_voice=first))["result"] == 0
-    for _ in range(8):
-        rt.process(None, 2, BLOCK)
+    last = []
     t0 = time.perf_counter()
-    for _ in range(blocks):
-        rt.process(None, 2, BLOCK)
-    return time.perf_counter() - t0
+    for k in range(blocks):
+        y = rt.process(None, 2, BLOCK)
+        if k >= blocks - tail:
+            last.append(y.astype(np.float64))
+    return time.perf_counter() - t0, (np.concatenate(last, axis=1) if last else None)
 
 
-def cpu_baseline_multicore(single_ms_per_block: float, target_seconds: float = 8.0):
+def cpu_baseline_multicore(single_ms_per_block: float, target_seconds: float = 8.0, advance_blocks: int = 0, tail: int = 0,
+                           budget_seconds: float = 45.0):
     """SURVEY 8(d) fairness variant: the 256 voices partitioned over P reference Runtimes on P host cores
-    (one process each, the host would sum P stereo buses per block: negligible, not timed)."""
+    (one process each, the host would sum P stereo buses per block: negligible, not timed).
+    With `advance_blocks` the P engines render exactly that many blocks FROM TIME ZERO (when the estimate fits
+    `budget_seconds`) and the partial buses of the last `tail` blocks come back summed in voice order (float64):
+    the reference's stream at the end of the benchmark's timed region, for the parity check."""
     import multiprocessing as mp
+    import numpy as np
     import oracle
     if not oracle.have_ref():
         return None
@@ -91,34 +111,50 @@ def cpu_baseline_multicore(single_ms_per_block: float, target_seconds: float = 8
     while 256 % cores:
         cores -= 1
     per = 256 // cores
-    blocks = int(max(50, min(2000, target_seconds / (single_ms_per_block * 1e-3 * per / 256.0))))
+    per_block_s = single_ms_per_block * 1e-3 * per / 256.0
+    blocks = int(max(50, min(2000, target_seconds / per_block_s)))
+    advanced = bool(advance_blocks) and advance_blocks * per_block_s * 1.3 <= budget_seconds
+    if advanced:
+        blocks = int(advance_blocks)
     ctx = mp.get_context("spawn")   # the parent holds a HIP context: never fork it
     with ctx.Pool(cores) as pool:
-        times = pool.map(_mc_worker, [(k * per, per, blocks) for k in range(cores)])
-    dt = max(times)
-    return {"value": BLOCK * blocks / dt, "unit": "samples/s", "cores": cores, "kind": "reference",
-            "sample": f"{blocks} blocks, {cores} processes x {per} voices each (same 256-voice graph partitioned by voice)",
-            "ms_per_block": 1e3 * dt / blocks}
+        res = pool.map(_mc_worker, [(k * per, per, blocks, tail if advanced else 0) for k in range(cores)])
+    dt = max(r[0] for r in res)
+    out = {"value": BLOCK * blocks / dt, "unit": "samples/s", "cores": cores, "kind": "reference",
+           "sample": f"{blocks} blocks from time zero, {cores} processes x {per} voices each (same 256-voice graph partitioned by voice)",
+           "ms_per_block": 1e3 * dt / blocks, "tail": None}
+    if advanced and tail:
+        acc = np.zeros_like(res[0][1])
+        for r in res:               # voice order: process k owns voices [k * per, (k + 1) * per)
+            acc += r[1]
+        out["tail"] = acc
+    return out
 
 
 def main_c4(args) -> None:
-    """BASELINE configs[3] (C4): `--instances` independent offline render jobs per GPU (1024 over 8 GPUs = 128 per GPU).
-    SURVEY.md 8(e): the unit of sharding is the whole render job, so ranks share nothing — no data-path collective, each
-    job's output stays in its rank's HBM; weak scaling by construction. Same timing protocol as the headline workload."""
+    """BASELINE configs[3] (C4): `--instances` independent offline render jobs per GPU (1024 over 8 GPUs = 128 per GPU),
+    "RCCL output gather". SURVEY.md 8(e): the unit of sharding is the whole render job, so ranks share nothing while they
+    render; the one exchange is the gather of the per-job outputs. N = 1: every job's samples are delivered to host memory
+    (elemhip_process_blocks_host). N > 1: each rank renders into HBM and the outputs of every chunk are gathered on rank 0
+    over RCCL (sharded.gather_outputs) INSIDE the timed region. Same timing protocol as the headline workload."""
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     from elementary_amd import graphs
     from elementary_amd.runtime import Runtime
+    from elementary_amd.sharded import gather_outputs
 
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    if args.shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     inst, B = args.instances, max(1, min(1024, args.batch_blocks))
     rt = Runtime(graphs.C4_SAMPLE_RATE, BLOCK, device=local)
     rt.set_option("batch_blocks", B)
@@ -130,22 +166,36 @@ def main_c4(args) -> None:
     assert rt.render(*[graphs.c4_instance(inst * rank + k) for k in range(inst)])["result"] == 0
     build_ms = 1e3 * (time.perf_counter() - t0)
     spc = max(1, args.steps_per_call)
+    host_mode = world == 1 and not args.device_resident
     out = torch.zeros((spc * B, inst, BLOCK), dtype=torch.float32, device="cuda")
+    gathered_elems = 0
 
-    def run(steps: int) -> None:
+    def run(steps: int, host_out=None) -> None:
+        nonlocal gathered_elems
+        if host_mode:
+            rt.process_blocks_host(None, inst, steps * B * BLOCK, out=host_out)
+            return
         done = 0
         while done < steps:
             c = min(spc, steps - done)
             rt.process_blocks(c * B, inst, out_ptr=out.data_ptr())
+            if world > 1:          # [blocks, inst, frames] -> per-job outputs [inst, blocks, frames], gathered on rank 0
+                g = gather_outputs(out[:c * B].transpose(0, 1).contiguous(), dst=0)
+                if g is not None:
+                    gathered_elems += g.numel()
             done += c
 
-    run(args.warmup)
+    warm_host = np.empty((inst, max(1, args.warmup) * B * BLOCK), dtype=np.float32) if host_mode else None
+    timed_host = np.zeros((inst, args.steps * B * BLOCK), dtype=np.float32) if host_mode else None
+    if args.warmup:
+        run(args.warmup, warm_host)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     rt.set_option("profile_launches", 1)
+    gathered_elems = 0
     t0 = time.perf_counter()
-    run(args.steps)
+    run(args.steps, timed_host)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -167,16 +217,21 @@ def main_c4(args) -> None:
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[3] (C4): {inst} independent render instances per GPU ({inst * world} in all), "
-                                   "each cycle -> biquad -> tanh, sr 48000, blockSize 512; one step = one launch set of "
-                                   f"{B} blocks of every instance", "instances_per_gpu": inst, "instances_total": inst * world,
+                                   "each rand -> svf -> delay{24000} -> biquad -> sdelay -> tanh (odd instances: biquad before svf), "
+                                   f"sr 48000, blockSize 512; one step = one launch set of {B} blocks of every instance",
+                       "instances_per_gpu": inst, "instances_total": inst * world,
                        "blocks_per_step": B, "islands": stats["num_islands"], "launch_levels": stats["num_levels"],
-                       "collectives": "none (jobs are independent; outputs stay on their rank)"},
+                       "mode": "host buffers (elemhip_process_blocks_host): every job's samples delivered to the caller's arrays" if host_mode
+                               else "device-resident render (elemhip_process_blocks)",
+                       "collectives": ("none on one GPU" if world == 1 else
+                                       "RCCL gather of every chunk's per-job outputs on rank 0 inside the timed region "
+                                       f"({gathered_elems * 4 / max(1, args.steps) / 1e6:.1f} MB per step); nothing is exchanged while rendering")},
             "us_per_block_step": us, "plan_build_ms": build_ms,
             "roofline": {"bound": "hbm", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                          "algorithmic_bytes_per_block_step": alg,
                          "launch_us_per_step": [1e3 * x / sets for x in prof["level_ms"]],
-                         "note": "bound by the biquad recurrence of one instance per workgroup (a lone wave), not by bytes"},
+                         "note": "bound by the float recurrences (biquad, delay feedback) of the instances, not by bytes"},
         }))
     if world > 1:
         dist.destroy_process_group()
@@ -195,6 +250,13 @@ def main() -> None:
     ap.add_argument("--graph-blocks", type=int, default=8, help="blocks per captured hipGraph (per-block launch path)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend for N > 1 ('nccl' = RCCL; 'gloo' lets a test run two ranks on ONE GPU)")
+    ap.add_argument("--shared-gpu", action="store_true", help="testing: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--check", action="store_true",
+                    help="N > 1, c2: compare the last reduced chunk on rank 0 with the reference engine rendering the whole graph")
+    ap.add_argument("--device-resident", action="store_true",
+                    help="time elemhip_process_blocks with the output bus left in HBM (the r01/r02 protocol) instead of the host-buffer entry")
     ap.add_argument("--voices", type=int, default=256)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra engine option (tuning experiments), repeatable")
     ap.add_argument("--specialize", type=int, default=2, choices=[0, 1, 2],
@@ -219,9 +281,11 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    if args.shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
 
     # ---- this rank's shard of the synth (independent voices: no data-path collective) ----
     if args.scaling == "strong":
@@ -245,32 +309,61 @@ def main() -> None:
     assert res["result"] == 0, res["result"]
     build_ms = 1e3 * (time.perf_counter() - t0)
 
+    import numpy as np
     spc = max(1, args.steps_per_call)
+    host_mode = world == 1 and not args.device_resident     # the headline mode: samples land in host memory
     bufs = [torch.zeros((spc * B, 2, BLOCK), dtype=torch.float32, device="cuda") for _ in range(2)]
+    pinned = torch.zeros((spc * B, 2, BLOCK), dtype=torch.float32).pin_memory() if world > 1 else None
 
-    def run(steps: int) -> None:
+    last_chunk = {}
+
+    def run_device(steps: int) -> None:
+        """elemhip_process_blocks: outputs stay in HBM (N > 1: async RCCL sum-reduce of every chunk to rank 0, which copies
+        the reduced bus to pinned host memory)."""
         done, k, works = 0, 0, []
         while done < steps:
             c = min(spc, steps - done)
             buf = bufs[k % 2]
             if world > 1 and len(works) >= 2:
-                works.pop(0).wait()            # the buffer we are about to overwrite has been reduced
+                w, b_ = works.pop(0)
+                w.wait()                       # the buffer we are about to overwrite has been reduced
+                if rank == 0:
+                    pinned[:b_.shape[0]].copy_(b_, non_blocking=True)
                 torch.cuda.current_stream().synchronize()   # the engine renders on its own stream
             rt.process_blocks(c * B, 2, out_ptr=buf.data_ptr())
             if world > 1:
-                works.append(reduce_bus(buf[:c * B], dst=0, async_op=True))
+                works.append((reduce_bus(buf[:c * B], dst=0, async_op=True), buf[:c * B]))
             done += c
             k += 1
-        for w in works:
+        for w, b_ in works:
             w.wait()
+            if rank == 0:
+                pinned[:b_.shape[0]].copy_(b_, non_blocking=True)
+        if world > 1 and rank == 0 and works:
+            torch.cuda.synchronize()
+            last_chunk["blocks"] = int(works[-1][1].shape[0])
 
-    run(args.warmup)
+    def run_host(steps: int, out) -> None:
+        """elemhip_process_blocks_host: ONE call renders `steps` launch sets into the planar host array out[2, frames]."""
+        rt.process_blocks_host(None, 2, steps * B * BLOCK, out=out)
+
+    warm_host = np.empty((2, max(1, args.warmup) * B * BLOCK), dtype=np.float32) if host_mode else None
+    timed_host = np.empty((2, args.steps * B * BLOCK), dtype=np.float32) if host_mode else None
+    if host_mode:
+        timed_host.fill(0.0)                                     # touch the pages outside the timed region
+        if args.warmup:
+            run_host(args.warmup, warm_host)
+    else:
+        run_device(args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     rt.set_option("profile_launches", 1)            # HIP event pair around every launch of the timed region
     t0 = time.perf_counter()
-    run(args.steps)
+    if host_mode:
+        run_host(args.steps, timed_host)
+    else:
+        run_device(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -298,14 +391,28 @@ def main() -> None:
         lvl_alg = graphs.c2_level_algorithmic_bytes(my_voices, 2, BLOCK)     # per block: [voices level, mixer level]
         dom_alg = lvl_alg[dom] if dom < len(lvl_alg) else alg_bytes
         dom_achieved = dom_alg * B / (lvl_us[dom] * 1e-6) / 1e9 if lvl_us and lvl_us[dom] > 0 else None
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("c2_hbm_bytes_per_block")
+                tj = json.load(open(tpath))
+                traffic = tj.get("c2_hbm_bytes_per_block")
                 traffic = traffic * B if traffic else None            # per launch set, like `achieved`'s basis
+                traffic_src = "profiles/traffic.json (rocprofv3 PMC passes of this command, committed; not re-measured in this run): " + str(tj.get("round", ""))
             except Exception:
                 traffic = None
+        # ---- the device-resident rate (no delivery), same engine, right after the timed region ----
+        device_resident = None
+        if host_mode:
+            run_device(min(args.warmup, 2))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_device(args.steps)
+            torch.cuda.synchronize()
+            dtd = time.perf_counter() - t1
+            device_resident = {"value": graph_frames / dtd, "unit": "samples/s", "ms_per_step": 1e3 * dtd / args.steps,
+                               "us_per_block": 1e6 * dtd / blocks,
+                               "mode": "elemhip_process_blocks, output bus left in HBM (one synchronous call per step)"}
         # ---- latency figures outside the timed region ----
         rt.set_option("time_batch", 1)
         lv1 = rt.time_launches(2, 100)
@@ -341,23 +448,29 @@ def main() -> None:
                 "voices_per_gpu": my_voices,
                 "voices_total": total_voices,
                 "block_size": BLOCK,
-                "mode": "offline elemhip_process_blocks, output bus resident in HBM"
-                        + (", RCCL sum-reduce of the bus to rank 0 per call" if world > 1 else ""),
-                "steps_per_call": spc,
+                "mode": ("host buffers: elemhip_process_blocks_host, every block delivered to the caller's planar host arrays "
+                         "(pinned double-buffered launch sets, D2H of set k under the rendering of set k + 1); all K steps in one call")
+                        if host_mode else
+                        ("offline elemhip_process_blocks, output bus resident in HBM"
+                         + (", RCCL sum-reduce of the bus to rank 0 per call, rank 0 copies the reduced bus to pinned host memory" if world > 1 else "")),
+                "steps_per_call": args.steps if host_mode else spc,
                 "pipelined_blocks_in_flight": rt.describe_plan()["islands"][0]["copies"],
                 "islands": stats["num_islands"], "launch_levels": stats["num_levels"], "max_lds_bytes": stats["max_lds_bytes"],
                 "island_kernels": ("run-time specialised per island shape (hiprtc, gfx950): %d shape(s) covering %d islands, %d launches; "
                                    "compile wait %.0f ms inside plan_build_ms (0 = on-disk cache hit)"
                                    % (stats["spec_shapes"], stats["spec_islands"], stats["spec_launches"], stats["last_jit_wait_ms"]))
                                   if args.specialize and stats["spec_launches"] else "ahead-of-time interpreter kernel",
+                "multi_gpu_note": "no 1 -> 8 GPU curve has been measured by the builder (single-GPU boxes only); N > 1 is covered by "
+                                  "2-process tests (gloo on CPU, two engines on one GPU)",
             },
             "us_per_block": us_per_block,
             "realtime_factor_48k": value / 48000.0,
             "plan_build_ms": build_ms,
             "sync_process_us_per_block": sync_us,
+            "device_resident": device_resident,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "basis": "timed region: algorithmic bytes per block x blocks / wall time of the K timed steps",
                 "algorithmic_bytes_per_block": alg_bytes, "algorithmic_bytes_per_step": alg_bytes * B,
                 "dominant_kernel": {
@@ -376,18 +489,57 @@ def main() -> None:
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline()
+            head_blocks = min(B, (args.warmup if args.warmup else args.steps) * B) if host_mode else 0
+            cb = cpu_baseline(keep_blocks=head_blocks)
             if cb:
+                head = cb.pop("head")
                 out["cpu_baseline"] = cb
                 out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+                parity = {"tolerance": 1e-6, "unit": "abs (x max|ref| when > 1)", "checker": cb["kind"]}
+                if host_mode and head is not None:
+                    got = (warm_host if args.warmup else timed_host)[:, :head.shape[1]]
+                    scale = max(1.0, float(np.abs(head).max()))
+                    parity["head"] = {"blocks": head.shape[1] // BLOCK, "max_abs_err": float(np.abs(got - head).max()), "scale": scale,
+                                      "what": "blocks 0.. of the first launch set (%s) vs the reference engine on one core" % ("warm-up" if args.warmup else "timed")}
                 try:
-                    mc = cpu_baseline_multicore(cb["ms_per_block"])
+                    mc = cpu_baseline_multicore(cb["ms_per_block"], advance_blocks=(args.warmup + args.steps) * B if host_mode else 0, tail=64)
                 except Exception as e:   # the fairness variant must never cost the headline line
                     mc = {"error": repr(e)}
                 if mc:
+                    tail = mc.pop("tail", None)
                     out["cpu_baseline_all_cores"] = mc
                     if "value" in mc:
                         out["speedup_vs_cpu_all_cores"] = out["value"] / mc["value"]
+                    if host_mode and tail is not None:
+                        got = timed_host[:, -tail.shape[1]:].astype(np.float64)
+                        scale = max(1.0, float(np.abs(tail).max()))
+                        parity["tail"] = {"blocks": tail.shape[1] // BLOCK, "max_abs_err": float(np.abs(got - tail).max()), "scale": scale,
+                                          "what": "the LAST blocks of the LAST timed step vs the reference engine advanced through all "
+                                                  "%d blocks (voices partitioned over %d host processes, partial buses summed in voice order in float64)"
+                                                  % ((args.warmup + args.steps) * B, mc.get("cores", 0))}
+                    elif host_mode:
+                        parity["tail"] = None
+                        parity["tail_skipped"] = "advancing the reference through the whole run would not fit the time budget on this host"
+                errs = [parity[k]["max_abs_err"] / parity[k]["scale"] for k in ("head", "tail") if parity.get(k)]
+                out["parity_max_abs_err"] = max(parity[k]["max_abs_err"] for k in ("head", "tail") if parity.get(k)) if errs else None
+                parity["ok"] = bool(errs) and max(errs) <= 1e-6
+                out["parity"] = parity
+        if world > 1 and args.check and last_chunk:
+            # the whole graph (every rank's voices) on the reference engine, advanced to the last reduced chunk
+            import oracle
+            chk = oracle.RefRuntime(graphs.C2_SAMPLE_RATE, BLOCK) if oracle.have_ref() else oracle.PortRuntime(graphs.C2_SAMPLE_RATE, BLOCK)
+            assert chk.render(*graphs.c2_graph(voices=total_voices, channels=2, first_voice=0))["result"] == 0
+            nb = last_chunk["blocks"]
+            total_blocks = (args.warmup + args.steps) * B
+            for _ in range(total_blocks - nb):
+                chk.process(None, 2, BLOCK)
+            ref = np.stack([chk.process(None, 2, BLOCK) for _ in range(nb)])
+            got = pinned[:nb].numpy()
+            scale = max(1.0, float(np.abs(ref).max()))
+            err = float(np.abs(got - ref).max())
+            out["parity_max_abs_err"] = err
+            out["parity"] = {"tolerance": 1e-6, "ok": err <= 1e-6 * scale, "scale": scale,
+                             "what": f"last {nb} blocks of the rank-0 reduced bus vs the reference engine rendering all {total_voices} voices"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -117,6 +117,11 @@ int elemhip_process_blocks(elemhip_t* h, const float* inDev, size_t nIn, float* 
     return h->engine.processBlocks(inDev, nIn, outDev, nOut, numBlocks, st);
 }
 
+int elemhip_process_blocks_host(elemhip_t* h, const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t numFrames, int64_t st) {
+    if (!h) return elemhip::kInvalidInstructionFormat;
+    return h->engine.processBlocksHost(in, nIn, out, nOut, numFrames, st);
+}
+
 int elemhip_add_shared_resource(elemhip_t* h, const char* name, const float* const* ch, size_t nCh, size_t nSamples) {
     if (!h || !name) return 0;
     return h->engine.addSharedResource(name, ch, nCh, nSamples) ? 1 : 0;

@@ -169,6 +169,17 @@ Engine::~Engine() {
     if (hPatches) (void)hipHostFree(hPatches);
     if (hOut) (void)hipHostFree(hOut);
     if (hIn) (void)hipHostFree(hIn);
+    if (ioStream) (void)hipStreamSynchronize(ioStream);
+    for (int k = 0; k < 2; ++k) {
+        if (hStageOut[k]) (void)hipHostFree(hStageOut[k]);
+        if (hStageIn[k]) (void)hipHostFree(hStageIn[k]);
+        if (dStageOut[k]) (void)hipFree(dStageOut[k]);
+        if (dStageIn[k]) (void)hipFree(dStageIn[k]);
+        if (evIn[k]) (void)hipEventDestroy(evIn[k]);
+        if (evRendered[k]) (void)hipEventDestroy(evRendered[k]);
+        if (evOut[k]) (void)hipEventDestroy(evOut[k]);
+    }
+    if (ioStream) (void)hipStreamDestroy(ioStream);
     if (ownStream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -230,7 +241,9 @@ void Engine::writeParam(Node& n, uint32_t dword, uint32_t value) {
     // a record that has not been uploaded yet travels whole; otherwise patch the one dword
     if (!freshFlag[n.rec])
         patches.push_back(Patch{0u, idx, value, 0u});
-    for (uint32_t cr : n.chanRecs) writeRec(cr, dword, value);   // a multi-output node: every channel's record (buffers are set per channel)
+    // a multi-output node: every channel's record — except the buffer slots (P0..P2: pointer, length), which differ per
+    // channel and are written by writeChannelBuffer only (two patches for one dword in one flush have no order)
+    if (dword > rec::P2) for (uint32_t cr : n.chanRecs) writeRec(cr, dword, value);
 }
 
 void Engine::writeRec(uint32_t rec, uint32_t dword, uint32_t value) {
@@ -284,6 +297,9 @@ uint32_t Engine::channelRec(Node& n, uint32_t ch) {
         // parameters and INITIAL state as the host last wrote them for channel 0 (pending-buffer flags included)
         std::memcpy(shadow.data() + (size_t)r * kRecDwords, shadow.data() + (size_t)n.rec * kRecDwords, kRecDwords * 4);
         writeChannelBuffer(n, (uint32_t)n.chanRecs.size(), r);
+        // channel 0 has been on the device already (it may be mid-playback): the new channel continues from channel 0's
+        // LIVE reader state and consumed flags — the reference keeps one state for all channels (mc/Sample.h, mc/SampleSeq.h)
+        if (!freshFlag[n.rec]) recClones.push_back({n.rec, r});
     }
     return n.chanRecs[ch - 1];
 }
@@ -1008,6 +1024,7 @@ size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
         const uint32_t lo = n.rec * kRecDwords, hi = lo + kRecDwords;
         patches.erase(std::remove_if(patches.begin(), patches.end(), [&](const Patch& p) { return p.kind != 2 && p.index >= lo && p.index < hi; }), patches.end());
         if (freshFlag[n.rec]) { freshRecs.erase(std::remove(freshRecs.begin(), freshRecs.end(), n.rec), freshRecs.end()); freshFlag[n.rec] = 0; }
+        recClones.erase(std::remove_if(recClones.begin(), recClones.end(), [&](const std::pair<uint32_t, uint32_t>& c) { return c.first == n.rec; }), recClones.end());
         freeRecs.push_back(n.rec);
         for (uint32_t cr : n.chanRecs) {
             const uint32_t clo = cr * kRecDwords, chi = clo + kRecDwords;
@@ -1191,6 +1208,12 @@ int Engine::flushPending() {
         off += cnt;
     }
     patches.clear();
+    // new channel records of multi-output nodes that are already rendering: everything but the buffer slots, AFTER the
+    // patches (a pending-buffer flag the host has just queued for channel 0 reaches the new channel with this copy)
+    for (auto& cl : recClones)
+        HIP_WARN(hipMemcpyAsync(dRecs + (size_t)cl.second * kRecDwords + rec::P3, dRecs + (size_t)cl.first * kRecDwords + rec::P3,
+                                (kRecDwords - rec::P3) * 4, hipMemcpyDeviceToDevice, stream));
+    recClones.clear();
     return kOk;
 }
 
@@ -1637,6 +1660,17 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
     std::lock_guard<std::mutex> lock(mu);
     if (dry) return kNoDevice;
     if (hipSetDevice(device) != hipSuccess) return kHipError;
+    int rc = enqueueBlocks(inDev, nIn, outDev, nOut, numBlocks, sampleTime);
+    if (rc != kOk) return rc;
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipGetLastError());
+    if (profUsed) profCollect();
+    freeDeferred();
+    return kOk;
+}
+
+// `mu` held, device current. Everything is enqueued on `stream`; the caller synchronises.
+int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime) {
     if (nIn > kMaxHostIn || nOut > kMaxOut) return kTooManyChannels;
     int rc = swapInPending();
     if (rc != kOk) return rc;
@@ -1726,11 +1760,128 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
         done += chunk;
         st.blocksRendered += chunk;
     }
-    HIP_OK(hipStreamSynchronize(stream));
-    HIP_OK(hipGetLastError());
-    if (profUsed) profCollect();
-    freeDeferred();
     return kOk;
+}
+
+int Engine::ensureHostStaging(size_t outFloats, size_t inFloats) {
+    if (!ioStream) {
+        HIP_OK(hipStreamCreateWithFlags(&ioStream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIP_OK(hipEventCreateWithFlags(&evIn[k], hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&evRendered[k], hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&evOut[k], hipEventDisableTiming));
+        }
+    }
+    auto grow = [&](float* (&h)[2], float* (&d)[2], size_t& have, size_t want) -> int {
+        if (want <= have) return kOk;
+        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipStreamSynchronize(ioStream));
+        for (int k = 0; k < 2; ++k) {
+            if (h[k]) (void)hipHostFree(h[k]);
+            if (d[k]) (void)hipFree(d[k]);
+            h[k] = nullptr; d[k] = nullptr;
+        }
+        have = 0;
+        for (int k = 0; k < 2; ++k) {
+            HIP_OK(hipHostMalloc((void**)&h[k], want * sizeof(float), hipHostMallocDefault));
+            HIP_OK(hipMalloc(&d[k], want * sizeof(float)));
+        }
+        have = want;
+        return kOk;
+    };
+    int rc = grow(hStageOut, dStageOut, stageOutFloats, outFloats);
+    if (rc != kOk) return rc;
+    return grow(hStageIn, dStageIn, stageInFloats, inFloats);
+}
+
+// Runtime::process for a whole offline render (offline-renderer/index.ts:87-133): planar host arrays of `numFrames` frames.
+// Set k (up to `batch_blocks` blocks) is gathered into pinned half k % 2, copied in on the copy stream, rendered on the
+// engine's stream into device half k % 2, copied out on the copy stream and scattered to the caller's arrays while set
+// k + 1 renders. The render lock is taken per set: a commit on another thread lands between two sets (block boundary).
+int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t numFrames, int64_t sampleTime) {
+    if (dry) return kNoDevice;
+    if (nIn > kMaxHostIn || nOut > kMaxOut) return kTooManyChannels;
+    if ((nIn && !in) || (nOut && !out)) return kInvalidInstructionFormat;
+    const size_t bs = (size_t)blockSize;
+    const size_t numBlocks = (numFrames + bs - 1) / bs;
+    if (numBlocks == 0) return kOk;
+    size_t setBlocks;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (hipSetDevice(device) != hipSuccess) return kHipError;
+        setBlocks = (size_t)std::max(1, batchBlocks);
+        if (setBlocks < 8) setBlocks = std::min<size_t>(64, numBlocks);     // per-block launch path: still stage whole chunks
+        setBlocks = std::min(setBlocks, numBlocks);
+        int rc = ensureHostStaging(setBlocks * std::max<size_t>(nOut, 1) * bs, setBlocks * std::max<size_t>(nIn, 1) * bs);
+        if (rc != kOk) return rc;
+    }
+    const size_t numSets = (numBlocks + setBlocks - 1) / setBlocks;
+    auto scatter = [&](size_t k) {     // pinned half -> the caller's planar arrays
+        const size_t b0 = k * setBlocks, nb = std::min(setBlocks, numBlocks - b0);
+        const float* src = hStageOut[k & 1];
+        for (size_t b = 0; b < nb; ++b) {
+            const size_t f0 = (b0 + b) * bs;
+            const size_t n = std::min(bs, numFrames - f0);
+            for (size_t c = 0; c < nOut; ++c) std::memcpy(out[c] + f0, src + (b * nOut + c) * bs, n * sizeof(float));
+        }
+    };
+    int result = kOk;
+    size_t issued = 0;
+    for (size_t k = 0; k < numSets; ++k) {
+        const size_t b0 = k * setBlocks, nb = std::min(setBlocks, numBlocks - b0);
+        const int half = (int)(k & 1);
+        if (nIn) {
+            if (k >= 2) HIP_OK(hipEventSynchronize(evIn[half]));     // the H2D of set k - 2 has left this pinned half
+            float* dst = hStageIn[half];
+            for (size_t b = 0; b < nb; ++b) {
+                const size_t f0 = (b0 + b) * bs;
+                const size_t n = f0 < numFrames ? std::min(bs, numFrames - f0) : 0;
+                for (size_t c = 0; c < nIn; ++c) {
+                    float* d = dst + (b * nIn + c) * bs;
+                    if (n) std::memcpy(d, in[c] + f0, n * sizeof(float));
+                    if (n < bs) std::memset(d + n, 0, (bs - n) * sizeof(float));
+                }
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (hipSetDevice(device) != hipSuccess) { result = kHipError; break; }
+            if (nIn) {
+                // (the copy stream is in order: this H2D runs behind the D2H of set k - 2, which waited for that set's render,
+                //  the last reader of this device half)
+                HIP_OK(hipMemcpyAsync(dStageIn[half], hStageIn[half], nb * nIn * bs * sizeof(float), hipMemcpyHostToDevice, ioStream));
+                HIP_OK(hipEventRecord(evIn[half], ioStream));
+                HIP_OK(hipStreamWaitEvent(stream, evIn[half], 0));
+            }
+            if (k >= 2) HIP_OK(hipStreamWaitEvent(stream, evOut[half], 0));   // the D2H of set k - 2 has drained this device half
+            int rc = enqueueBlocks(nIn ? dStageIn[half] : nullptr, nIn, nOut ? dStageOut[half] : nullptr, nOut, nb,
+                                   sampleTime + (int64_t)(b0 * bs));
+            if (rc != kOk) { result = rc; break; }
+            HIP_OK(hipEventRecord(evRendered[half], stream));
+            HIP_OK(hipStreamWaitEvent(ioStream, evRendered[half], 0));
+            if (nOut) HIP_OK(hipMemcpyAsync(hStageOut[half], dStageOut[half], nb * nOut * bs * sizeof(float), hipMemcpyDeviceToHost, ioStream));
+            HIP_OK(hipEventRecord(evOut[half], ioStream));
+            issued = k + 1;
+        }
+        if (k >= 1) {   // set k - 1 arrives while set k renders
+            HIP_OK(hipEventSynchronize(evOut[(k - 1) & 1]));
+            if (nOut) scatter(k - 1);
+        }
+    }
+    if (issued) {
+        const size_t last = issued - 1;
+        if (hipEventSynchronize(evOut[last & 1]) != hipSuccess) return kHipError;
+        if (nOut && result == kOk) scatter(last);
+    }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipStreamSynchronize(ioStream));
+        HIP_OK(hipGetLastError());
+        if (profUsed) profCollect();
+        freeDeferred();
+    }
+    return result;
 }
 
 } // namespace elemhip

@@ -90,6 +90,14 @@ struct Node {
 
 struct Plan;   // plan.cpp
 
+// Generated text of one island-program signature (codegen.cpp) and, once computed, its kernel cache key (jit.cpp). Shared by
+// Engine::specTextCache and the plans being built; the key is written under the control lock.
+struct SpecText {
+    std::string text;
+    std::string key;          // empty until buildPlan first needs it
+    uint32_t keyLdsWords = 0; // the LDS footprint the key was computed for
+};
+
 struct Stats {
     uint64_t blocksRendered = 0;
     uint64_t plansBuilt = 0;
@@ -120,6 +128,11 @@ public:
     // numBlocks consecutive full blocks, device-resident output `outDev[block][nOut][blockSize]`
     // (may be null: render only) and optional device-resident input `inDev[block][nIn][blockSize]`
     int processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime);
+    // the same for HOST buffers, planar like Runtime::process (Runtime.h:51-57) over `numFrames` = any number of frames: the
+    // offline caller's block loop (offline-renderer/index.ts:87-133) in one call. Renders ceil(numFrames / blockSize) full
+    // blocks (a short tail of the inputs is zero-padded, the outputs receive numFrames frames). Launch sets are staged
+    // through pinned double buffers: the D2H of set k and the H2D of set k + 1 run on a copy stream while set k + 1 renders.
+    int processBlocksHost(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t numFrames, int64_t sampleTime);
     // render `numBlocks` blocks with a HIP event pair around every kernel launch; msOut[l] = mean
     // duration of launch level l (l < numLevels), msOut[numLevels] = epilogue. Returns levels + 1.
     int timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap);
@@ -171,9 +184,9 @@ private:
     std::unordered_map<std::string, std::unique_ptr<HostVTable>> hostTypes;
     std::vector<float> hostIn, hostOut;    // staging for call-out nodes
     // generated text per island-program signature: 256 voices (and every re-plan of a live graph) format their text once
-    std::unordered_map<uint64_t, std::shared_ptr<const std::string>> specTextCache;
-    std::unordered_map<const std::string*, std::string> specKeyCache;
-    uint32_t planEpoch = 0;                // PlanBuilder::traverse marks   // text object (owned by specTextCache) -> kernel cache key
+    // (the kernel cache key of a text lives NEXT TO the text, in the same shared object: nothing is keyed by an address)
+    std::unordered_map<uint64_t, std::shared_ptr<SpecText>> specTextCache;
+    uint32_t planEpoch = 0;                // PlanBuilder::traverse marks
     int64_t curBlockTime = 0;              // sample time of the block being enqueued (call-out nodes get it as userData)
     bool shouldRebuild = false;
     bool rebuildOwed = false;              // a commit failed to build its plan: the next commit retries even without ACTIVATE_ROOTS
@@ -187,6 +200,7 @@ private:
     std::vector<uint32_t> freeRecs;
     uint32_t nextRec = 0;
     std::vector<uint32_t> freshRecs;       // records to upload whole before the next block
+    std::vector<std::pair<uint32_t, uint32_t>> recClones;   // (channel-0 record, new channel record): device-side copy of the live state at the next flush
     std::vector<uint8_t> freshFlag;        // freshFlag[rec] != 0 while rec is in freshRecs
     std::vector<Patch> patches;            // param patches to apply before the next block
     Patch* hPatches = nullptr;             // pinned staging
@@ -204,6 +218,16 @@ private:
     float* hOut = nullptr; size_t hOutFloats = 0;     // pinned
     float* hIn = nullptr; size_t hInFloats = 0;       // pinned
     std::vector<void*> deferredFree;
+
+    // host-buffer launch sets (processBlocksHost): copy stream, pinned + device staging halves, hand-over events
+    hipStream_t ioStream = nullptr;
+    float* hStageOut[2] = {nullptr, nullptr}; float* hStageIn[2] = {nullptr, nullptr};
+    float* dStageOut[2] = {nullptr, nullptr}; float* dStageIn[2] = {nullptr, nullptr};
+    size_t stageOutFloats = 0, stageInFloats = 0;
+    hipEvent_t evIn[2] = {nullptr, nullptr}, evRendered[2] = {nullptr, nullptr}, evOut[2] = {nullptr, nullptr};
+    int ensureHostStaging(size_t outFloats, size_t inFloats);
+    // enqueue `numBlocks` blocks on `stream` (no synchronise at the end): the body of processBlocks
+    int enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime);
 
     std::shared_ptr<Plan> current, pending;
     uint32_t maxLdsConfigured = 0;
@@ -313,7 +337,7 @@ struct Plan {
     std::vector<uint32_t> specLists;           // island indices, shape-major
     std::vector<uint32_t> restIslands;         // per level: the levelIslands entries no shape covers (interpreter launch)
     std::vector<uint32_t> restOffsets;         // numLevels + 1
-    std::vector<std::shared_ptr<const std::string>> specText;   // per island: generated text (null = interpreter only), consumed by buildPlan
+    std::vector<std::shared_ptr<SpecText>> specText;   // per island: generated text (null = interpreter only), consumed by buildPlan
     const uint32_t* dSpecLists = nullptr;      // device copies (inside `dev`)
     const uint32_t* dRestIslands = nullptr;
     // captured launch sequence for multi-block offline rendering

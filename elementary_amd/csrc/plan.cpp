@@ -1180,8 +1180,9 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             mix(bs); mix((uint32_t)sp.hbmTab.size());
             auto it = e.specTextCache.find(h);
             if (it == e.specTextCache.end()) {
-                if (e.specTextCache.size() > 4096) { e.specTextCache.clear(); e.specKeyCache.clear(); }
-                it = e.specTextCache.emplace(h, std::make_shared<const std::string>(emitSpecSource(I, tasks, sp, stageTab, bs))).first;
+                auto txt = std::make_shared<SpecText>();
+                txt->text = emitSpecSource(I, tasks, sp, stageTab, bs);
+                it = e.specTextCache.emplace(h, std::move(txt)).first;
             }
             p.specText[ii] = it->second;
         }
@@ -1237,9 +1238,12 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     if (debugBuildDelayMs > 0) std::this_thread::sleep_for(std::chrono::milliseconds(debugBuildDelayMs));
     std::shared_ptr<Plan> plan;
     const uint32_t ldsLimit = 160u * 1024u - 1024u;
+    // the text cache is only ever trimmed BETWEEN builds (texts in use stay alive through the shared objects the plan holds)
+    if (specTextCache.size() > 4096) specTextCache.clear();
     for (uint32_t limit = 56; limit >= 4; limit /= 2) {
         PlanBuilder b(*this);
-        b.wantSpec = specialize != 0;
+        // a dry handle (no device) only generates / compiles kernels when asked to wait for them (cache warming, tests)
+        b.wantSpec = specialize != 0 && (!dry || specialize >= 2);
         plan = b.build(limit, (uint32_t)std::max(1, pipelineCopies));
         if (!plan) return nullptr;
         if (plan->maxLdsBytes <= ldsLimit) break;
@@ -1266,7 +1270,7 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
         p.restOffsets.assign(L + 1, 0);
         std::vector<uint8_t> covered(p.islands.size(), 0);
         for (size_t l = 0; l < L; ++l) {
-            std::map<const std::string*, std::vector<uint32_t>> byText;   // identical text = the same cached string object
+            std::map<SpecText*, std::vector<uint32_t>> byText;   // identical text = the same cached object (alive: p.specText holds it)
             for (uint32_t q = p.levelOffsets[l]; q < p.levelOffsets[l + 1]; ++q) {
                 const uint32_t isl = p.levelIslands[q] & 0xFFFFFFu;
                 if (isl < p.specText.size() && p.specText[isl] && !covered[isl]) byText[p.specText[isl].get()].push_back(isl);
@@ -1275,11 +1279,11 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
                 // background mode: a shape only one island has (a voice that is fading out next to its replacement, a
                 // one-off graph) is not worth a compile of its own: it renders through the interpreter kernel
                 const uint32_t ldsW = p.islands[kv.second[0]].ldsWords;
-                auto kc = specKeyCache.find(kv.first);
-                if (kc == specKeyCache.end()) kc = specKeyCache.emplace(kv.first, Jit::get().keyFor(*kv.first, ldsW)).first;
-                if (specialize == 1 && kv.second.size() < 2 && !Jit::get().knownKey(kc->second)) continue;
+                SpecText& tx = *kv.first;
+                if (tx.key.empty() || tx.keyLdsWords != ldsW) { tx.key = Jit::get().keyFor(tx.text, ldsW); tx.keyLdsWords = ldsW; }
+                if (specialize == 1 && kv.second.size() < 2 && !Jit::get().knownKey(tx.key)) continue;
                 Plan::SpecShape sh;
-                sh.entry = Jit::get().requestKey(kc->second, *kv.first, ldsW);
+                sh.entry = Jit::get().requestKey(tx.key, tx.text, ldsW);
                 sh.level = (uint32_t)l; sh.listBegin = (uint32_t)p.specLists.size(); sh.count = (uint32_t)kv.second.size();
                 for (uint32_t isl : kv.second) { p.specLists.push_back(isl); covered[isl] = 1; }
                 p.shapes.push_back(std::move(sh));

@@ -37,6 +37,9 @@ def load_library() -> C.CDLL:
         lib.elemhip_describe.restype = C.c_char_p
         lib.elemhip_process_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int64]
         lib.elemhip_process_blocks.restype = C.c_int
+        _fpp = C.POINTER(C.POINTER(C.c_float))
+        lib.elemhip_process_blocks_host.argtypes = [C.c_void_p, _fpp, C.c_size_t, _fpp, C.c_size_t, C.c_size_t, C.c_int64]
+        lib.elemhip_process_blocks_host.restype = C.c_int
         lib.elemhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         lib.elemhip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         lib.elemhip_get_stats.argtypes = [C.c_void_p, C.c_void_p]
@@ -93,6 +96,38 @@ class Runtime(CRuntime):
         if sample_time is None:
             self.sample_time += int(num_blocks) * self.block_size
 
+    def process_blocks_host(self, inputs, num_outputs: int, num_frames: Optional[int] = None, out=None,
+                            sample_time: Optional[int] = None):
+        """``elemhip_process_blocks_host``: the offline caller's whole block loop over HOST arrays.
+
+        ``inputs``: float32 ``[num_inputs, num_frames]`` (or None); returns / fills ``out``: float32
+        ``[num_outputs, num_frames]`` (C-contiguous rows). ``ceil(num_frames / block_size)`` full blocks are rendered.
+        """
+        import numpy as np
+        from ._cabi import _ptr_array
+        rows = []
+        if inputs is not None:
+            a = np.ascontiguousarray(inputs, dtype=np.float32)
+            if a.ndim == 1:
+                a = a[None, :]
+            rows = [a[i] for i in range(a.shape[0])]
+            if num_frames is None:
+                num_frames = a.shape[1]
+        if num_frames is None:
+            num_frames = out.shape[1]
+        if out is None:
+            out = np.empty((num_outputs, int(num_frames)), dtype=np.float32)
+        assert out.dtype == np.float32 and out.shape[0] == num_outputs and out.shape[1] >= num_frames and out.strides[1] == 4
+        st = self.sample_time if sample_time is None else int(sample_time)
+        rc = self._lib.elemhip_process_blocks_host(self._h, _ptr_array(rows), len(rows),
+                                                   _ptr_array([out[i] for i in range(num_outputs)]), num_outputs, int(num_frames), st)
+        if rc != 0:
+            raise ElemHipError(f"elemhip_process_blocks_host failed: {describe(rc)} (code {rc})")
+        if sample_time is None:
+            nb = (int(num_frames) + self.block_size - 1) // self.block_size
+            self.sample_time += nb * self.block_size
+        return out
+
     def set_stream(self, hip_stream: int) -> None:
         self._lib.elemhip_set_stream(self._h, C.c_void_p(hip_stream))
 
@@ -123,6 +158,9 @@ class Runtime(CRuntime):
         k = f(self._h, buf, 64, C.byref(sets), C.byref(blocks))
         if k <= 0:
             return {"level_ms": [], "epilogue_ms": 0.0, "launch_sets": int(sets.value), "blocks": int(blocks.value)}
+        if k > 64:      # more launch levels than the first buffer holds: ask again with room for all of them
+            buf = (C.c_double * k)()
+            k = min(k, f(self._h, buf, k, C.byref(sets), C.byref(blocks)))
         vals = [float(buf[i]) for i in range(k)]
         return {"level_ms": vals[:-1], "epilogue_ms": vals[-1], "launch_sets": int(sets.value), "blocks": int(blocks.value)}
 
@@ -131,7 +169,7 @@ class Runtime(CRuntime):
         f = self._lib.elemhip_spec_info
         f.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
         f.restype = C.c_int
-        src, log = C.create_string_buffer(1 << 20), C.create_string_buffer(1 << 18)
+        src, log = C.create_string_buffer(4 << 20), C.create_string_buffer(1 << 20)    # (C2 voice: 170 KB of text)
         state, isl = C.c_int(0), C.c_uint32(0)
         n = f(self._h, k, src, len(src), log, len(log), C.byref(state), C.byref(isl))
         return {"shapes": n, "source": src.value.decode(), "log": log.value.decode(errors="replace"), "state": state.value, "islands": isl.value}

@@ -31,6 +31,9 @@ def reduce_bus(bus: torch.Tensor, dst: int = 0, async_op: bool = False):
     """Sum the per-rank output buses [blocks, channels, frames] onto `dst` (in place on dst)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return None
+    if dist.get_backend() == "gloo" and bus.is_cuda:
+        # gloo has no reduce for device tensors (tests: two ranks sharing one GPU); its all-reduce leaves the same sum on dst
+        return dist.all_reduce(bus, op=dist.ReduceOp.SUM, async_op=async_op)
     return dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
@@ -56,6 +59,8 @@ def gather_outputs(local: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local.clone()
     world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        local = local.cpu()          # gloo gathers host tensors only (tests: two ranks sharing one GPU)
     counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device))
     most = int(max(int(c.item()) for c in counts))

@@ -4,7 +4,8 @@
 // engine.  The reference evaluates a JS bundle in QuickJS to obtain the batch; here the batch is
 // read from a JSON file (e.g. written by `python -m elementary_amd.tools dump c1 batch.json`).
 //
-//   hipcc -O2 -Iinclude examples/benchmark_main.cpp -Lelementary_amd -lelemhip -Wl,-rpath,$PWD/elementary_amd -o bench_cli
+//   g++ -std=c++17 -O2 -Iinclude examples/benchmark_main.cpp -Lelementary_amd -lelemhip -Wl,-rpath,$PWD/elementary_amd -o examples/bench_cli
+// (`make -C elementary_amd/csrc` builds it; tests/test_gpu_parity.py::test_cli_benchmark_host runs it on the GPU box)
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -16,7 +17,7 @@
 #include <elemhip/Runtime.hpp>
 
 int main(int argc, char** argv) {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s batch.json [blocks=10000] [sampleRate=44100]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s batch.json [blocks=10000] [sampleRate=44100] [last_block.f32]\n", argv[0]); return 2; }
     const size_t blocks = argc > 2 ? std::stoul(argv[2]) : 10000;
     const double sr = argc > 3 ? std::stod(argv[3]) : 44100.0;
     std::ifstream f(argv[1]);
@@ -38,6 +39,10 @@ int main(int argc, char** argv) {
         deltas.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());   // ns resolution, not truncated
     }
     const double sum = std::accumulate(deltas.begin(), deltas.end(), 0.0);
+    if (argc > 4) {   // the last rendered block (2 x 512 floats), for a checker
+        std::ofstream o(argv[4], std::ios::binary);
+        for (auto& c : scratch) o.write(reinterpret_cast<const char*>(c.data()), 512 * sizeof(float));
+    }
     std::printf("[Running float]:\nTotal run time: %.0fus (%.3fs)\nAverage iteration time: %.2fus\nDone\n", sum, sum / 1e6, sum / deltas.size());
     return 0;
 }

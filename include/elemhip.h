@@ -9,10 +9,21 @@
  *
  * Threading contract: one mutator thread (apply/add/gc) + one render thread (process*) per
  * handle; mutations become visible atomically at the next process call (reference: SPSC queue of
- * render sequences, Runtime.h:133,204,277-285).  Calls are serialised internally by a mutex.
+ * render sequences, Runtime.h:133,204,277-285).  Two locks inside the engine: a control lock
+ * serialises the mutator-side calls and owns the node table; a render lock guards what process*
+ * touches.  process* take the render lock only, and a commit releases it while it plans the new
+ * render sequence, so a render call never waits for a plan build; the mutator can
+ * wait for a render call in flight (at most one launch set), never the other way round.
  *
- * The engine has NO CPU fallback: every block is rendered by the HIP kernels of
- * elementary_amd/csrc/kernels.hip; elemhip_create fails (NULL) when no gfx950 device is usable.
+ * The engine has NO CPU fallback: every block is rendered by HIP kernels for gfx950 — the
+ * ahead-of-time island kernels (elementary_amd/csrc/kernels.hip, kernels_rt.hip: island.inc +
+ * island_ops.inc), the convolve kernels (conv.hip) and the per-island-shape kernels compiled at run
+ * time from island_spec.inc + generated text (codegen.cpp, jit.cpp); elemhip_create fails (NULL)
+ * when no gfx950 device is usable.
+ *
+ * Block size: the reference sizes its buffers to any blockSize (Runtime.h:44); this engine keeps a
+ * block's buffers in LDS slots of 512 frames, so elemhip_create rejects blockSize > 512 (code 102).
+ * Hosts with longer callbacks split them (elemhip_process_blocks_host does so itself).
  */
 #ifndef ELEMHIP_H
 #define ELEMHIP_H
@@ -71,6 +82,17 @@ int elemhip_process(elemhip_t*, const float* const* in, size_t nIn, float* const
  *   out_dev : device pointer [numBlocks][nOut][blockSize], or NULL to render without copying out */
 int elemhip_process_blocks(elemhip_t*, const float* in_dev, size_t nIn, float* out_dev, size_t nOut,
                            size_t numBlocks, int64_t sampleTime);
+
+/* The same block loop over HOST buffers: what OfflineRenderer.process(inputs, outputs) does with the reference engine
+ * (js/packages/offline-renderer/index.ts:87-133: ceil(numFrames / blockSize) FULL blocks, a short input tail zero-padded,
+ * every block copied to the caller's arrays) and what a host gets from calling Runtime::process (Runtime.h:51-57) in a loop.
+ *   in  : nIn planar channel arrays of numFrames frames each (caller-owned, pageable is fine), NULL when nIn == 0
+ *   out : nOut planar channel arrays of numFrames frames each; overwritten
+ * No HIP types cross the boundary. Launch sets of `batch_blocks` blocks go through pinned double buffers: the D2H of set k
+ * and the H2D of set k + 1 run on a copy stream while set k + 1 renders, so the samples land in host memory at the
+ * device-resident rate. `sampleTime` = sample time of the first frame (userData of the reference hosts). */
+int elemhip_process_blocks_host(elemhip_t*, const float* const* in, size_t nIn, float* const* out, size_t nOut,
+                                size_t numFrames, int64_t sampleTime);
 
 /* bool addSharedResource(name, unique_ptr<SharedResource>)       Runtime.h:83,461-465 (insert-only) */
 int    elemhip_add_shared_resource(elemhip_t*, const char* name, const float* const* channels, size_t nCh, size_t nSamples);

@@ -105,6 +105,16 @@ public:
         if (!userData) implicitTime += (int64_t)numSamples;
     }
 
+    // The offline caller's block loop (js/packages/offline-renderer/index.ts:87-133) in one call: planar HOST arrays of
+    // numFrames frames per channel, ceil(numFrames / blockSize) full blocks, outputs overwritten. Same userData rule as
+    // process(): a pointer to the int64_t sample time of the first frame, or null for the implicit running clock.
+    int processBlocks(const float** in, size_t nIn, float** out, size_t nOut, size_t numFrames, void* userData = nullptr) {
+        const int64_t t = userData ? *static_cast<int64_t*>(userData) : implicitTime;
+        const int rc = elemhip_process_blocks_host(h, in, nIn, out, nOut, numFrames, t);
+        if (!userData) implicitTime += (int64_t)numFrames;
+        return rc;
+    }
+
     // bool addSharedResource(name, unique_ptr<SharedResource>)         Runtime.h:83 — planar float channels
     bool addSharedResource(std::string const& name, const float* const* channels, size_t nCh, size_t nSamples) {
         return elemhip_add_shared_resource(h, name.c_str(), channels, nCh, nSamples) != 0;
@@ -145,6 +155,15 @@ public:
 
 #ifdef ELEMHIP_HAVE_ELEM_HEADERS
     // ---- the members that speak elem::js::Value (reference headers on the include path) ----
+    // bool addSharedResource(std::string const& name, std::unique_ptr<SharedResource> resource)   Runtime.h:83,461-465
+    // The engine copies the channels (the resource may die when this returns); insert-only like the reference.
+    bool addSharedResource(std::string const& name, std::unique_ptr<elem::SharedResource> resource) {
+        if (!resource) return false;
+        const size_t nCh = resource->numChannels(), n = resource->numSamples();
+        std::vector<const float*> chans(nCh ? nCh : 1, nullptr);
+        for (size_t c = 0; c < nCh; ++c) chans[c] = resource->getChannelData(c).data();
+        return addSharedResource(name, chans.data(), nCh, n);
+    }
     int applyInstructions(elem::js::Array const& batch) {                                 // Runtime.h:48,170-218
         std::string j;
         detail::toJSON(elem::js::Value(batch), j);

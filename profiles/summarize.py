@@ -71,8 +71,29 @@ if c3:
         w.writerows(rows)
     print("c3 kernel stats:", [(r.get("Name", "")[:40], r.get("Calls"), r.get("AverageNs")) for r in rows[:8]])
 
-out = {"command": "rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE} --output-format csv -- "
-                  "python bench.py --no-cpu-baseline --steps 20 --warmup 5 (the driver-shaped run: 25 launch sets of 64 blocks)",
+cmd_file = os.path.join(src, "prof_cmd.txt")
+bench_cmd = open(cmd_file).read().strip() if os.path.exists(cmd_file) else "python bench.py (command line not recorded)"
+out = {"command": "rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE} --output-format csv -- " + bench_cmd,
        "kernel_trace_per_dispatch": trace_summary, "pmc_per_dispatch": pmc}
 json.dump(out, open(os.path.join(dst, "c2_n1_rocprof_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
+
+# 4. HBM traffic of one launch set (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; gfx950 reports wide coalesced reads at
+#    half their size, hence 2 x FETCH_SIZE): the kernels dispatched once per launch set = as often as the batch epilogue
+sets = max([v for k, v in pmc.items() if k.startswith("elemhip_epilogue_batch_kernel") and k.endswith("_dispatches")] or [0])
+if sets:
+    fetch_kb = sum(pmc[k[:-len("dispatches")] + "KB_mean"] for k, v in pmc.items() if k.endswith("FETCH_SIZE_dispatches") and v == sets)
+    write_kb = sum(pmc[k[:-len("dispatches")] + "KB_mean"] for k, v in pmc.items() if k.endswith("WRITE_SIZE_dispatches") and v == sets)
+    blocks = 1024
+    for tok in bench_cmd.split():
+        pass
+    if "--batch-blocks" in bench_cmd:
+        blocks = int(bench_cmd.split("--batch-blocks")[1].split()[0])
+    per_set = 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0
+    traffic = {"c2_hbm_bytes_per_block": per_set / blocks, "c2_hbm_bytes_per_launch_set": per_set, "blocks_per_launch": blocks,
+               "fetch_bytes_corrected_x2": 2.0 * fetch_kb * 1024.0, "write_bytes": write_kb * 1024.0, "round": tag,
+               "launch_sets_profiled": sets,
+               "source": f"profiles/{tag}/c2_n1_rocprof_summary.json: 2 x FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE over the kernels "
+                         f"dispatched once per launch set, separate --pmc passes of `{bench_cmd}`"}
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    print("traffic:", traffic["c2_hbm_bytes_per_block"], "bytes per block")

@@ -6,8 +6,9 @@
 // getSharedResourceMapKeys(), processQueuedEvents(js::Value). Built by oracle/Makefile (it needs the reference headers)
 // into oracle/_ref/facade_host; tests/test_facade.py drives it.
 //
-//   facade_host <batch.json> <blocks> <nOut> <out.f32> [device=0] [sampleRate=44100]
+//   facade_host <batch.json> <blocks> <nOut> <out.f32> [device=0] [sampleRate=44100] [mode=process|blocks]
 // device -1: dry handle (host logic only; nothing is rendered, the output file holds zeros).
+// mode blocks: the whole render through ONE processBlocks call (elemhip_process_blocks_host: planar host arrays).
 #include <array>
 #include <atomic>
 #include <cmath>
@@ -25,6 +26,7 @@
 #include <vector>
 
 #include <elemhip/Runtime.hpp>   // pulls <elem/Value.h>, <elem/JSON.h>, <elem/GraphNode.h> from the reference tree
+#include <elem/AudioBufferResource.h>
 #include <SampleTime.h>
 #include <Metro.h>
 
@@ -37,6 +39,7 @@ int main(int argc, char** argv) {
     const size_t blocks = std::stoul(argv[2]), nOut = std::stoul(argv[3]);
     const int device = argc > 5 ? std::stoi(argv[5]) : 0;
     const double sr = argc > 6 ? std::stod(argv[6]) : 44100.0;
+    const bool blocksMode = argc > 7 && std::string(argv[7]) == "blocks";
     std::ifstream f(argv[1]);
     std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 
@@ -51,7 +54,8 @@ int main(int argc, char** argv) {
     std::vector<float> table(64);
     for (size_t i = 0; i < table.size(); ++i) table[i] = (float)i / 64.0f;
     const float* chans[1] = {table.data()};
-    const bool added = runtime.addSharedResource("ramp", chans, 1, table.size());
+    // Runtime::addSharedResource(name, std::unique_ptr<SharedResource>) as the reference's hosts call it (Runtime.h:83)
+    const bool added = runtime.addSharedResource("ramp", std::make_unique<elem::AudioBufferResource>(table.data(), table.size()));
     const bool addedTwice = runtime.addSharedResource("ramp", chans, 1, table.size());
 
     rc = runtime.applyInstructions(elem::js::parseJSON(text).getArray());          // cli/Benchmark.cpp:41
@@ -62,6 +66,15 @@ int main(int argc, char** argv) {
     for (auto& s : scratch) ptrs.push_back(s.data());
     std::ofstream out(argv[4], std::ios::binary);
     size_t events = 0;
+    if (blocksMode) {
+        std::vector<std::vector<float>> whole(nOut, std::vector<float>(blocks * 512));
+        std::vector<float*> wp;
+        for (auto& s : whole) wp.push_back(s.data());
+        int64_t t0 = 0;
+        if (device >= 0) { rc = runtime.processBlocks(nullptr, 0, wp.data(), nOut, blocks * 512, &t0); if (rc) { std::fprintf(stderr, "processBlocks: %d\n", rc); return 1; } }
+        for (size_t b = 0; b < blocks; ++b)
+            for (auto& s : whole) out.write(reinterpret_cast<const char*>(s.data() + b * 512), 512 * sizeof(float));
+    } else
     for (size_t b = 0; b < blocks; ++b) {
         int64_t t = (int64_t)(b * 512);
         if (device >= 0) runtime.process(nullptr, 0, ptrs.data(), nOut, 512, &t);    // userData = &sampleTime (wasm/Main.cpp:212)

@@ -35,11 +35,11 @@ def _batch(custom: bool):
     return sent[0]
 
 
-def _run(device: int, blocks: int, custom=True):
+def _run(device: int, blocks: int, custom=True, mode="process"):
     with tempfile.TemporaryDirectory() as d:
         bpath, opath = os.path.join(d, "batch.json"), os.path.join(d, "out.f32")
         open(bpath, "w").write(batch_to_json(_batch(custom)))
-        res = subprocess.run([HOST, bpath, str(blocks), "3", opath, str(device), "44100"], capture_output=True, text=True, timeout=300)
+        res = subprocess.run([HOST, bpath, str(blocks), "3", opath, str(device), "44100", mode], capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stderr
         out = np.fromfile(opath, dtype=np.float32).reshape(blocks, 3, 512)
         return json.loads(res.stdout.strip().splitlines()[-1]), out
@@ -61,11 +61,13 @@ def test_facade_host_logic_on_a_dry_handle():
 
 @needs_host
 @pytest.mark.gpu
-def test_facade_renders_with_reference_node_classes_as_callouts(gpu_required):
+@pytest.mark.parametrize("mode", ["process", "blocks"])
+def test_facade_renders_with_reference_node_classes_as_callouts(gpu_required, mode):
     """The reference's MetronomeNode / SampleTimeNode run on the CPU between GPU launch levels; the output must equal the
-    reference engine rendering the same graph with its natively registered metro / time."""
+    reference engine rendering the same graph with its natively registered metro / time. mode "blocks": the whole render
+    through one Runtime::processBlocks call (elemhip_process_blocks_host, planar host arrays)."""
     import oracle
-    info, got = _run(0, 40)
+    info, got = _run(0, 40, mode=mode)
     chk = oracle.RefRuntime(44100.0, 512)
     table = (np.arange(64, dtype=np.float32) / 64.0)[None, :]
     assert chk.add_shared_resource("ramp", table)

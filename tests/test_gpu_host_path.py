@@ -1,0 +1,161 @@
+"""The host-buffer offline entry point (elemhip_process_blocks_host: pinned double-buffered launch sets) and parity at
+EXACTLY the geometry bench.py times: the full 256-voice C2 graph, run-time specialised kernels, 1024- and 256-block
+launch sets, more than two full sets, every block against the reference engine. Tolerance 1e-6 absolute (x max|ref|
+when > 1)."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from elementary_amd import el, graphs
+from elementary_amd.reconciler import Renderer, batch_to_json
+from helpers import lcg_noise
+from cases import NODE_CASES, node_case_resources
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _checker(sr, bs):
+    import oracle
+    return oracle.RefRuntime(sr, bs) if oracle.have_ref() else oracle.PortRuntime(sr, bs)
+
+
+def _hip(sr, bs, **opts):
+    from elementary_amd.runtime import Runtime
+    rt = Runtime(sr, bs, device=0)
+    for k, v in opts.items():
+        rt.set_option(k, v)
+    return rt
+
+
+def _ref_planar(c, n_out, blocks, x=None, bs=512):
+    """[n_out, blocks * bs] from block-by-block process() calls (x: [n_in, frames] or None)."""
+    out = np.empty((n_out, blocks * bs), dtype=np.float32)
+    for k in range(blocks):
+        xin = None if x is None else x[:, k * bs:(k + 1) * bs]
+        out[:, k * bs:(k + 1) * bs] = c.process(xin, n_out, bs)
+    return out
+
+
+@pytest.mark.parametrize("batch", [1024, 256])
+def test_bench_geometry_full_c2(gpu_required, batch):
+    """What bench.py times, checked block by block: 256 voices, specialize = 2, `batch`-block launch sets, two full sets and
+    a ragged third (byte offsets beyond 2^31 in the 1024-block arena), delivered to host arrays."""
+    nb = 2 * batch + 77 if batch == 1024 else 2 * batch + 300
+    a, c = _hip(graphs.C2_SAMPLE_RATE, 512, specialize=2, batch_blocks=batch), _checker(graphs.C2_SAMPLE_RATE, 512)
+    roots = graphs.c2_graph()
+    assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
+    st = a.stats()
+    assert st["spec_shapes"] >= 1 and st["spec_islands"] >= 256, st
+    got = a.process_blocks_host(None, 2, nb * 512)
+    st = a.stats()
+    assert st["spec_launches"] >= 3 and st["batch_launches"] >= 3, st          # the specialised kernels rendered every set
+    info = a.spec_info(0)
+    assert info["state"] == 1, info["log"][:2000]
+    ref = _ref_planar(c, 2, nb)
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(got - ref).reshape(2, nb, 512).max(axis=(0, 2))                # per block
+    worst = int(err.argmax())
+    assert float(err.max()) <= TOL * scale, f"block {worst}: {err.max():.3e} (max|ref| {scale:.3f})"
+    # the tail of the last full set and the ragged set are as good as the head
+    assert float(err[batch - 8:batch + 8].max()) <= TOL * scale and float(err[-8:].max()) <= TOL * scale
+
+
+def test_host_path_equals_device_path(gpu_required):
+    """elemhip_process_blocks_host vs elemhip_process_blocks on two engines with the same options: bit-identical, for a
+    frame count that is not a multiple of the block size (the tail block is rendered whole, delivered cut)."""
+    import torch
+    frames = 300 * 512 + 137
+    nb = 301
+    a, b, c = (_hip(graphs.C2_SAMPLE_RATE, 512, specialize=2, batch_blocks=64), _hip(graphs.C2_SAMPLE_RATE, 512, specialize=2, batch_blocks=64),
+               _checker(graphs.C2_SAMPLE_RATE, 512))
+    roots = graphs.c2_graph(voices=48)
+    for rt in (a, b, c):
+        assert rt.render(*roots)["result"] == 0
+    got = a.process_blocks_host(None, 2, frames)
+    out = torch.zeros((nb, 2, 512), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    b.process_blocks(nb, 2, out_ptr=out.data_ptr())
+    dev = out.cpu().numpy().transpose(1, 0, 2).reshape(2, nb * 512)[:, :frames]
+    assert got.shape == (2, frames)
+    assert np.array_equal(got, dev)
+    ref = _ref_planar(c, 2, nb)[:, :frames]
+    assert float(np.abs(got - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
+    # the engine's clock moved by whole blocks: the next call continues the stream
+    more = a.process_blocks_host(None, 2, 5 * 512)
+    assert float(np.abs(more - _ref_planar(c, 2, 5)).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("name,batch", [("in_passthrough", 7), ("pole", 64), ("delay_long", 5), ("taps", 16), ("svf_modulated", 3)])
+def test_host_path_with_inputs(gpu_required, name, batch):
+    """Host inputs through the pinned H2D halves (several sets in flight), ragged frame count: the short input tail is
+    zero-padded like the offline caller does (offline-renderer/index.ts:95-103). `taps` renders block at a time inside."""
+    roots_fn, n_in = NODE_CASES[name]
+    frames = 41 * 512 + 200
+    nb = 42
+    a, c = _hip(44100.0, 512, batch_blocks=batch), _checker(44100.0, 512)
+    for rt in (a, c):
+        for rname, data in node_case_resources().items():
+            assert rt.add_shared_resource(rname, data)
+    roots = roots_fn()
+    assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
+    x = np.stack([lcg_noise(frames, 11 + ch, 0.5) for ch in range(n_in)])
+    xpad = np.zeros((n_in, nb * 512), dtype=np.float32)
+    xpad[:, :frames] = x
+    got = a.process_blocks_host(x, len(roots), frames)
+    ref = _ref_planar(c, len(roots), nb, xpad)[:, :frames]
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.isfinite(got).all()
+    assert float(np.abs(got - ref).max()) <= TOL * scale
+
+
+def test_offline_renderer_uses_the_host_batch_entry(gpu_required):
+    """OfflineRenderer.process (offline-renderer/index.ts:87-133) on the HIP engine goes through ONE
+    elemhip_process_blocks_host call when nobody listens for events; same samples as the reference engine block by block."""
+    from elementary_amd.offline import OfflineRenderer
+    from elementary_amd.runtime import Runtime
+    made = []
+
+    def hip(sr, bs):
+        made.append(Runtime(sr, bs, device=0))
+        return made[-1]
+    outs = []
+    for factory in (hip, _checker):
+        r = OfflineRenderer(factory)
+        r.initialize(num_input_channels=1, num_output_channels=2, sample_rate=48000, block_size=512)
+        r.render(el.mul(0.5, el.add(el.cycle(220.0), el.in_({"channel": 0}))), el.lowpass(900.0, 1.2, el.blepsaw(110.0)))
+        x = lcg_noise(70 * 512 + 33, 5, 0.25)
+        y = [np.zeros(70 * 512 + 33, dtype=np.float32) for _ in range(2)]
+        r.process([x], y)
+        outs.append(np.stack(y))
+    assert made[0].stats()["batch_launches"] >= 1            # launch sets, not 71 single-block calls
+    assert float(np.abs(outs[0] - outs[1]).max()) <= TOL
+
+
+def test_cli_benchmark_host(gpu_required):
+    """examples/benchmark_main.cpp (the timing protocol of cli/Benchmark.cpp:31-112 on the C++ facade), built by
+    `make -C elementary_amd/csrc`, run on the C1 graph: its last block equals the reference engine's."""
+    exe = os.path.join(ROOT, "examples", "bench_cli")
+    if not os.path.exists(exe):
+        res = subprocess.run(["make", "-C", os.path.join(ROOT, "elementary_amd", "csrc")], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+    sent = []
+    Renderer(lambda b: sent.append(b) or 0).render(*graphs.c1_graph())
+    c = _checker(graphs.C1_SAMPLE_RATE, 512)
+    assert c.apply_instructions(sent[0]) == 0
+    blocks = 300
+    with tempfile.TemporaryDirectory() as d:
+        bpath, opath = os.path.join(d, "batch.json"), os.path.join(d, "last.f32")
+        open(bpath, "w").write(batch_to_json(sent[0]))
+        res = subprocess.run([exe, bpath, str(blocks), str(graphs.C1_SAMPLE_RATE), opath], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        assert "Average iteration time" in res.stdout
+        got = np.fromfile(opath, dtype=np.float32).reshape(2, 512)
+    for _ in range(blocks):                                   # warm-up block + (blocks - 1) timed ones precede the last
+        c.process(None, 2, 512)
+    ref = c.process(None, 2, 512)
+    assert float(np.abs(got - ref).max()) <= TOL

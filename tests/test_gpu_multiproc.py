@@ -1,0 +1,49 @@
+"""The HIP engine under a process group, on the hardware the driver has: TWO ranks sharing ONE GPU (gloo backend, device
+tensors), running bench.py's own N > 1 code path — per-rank engines on their own streams, double-buffered device buses,
+asynchronous bus reduce with buffer reuse, the C4 output gather — and checked against the reference engine rendering
+the whole graph. (RCCL itself refuses two ranks on one device; the 8-GPU run is the driver's.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ELEMHIP_SPECIALIZE="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--shared-gpu",
+           "--no-cpu-baseline"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]          # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_ranks_one_gpu_bus_reduce(gpu_required, scaling):
+    out = _launch(["--steps", "3", "--warmup", "1", "--batch-blocks", "64", "--voices", "24", "--scaling", scaling,
+                   "--steps-per-call", "1", "--check"])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling
+    assert out["config"]["voices_total"] == (48 if scaling == "weak" else 24)
+    assert out["parity"]["ok"], out["parity"]
+    assert out["value"] > 0
+
+
+def test_two_ranks_one_gpu_c4_gather(gpu_required):
+    out = _launch(["--workload", "c4", "--instances", "6", "--steps", "2", "--warmup", "1", "--batch-blocks", "32"])
+    assert out["n_gpus"] == 2 and out["config"]["instances_total"] == 12
+    assert "gather" in out["config"]["collectives"]
+    assert out["value"] > 0
