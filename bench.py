@@ -36,7 +36,7 @@ HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/
 BLOCK = 512
 
 
-def cpu_baseline(target_seconds: float = 15.0, keep_blocks: int = 0):
+def cpu_baseline(target_seconds: float = 15.0, keep_blocks: int = 0, voices: int = 256):
     """Reference engine (oracle/_ref, -O3 -march=x86-64-v3 -ffp-contract=off) on ONE host core,
     same graph, cli/Benchmark.cpp protocol (warm-up then timed process() calls, steady clock).
     The first `keep_blocks` blocks of its output stream are kept (``head``, [2, frames]) for the parity check."""
@@ -52,7 +52,7 @@ def cpu_baseline(target_seconds: float = 15.0, keep_blocks: int = 0):
         kind = "port"
     else:
         return None
-    assert rt.render(*graphs.c2_graph())["result"] == 0
+    assert rt.render(*graphs.c2_graph(voices=voices))["result"] == 0
     head = []
 
     def step():
@@ -73,7 +73,7 @@ def cpu_baseline(target_seconds: float = 15.0, keep_blocks: int = 0):
     dt = time.perf_counter() - t0
     return {
         "value": BLOCK * m / dt, "unit": "samples/s", "cores": 1, "kind": kind,
-        "sample": f"{m} blocks of {BLOCK} frames of the same 4107-node C2 graph, 1 thread, after 58 warm-up blocks",
+        "sample": f"{m} blocks of {BLOCK} frames of the same {voices}-voice C2 graph, 1 thread, after 58 warm-up blocks",
         "ms_per_block": 1e3 * dt / m,
         "head": np.concatenate(head, axis=1) if head else None,
     }
@@ -96,7 +96,7 @@ def _mc_worker(args):
 
 
 def cpu_baseline_multicore(single_ms_per_block: float, target_seconds: float = 8.0, advance_blocks: int = 0, tail: int = 0,
-                           budget_seconds: float = 45.0):
+                           budget_seconds: float = 45.0, voices: int = 256):
     """SURVEY 8(d) fairness variant: the 256 voices partitioned over P reference Runtimes on P host cores
     (one process each, the host would sum P stereo buses per block: negligible, not timed).
     With `advance_blocks` the P engines render exactly that many blocks FROM TIME ZERO (when the estimate fits
@@ -108,10 +108,10 @@ def cpu_baseline_multicore(single_ms_per_block: float, target_seconds: float = 8
     if not oracle.have_ref():
         return None
     cores = max(1, min(32, (os.cpu_count() or 1)))
-    while 256 % cores:
+    while voices % cores:
         cores -= 1
-    per = 256 // cores
-    per_block_s = single_ms_per_block * 1e-3 * per / 256.0
+    per = voices // cores
+    per_block_s = single_ms_per_block * 1e-3 * per / float(voices)
     blocks = int(max(50, min(2000, target_seconds / per_block_s)))
     advanced = bool(advance_blocks) and advance_blocks * per_block_s * 1.3 <= budget_seconds
     if advanced:
@@ -121,7 +121,7 @@ def cpu_baseline_multicore(single_ms_per_block: float, target_seconds: float = 8
         res = pool.map(_mc_worker, [(k * per, per, blocks, tail if advanced else 0) for k in range(cores)])
     dt = max(r[0] for r in res)
     out = {"value": BLOCK * blocks / dt, "unit": "samples/s", "cores": cores, "kind": "reference",
-           "sample": f"{blocks} blocks from time zero, {cores} processes x {per} voices each (same 256-voice graph partitioned by voice)",
+           "sample": f"{blocks} blocks from time zero, {cores} processes x {per} voices each (same {voices}-voice graph partitioned by voice)",
            "ms_per_block": 1e3 * dt / blocks, "tail": None}
     if advanced and tail:
         acc = np.zeros_like(res[0][1])
@@ -437,8 +437,9 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1] (C2): 256-voice subtractive synth, 4107 nodes "
-                            "(2 blepsaw, train gate, pole envelope, svf lowpass, tanh per voice; 2 mix adds, 2 roots), "
+                "workload": ("BASELINE configs[1] (C2): 256-voice subtractive synth, 4107 nodes " if my_voices == 256 else
+                             f"C2 voice graph at {my_voices} voices ({my_voices * 16 + 11} nodes; BASELINE configs[1] is the 256-voice case) ")
+                            + "(2 blepsaw, train gate, pole envelope, svf lowpass, tanh per voice; 2 mix adds, 2 roots), "
                             "sr 48000, blockSize 512, 0 in / 2 out"
                             + (", per GPU" if args.scaling == "weak" and world > 1 else ""),
                 "step": f"one launch set = {B} consecutive 512-frame blocks of the whole graph ({B * BLOCK} output frames)",
@@ -455,6 +456,7 @@ def main() -> None:
                          + (", RCCL sum-reduce of the bus to rank 0 per call, rank 0 copies the reduced bus to pinned host memory" if world > 1 else "")),
                 "steps_per_call": args.steps if host_mode else spc,
                 "pipelined_blocks_in_flight": rt.describe_plan()["islands"][0]["copies"],
+                "voices_per_island": rt.describe_plan()["pack_k"],
                 "islands": stats["num_islands"], "launch_levels": stats["num_levels"], "max_lds_bytes": stats["max_lds_bytes"],
                 "island_kernels": ("run-time specialised per island shape (hiprtc, gfx950): %d shape(s) covering %d islands, %d launches; "
                                    "compile wait %.0f ms inside plan_build_ms (0 = on-disk cache hit)"
@@ -490,7 +492,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             head_blocks = min(B, (args.warmup if args.warmup else args.steps) * B) if host_mode else 0
-            cb = cpu_baseline(keep_blocks=head_blocks)
+            cb = cpu_baseline(keep_blocks=head_blocks, voices=my_voices)
             if cb:
                 head = cb.pop("head")
                 out["cpu_baseline"] = cb
@@ -502,7 +504,7 @@ def main() -> None:
                     parity["head"] = {"blocks": head.shape[1] // BLOCK, "max_abs_err": float(np.abs(got - head).max()), "scale": scale,
                                       "what": "blocks 0.. of the first launch set (%s) vs the reference engine on one core" % ("warm-up" if args.warmup else "timed")}
                 try:
-                    mc = cpu_baseline_multicore(cb["ms_per_block"], advance_blocks=(args.warmup + args.steps) * B if host_mode else 0, tail=64)
+                    mc = cpu_baseline_multicore(cb["ms_per_block"], advance_blocks=(args.warmup + args.steps) * B if host_mode else 0, tail=64, voices=my_voices)
                 except Exception as e:   # the fairness variant must never cost the headline line
                     mc = {"error": repr(e)}
                 if mc:

@@ -23,8 +23,14 @@ static std::string u(uint32_t v) {
 
 // Arena buffer indices differ between the instances of a shape: the text names position k of the island's arena table
 // (appended to its program blob, staged in LDS with it) instead of the index itself.
+// A stream-ring buffer keeps its kOpStream bit in the TEXT (a compile-time fact of the shape: which base pointer an access
+// uses folds away); the table entry holds the index inside the ring slice.
 static std::string arenaRef(const SpecProgram& sp, uint32_t abs, uint32_t tabWord) {
-    for (size_t k = 0; k < sp.hbmTab.size(); ++k) if (sp.hbmTab[k] == abs) return "UNI(ldsu(" + u(tabWord + (uint32_t)k) + "))";
+    for (size_t k = 0; k < sp.hbmTab.size(); ++k)
+        if (sp.hbmTab[k] == abs) {
+            const std::string e = "UNI(ldsu(" + u(tabWord + (uint32_t)k) + "))";
+            return (abs & kOpStream) ? "(kOpStream | (" + e + " & (kOpStream - 1u)))" : "(" + e + " & (kOpStream - 1u))";
+        }
     return "0u";
 }
 
@@ -92,17 +98,31 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
             uint32_t ntasks = 0;
             bool writes = false;     // the slot stores into arena buffers (read by other waves of the same launch, or by later launches)
             bool allDirect = true;   // ... and every task of it is a streamed recurrence (its block goes straight to the arena)
+            bool plainFamily = true; // ... whose whole state lives in registers across blocks (island_ops.inc chain_blocks callers)
             o << "template <> struct Slot<" << w << ", " << j << "> {\n";
             std::ostringstream body;
             for (uint32_t q = I.waveTask[w]; q < I.waveTask[w + 1]; ++q)
                 if (tasks[q].stage == st) {
                     body << "        spec_task<T" << q << ">(c, off);\n"; ++ntasks;
                     if (!sp.gdirect[q]) allDirect = false;
+                    switch (tasks[q].opcode) {
+                        case OP_PHASOR: case OP_SPHASOR: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_COUNTER: case OP_ACCUM: case OP_LATCH:
+                        case OP_MAXHOLD: case OP_PHASE: break;
+                        case OP_BLEPSAW: case OP_BLEPSQUARE: if (!(tasks[q].flags & 1u)) plainFamily = false; break;
+                        default: plainFamily = false;
+                    }
+                    // every member's operands: a broadcast cell, zero, or an arena stream (never an LDS buffer)
+                    for (uint32_t k = 0; k < tasks[q].count; ++k) {
+                        const Member& mm = members[tasks[q].first + k];
+                        if (mm.nin == kNone) { plainFamily = false; continue; }
+                        for (uint32_t j = 0; j < mm.nin; ++j) if ((operands[mm.opnd + j] & kOpKindMask) == kOpLds) plainFamily = false;
+                    }
                     for (uint32_t k = 0; k < tasks[q].count; ++k) if (members[tasks[q].first + k].outHbm != kNone) writes = true;
                 }
             o << "    static constexpr uint32_t stage = " << st << "u, prev = " << u(prev) << ", prevT = " << (prev == kNone ? 0u : stageTab[prev])
               << "u, ntasks = " << ntasks << "u;\n    static constexpr bool writesStreams = " << (writes ? "true" : "false")
-              << ", deferPublish = " << (writes && allDirect ? "true" : "false") << ";\n";
+              << ", deferPublish = " << (writes && allDirect ? "true" : "false")
+              << ", persistent = " << (stages.size() == 1 && ntasks == 1 && writes && allDirect && plainFamily && I.copies > 1 ? "true" : "false") << ";\n";
             o << "    static __device__ __forceinline__ void run(const Ctx& c, uint32_t off) {\n" << body.str() << "    }\n};\n";
         }
     }
@@ -114,8 +134,8 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
     for (uint32_t w = 0; w < kWaves; ++w) o << (w ? ", " : "") << waveSlots[w];
     o << "};\n};\n} // namespace gen\n";
     o << "extern \"C\" __global__ __launch_bounds__(512) void elemhip_spec_island(PlanView pv, uint32_t* recs, float* hbm, const Globals* g,\n"
-         "        const uint32_t* lcg, const uint32_t* islandList, uint32_t batch, uint32_t arenaFloats) {\n"
-         "    spec_island_main<gen::P>(pv, recs, hbm, g, lcg, islandList, batch, arenaFloats);\n}\n";
+         "        const uint32_t* lcg, const uint32_t* islandList, uint32_t batch, uint32_t arenaFloats, uint32_t streamBase, uint32_t streamSlice) {\n"
+         "    spec_island_main<gen::P>(pv, recs, hbm, g, lcg, islandList, batch, arenaFloats, streamBase, streamSlice);\n}\n";
     return o.str();
 }
 

@@ -42,6 +42,12 @@ enum : uint32_t {
     kOpZero  = 3u << 30,   // reads as 0.0f
     kOpKindMask = 3u << 30,
     kOpValMask  = ~(3u << 30),
+    // kOpHbm values (and Member::outHbm) with this bit name a buffer of the STREAM ring instead of the block's arena slice:
+    // buffers that only carry a block from one wave of an island to another (the blocks a float recurrence reads / writes in
+    // a specialised kernel). Block b of an island with D buffer sets uses ring slice b % D, so those lines are rewritten in
+    // L2 before they are ever evicted; only exports (read by another island, a later launch or the epilogue) need a slice
+    // per block of the launch set.
+    kOpStream   = 1u << 29,
 };
 
 // Opcodes. The first block mirrors the registry names of runtime/elem/DefaultNodeTypes.h:49-144
@@ -67,6 +73,10 @@ enum Op : uint16_t {
     OP_SHELF_COEF,    // shelf variant (a1,a2,a3,k,A)
     OP_SAW_SHAPE,     // blepsaw waveform from (phase, frequency), sample-parallel, one stage after the phase recurrence
     OP_SQUARE_SHAPE,  // blepsquare variant
+    OP_PHASE,         // constant-frequency phase recurrences of one stage merged into ONE lane-per-node task: `phasor` members
+                      // first (Task::s0 of them: step = f * (1 / sr), Core.h:85-136), then the phase halves of blepsaw / blepsquare
+                      // (inc = f / sr, Oscillators.h:60-66). Same loop for every lane — phase' = fract(phase + inc) — so a synth
+                      // voice's gate phasor and its two oscillators cost one recurrence wave instead of two.
     OP_COUNT_
 };
 

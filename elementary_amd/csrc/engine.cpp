@@ -101,6 +101,7 @@ Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), devi
     if (hipSetDevice(dev) != hipSuccess) { fail(kHipError); return; }
     if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { fail(kHipError); return; }
     ownStream = true;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) cuCount = cus; }
 
     recCapacity = 8192;
     if (hipMalloc(&dRecs, (size_t)recCapacity * kRecDwords * 4) != hipSuccess) { fail(kHipError); return; }
@@ -210,6 +211,20 @@ int Engine::ensureHbm(size_t buffers) {
     dHbm = nb; hbmBuffers = want;
     if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
     return kOk;
+}
+
+// Arena buffers a launch set of `blocks` blocks of plan `p` needs: one slice (host inputs + exports) per block, then the
+// stream ring of the specialised kernels, one slice per buffer set an island may keep in flight.
+size_t Engine::arenaBuffers(const Plan& p, size_t blocks) const {
+    return (size_t)p.numHbmBuffers * blocks + (size_t)p.numStreamBuffers * (streamRing ? (size_t)p.maxCopies : blocks);
+}
+// The recurrence loops of the specialised kernels address the whole arena through 32-bit buffer offsets with the top bit
+// reserved as "out of range": a launch set stays under 2 GB of arena (C2: 0.6 MB per block).
+size_t Engine::maxSetBlocks(const Plan& p) const {
+    const size_t cap = ((size_t)1 << 29) / (size_t)blockSize;                       // buffers of blockSize floats in 2 GB
+    if (!streamRing) return std::max<size_t>(1, (cap - 2) / std::max<uint32_t>(1u, p.numHbmBuffers + p.numStreamBuffers));
+    const size_t ring = (size_t)p.numStreamBuffers * p.maxCopies + 2;
+    return cap > ring ? std::max<size_t>(1, (cap - ring) / std::max<uint32_t>(1u, p.numHbmBuffers)) : 1;
 }
 
 int Engine::ensureOutRing(size_t floats) {
@@ -1154,6 +1169,12 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "mixer_split") { const int v = (int)value; mixerSplit = (v == 2 || v == 4 || v == 8) ? (uint32_t)v : 1u; planStale = true; return kOk; }
     if (key == "stateless_rows") { statelessRows = (uint32_t)std::max(1, std::min(64, (int)value)); return kOk; }   // gridDim.y of a multi-block launch: blocks that stateless islands render side by side
     if (key == "pipeline_copies") { pipelineCopies = std::max(1, std::min(6, (int)value)); planStale = true; return kOk; }   // next commit re-plans
+    if (key == "stream_ring") { streamRing = value != 0.0; return kOk; }   // 0: measurement only, needs kernels built with ELEMHIP_STREAM_PER_BLOCK
+    if (key == "pack_islands") { packIslands = std::max(0, std::min(16, (int)value)); planStale = true; return kOk; }   // next commit re-plans
+    if (key == "pack_max") { packMax = std::max(1, std::min(16, (int)value)); planStale = true; return kOk; }
+    if (key == "cu_count") { cuCount = std::max(1, (int)value); planStale = true; return kOk; }      // (dry handles / tests: the CU count the auto mode plans for)
+    if (key == "chain_lds_out") { chainLdsOut = value != 0.0; planStale = true; return kOk; }
+    if (key == "merge_phases") { mergePhases = value != 0.0; planStale = true; return kOk; }   // next commit re-plans
     if (key == "specialize") { specialize = std::max(0, std::min(2, (int)value)); planStale = true; return kOk; }   // next commit re-plans
     if (key == "profile_launches") {
         profileLaunches = value != 0.0;
@@ -1255,7 +1276,7 @@ int Engine::swapInPending() {   // Runtime.h:277-285: newest sequence wins
         st.numHbmBuffers = current->numHbmBuffers;
     }
     if (!current) return kOk;
-    int rc = ensureHbm(current->numHbmBuffers);
+    int rc = ensureHbm(arenaBuffers(*current, 1));
     if (rc != kOk) return rc;
     if (current->maxLdsBytes > maxLdsConfigured) {
         HIP_OK(configure_kernels(current->maxLdsBytes));
@@ -1415,10 +1436,10 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
     for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -kHipError;
     std::vector<double> acc(L + 2, 0.0);
     // timeBatch > 1: time the multi-block launches elemhip_process_blocks issues (msOut = per LAUNCH of `batch` blocks)
-    const uint32_t batch = (timeBatch > 1 && p.convs.empty() && batchEligible(p, nOut)) ? (uint32_t)timeBatch : 1u;
+    const uint32_t batch = (timeBatch > 1 && p.convs.empty() && batchEligible(p, nOut)) ? (uint32_t)std::min<size_t>((size_t)timeBatch, maxSetBlocks(p)) : 1u;
     const uint32_t arenaFloats = batch > 1 ? p.numHbmBuffers * (uint32_t)blockSize : 0u;
     if (batch > 1) {
-        rc = ensureHbm((size_t)p.numHbmBuffers * batch); if (rc != kOk) return -rc;
+        rc = ensureHbm(arenaBuffers(p, batch)); if (rc != kOk) return -rc;
         rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize * batch); if (rc != kOk) return -rc;
     }
     lastTimeBatch = batch;
@@ -1476,10 +1497,10 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
     rc = flushPending();
     if (rc != kOk) return rc;
     const uint64_t tp = (uint64_t)reinterpret_cast<uintptr_t>(dTrace);
-    const uint32_t batch = (timeBatch > 1 && p.convs.empty() && batchEligible(p, nOut)) ? (uint32_t)timeBatch : 1u;
+    const uint32_t batch = (timeBatch > 1 && p.convs.empty() && batchEligible(p, nOut)) ? (uint32_t)std::min<size_t>((size_t)timeBatch, maxSetBlocks(p)) : 1u;
     const uint32_t arenaFloats = batch > 1 ? p.numHbmBuffers * (uint32_t)blockSize : 0u;
     if (batch > 1) {
-        rc = ensureHbm((size_t)p.numHbmBuffers * batch); if (rc != kOk) return rc;
+        rc = ensureHbm(arenaBuffers(p, batch)); if (rc != kOk) return rc;
         rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize * batch); if (rc != kOk) return rc;
     }
     for (size_t l = 0; l < L; ++l) {
@@ -1613,8 +1634,9 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         PlanView pv = p.view;
         uint32_t* recs = dRecs; float* hbm = dHbm; const Globals* g = dGlobals; const uint32_t* lcg = dLcg;
         const uint32_t* list = p.dSpecLists + f.second->listBegin;
-        uint32_t bt = batch, af = arenaFloats;
-        void* args[] = {&pv, &recs, &hbm, &g, &lcg, &list, &bt, &af};
+        // the stream ring sits behind the `batch` block slices of this launch set
+        uint32_t bt = batch, af = arenaFloats, sb = batch * arenaFloats, ss = p.numStreamBuffers * (uint32_t)blockSize;
+        void* args[] = {&pv, &recs, &hbm, &g, &lcg, &list, &bt, &af, &sb, &ss};
         HIP_WARN(hipModuleLaunchKernel(f.first, f.second->count, 1, 1, kThreads, 1, 1, 0, st_, args, nullptr));
         st.specLaunches++;
     }
@@ -1688,8 +1710,9 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
     while (done < numBlocks) {
         if (batchBlocks > 1 && numBlocks - done > 1 && batchEligible(p, nOut)) {
             // ---- multi-block launches: one kernel per level renders `chunk` blocks (kernels.hip) ----
-            const size_t chunk = std::min((size_t)batchBlocks, numBlocks - done);
-            rc = ensureHbm((size_t)p.numHbmBuffers * (size_t)batchBlocks);
+            const size_t setCap = std::min((size_t)batchBlocks, maxSetBlocks(p));
+            const size_t chunk = std::min(setCap, numBlocks - done);
+            rc = ensureHbm(arenaBuffers(p, setCap));
             if (rc != kOk) return rc;
             rc = ensureOutRing(std::max<size_t>(nOut, 1) * bs * (size_t)batchBlocks);
             if (rc != kOk) return rc;

@@ -238,6 +238,12 @@ private:
     bool convAligned = true;               // every process call so far rendered whole 512-frame blocks (conv.hip batch path)
     float* dConvScratch = nullptr; size_t convScratchFloats = 0;
     uint32_t mixerSplit = 2;               // workgroups a mixer island is cut into (plan.cpp; each renders blockSize / split frames on 8 / split waves)
+    bool streamRing = true;                // stream buffers of the specialised kernels live in a ring of `copies` slices (0: one slice per block; measurement)
+    int  packIslands = 0;                  // option "pack_islands": same-shape islands merged into one workgroup (0 auto: when a launch level has more
+                                           // stateful islands than the device has CUs; 1 never; K: K per island)
+    int  packMax = 2, cuCount = 256;       // auto mode: at most packMax per island (measured on C2: 2 per island pays, 3 leaves two buffer sets and loses); CUs of the device
+    bool chainLdsOut = false;              // option "chain_lds_out" (experiment): streamed recurrences write their block to LDS, only their operands come through the arena
+    bool mergePhases = true;               // option "merge_phases": constant-frequency phasors and oscillator phases of a stage share one recurrence task (OP_PHASE)
     uint32_t statelessRows = 64;           // gridDim.y of a multi-block launch: blocks that stateless islands render side by side
     int  timeBatch = 1;
     int  specialize = 1;                   // 0: interpreter kernels only; 1: specialised kernels compiled in the background and used
@@ -272,6 +278,8 @@ private:
     int  flushPending();                   // fresh records + patches -> device (stream-ordered)
     void freeDeferred();
     int  ensureHbm(size_t buffers);
+    size_t arenaBuffers(const Plan& p, size_t blocks) const;
+    size_t maxSetBlocks(const Plan& p) const;
     int  ensureOutRing(size_t floats);
     int  swapInPending();
     void enqueueBlock(const Plan& p);
@@ -313,7 +321,10 @@ struct Plan {
     std::vector<int32_t> rootIds;          // same order as `roots`
     std::vector<uint32_t> islandLevel;     // launch level of each island
     std::set<int32_t> nodeIds;             // every node the render sequence references (gc)
-    uint32_t numHbmBuffers = kMaxHostIn;
+    uint32_t numHbmBuffers = kMaxHostIn;       // per block of a launch set: host inputs + exports
+    uint32_t numStreamBuffers = 0;             // per slice of the stream ring (specialised kernels; device.h kOpStream)
+    uint32_t maxCopies = 1;                    // most buffer sets an island of the plan keeps in flight = slices of the stream ring
+    uint32_t packK = 1;                        // islands merged per workgroup by the lane-packing step (1 = none were)
     uint32_t maxLdsBytes = 0;
     // device copies
     DevBuf dev;                            // one allocation holding all tables

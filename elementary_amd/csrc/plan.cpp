@@ -38,7 +38,7 @@ Kind kindOf(uint16_t op) {
         case OP_HOST: return K_HOST;       // always an island of its own, rendered on the CPU between launch levels
         case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD:
         case OP_ONCE: case OP_SEQ: case OP_SEQ2: case OP_SAMPLE: case OP_MCSAMPLE: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
-        case OP_SVFSHELF: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
+        case OP_SVFSHELF: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE: case OP_PHASE:
             return K_CHAIN;
         default: return K_PAR;
     }
@@ -84,7 +84,7 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
                            const std::vector<uint32_t>& stageTab, uint32_t blockSize);   // codegen.cpp
 namespace {
 uint32_t leafArityOfOp(uint16_t op) {
-    if (op == OP_SAW_SHAPE || op == OP_SQUARE_SHAPE) return 1;
+    if (op == OP_SAW_SHAPE || op == OP_SQUARE_SHAPE || op == OP_PHASE) return 1;
     if (op == OP_SVF_COEF) return leafArity(OP_SVF);
     if (op == OP_SHELF_COEF) return leafArity(OP_SVFSHELF);
     return leafArity(op);
@@ -97,7 +97,7 @@ uint32_t taskCost(uint16_t op, uint32_t units, uint32_t count) {
     if (op == OP_SVF_COEF || op == OP_SHELF_COEF) return gap + 2300u * units * count;      // double tan + divides per frame
     if (op == OP_SVF || op == OP_SVFSHELF || op == OP_MM1P) return gap + 9500u * count;    // wave scan
     if (op == OP_SAW_SHAPE || op == OP_SQUARE_SHAPE) return gap + 500u * units * count;
-    if (op == OP_BLEPSAW || op == OP_BLEPSQUARE) return gap + 12500u;                       // phase recurrence only
+    if (op == OP_BLEPSAW || op == OP_BLEPSQUARE || op == OP_PHASE) return gap + 12500u;     // phase recurrence only
     if (op == OP_BLEPTRIANGLE) return gap + 30000u;
     if (op == OP_POLE || op == OP_ENV || op == OP_BIQUAD) return gap + 15300u;
     if (kindOf(op) == K_CHAIN) return gap + 12000u;
@@ -182,6 +182,11 @@ struct PlanBuilder {
 
     bool splitCoefStage = false;
     bool wantSpec = false;                  // also write the specialised-kernel text of every pipelined island
+    uint32_t packK = 1;                     // merge up to this many same-shape islands of a launch level into one (lane-packing); 0 = as many as it takes
+    uint32_t packMax = 2, cuCount = 256;    // ... to bring the fullest launch level down to the CU count, at most packMax
+    uint32_t packedIslands = 0;             // out: islands that disappeared into another
+    uint32_t minPackedCopies = 0;           // out: fewest buffer sets of an island that carries more than one original island
+    uint32_t statefulIslandsMax = 0;        // out: most stateful islands of one launch level (before packing)
     std::shared_ptr<Plan> build(uint32_t maxIslandNodes, uint32_t maxCopies);
 };
 
@@ -414,6 +419,75 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             for (int o : out[i]) { ib[o].level = std::max(ib[o].level, ib[i].level + 1); if (--indeg[o] == 0) q.push_back(o); }
         }
         if (seen != ib.size()) { std::fprintf(stderr, "[elemhip] plan: island graph is cyclic\n"); return nullptr; }
+    }
+    // ---- 2b. lane-packing of isomorphic islands -----------------------------------------------------------------------
+    // A stateful island is one workgroup, and its float recurrences run one NODE PER LANE: a voice's envelope pole keeps a
+    // whole wavefront busy with one lane. When a launch level has more such islands than the chip has CUs (512 voices, 1024
+    // render jobs) the islands of one shape are merged K at a time: the recurrence tasks of the merged island carry K lanes at
+    // the price of one (same-opcode chain members of a stage share a task anyway), only the sample-parallel work grows K-fold.
+    // Islands of one launch level never depend on each other, so any such merge keeps the island graph acyclic. Only islands
+    // of ONE root sequence are merged: an island renders while its root runs (GraphRenderSequence.h:214-219), and two roots
+    // may stop at different blocks — independent render jobs with a root each (C4) stay one per workgroup.
+    packedIslands = 0;
+    std::vector<uint32_t> packCount(ib.size(), 1u);        // original islands inside each island
+    {   // how many stateful islands does the fullest launch level hold?  packK = 0: as many per island as it takes to fit the CUs
+        std::map<int, uint32_t> perLevel;
+        for (size_t i = 0; i < ib.size(); ++i) {
+            bool stateful = false;
+            for (int k : ib[i].nodes) if (ni[k].kind != K_PAR || ni[k].n->op == OP_TAPIN || ni[k].n->op == OP_TAPOUT) stateful = true;
+            if (stateful) perLevel[ib[i].level]++;
+        }
+        statefulIslandsMax = 0;
+        for (auto& kv : perLevel) statefulIslandsMax = std::max(statefulIslandsMax, kv.second);
+        if (packK == 0) packK = std::max(1u, std::min(packMax, (statefulIslandsMax + cuCount - 1u) / std::max(1u, cuCount)));
+    }
+    if (packK > 1) {
+        struct Key { int level, seq; uint64_t shape; bool operator<(const Key& o) const { return level != o.level ? level < o.level : seq != o.seq ? seq < o.seq : shape < o.shape; } };
+        std::map<Key, std::vector<int>> groups;
+        for (size_t i = 0; i < ib.size(); ++i) {
+            bool stateful = false, sealed = false;
+            uint64_t h = 1469598103934665603ull;
+            for (int k : ib[i].nodes) {
+                const NI& x = ni[k];
+                if (x.kind == K_CONV || x.kind == K_HOST) sealed = true;
+                if (x.kind != K_PAR || x.n->op == OP_TAPIN || x.n->op == OP_TAPOUT) stateful = true;
+                h ^= (uint64_t)x.n->op | ((uint64_t)x.n->inlets.size() << 16); h *= 1099511628211ull;
+            }
+            if (sealed || !stateful) continue;
+            groups[Key{ib[i].level, ib[i].seq, h}].push_back((int)i);
+        }
+        std::vector<int> mergedInto(ib.size(), -1);
+        for (auto& kv : groups) {
+            std::vector<int>& g = kv.second;
+            for (size_t q = 0; q + 1 < g.size(); q += packK) {
+                const int head = g[q];
+                for (size_t j = q + 1; j < std::min(g.size(), q + (size_t)packK); ++j) {
+                    const int from = g[j];
+                    ib[head].nodes.insert(ib[head].nodes.end(), ib[from].nodes.begin(), ib[from].nodes.end());
+                    for (int d : ib[from].deps) if (std::find(ib[head].deps.begin(), ib[head].deps.end(), d) == ib[head].deps.end()) ib[head].deps.push_back(d);
+                    ib[from].nodes.clear(); ib[from].deps.clear();
+                    mergedInto[from] = head;
+                    packCount[head] += 1u;
+                    ++packedIslands;
+                }
+                std::sort(ib[head].nodes.begin(), ib[head].nodes.end());          // NI indices are render-order positions
+            }
+        }
+        if (packedIslands) {   // compact the island list, renumber
+            std::vector<int> newIdx(ib.size(), -1);
+            std::vector<IslandBuild> nb;
+            std::vector<uint32_t> pc;
+            for (size_t i = 0; i < ib.size(); ++i) if (mergedInto[i] < 0) { newIdx[i] = (int)nb.size(); nb.push_back(std::move(ib[i])); pc.push_back(packCount[i]); }
+            packCount.swap(pc);
+            for (size_t i = 0; i < newIdx.size(); ++i) if (mergedInto[i] >= 0) newIdx[i] = newIdx[mergedInto[i]];
+            for (IslandBuild& B : nb) {
+                for (int& d : B.deps) d = newIdx[d];
+                std::sort(B.deps.begin(), B.deps.end());
+                B.deps.erase(std::unique(B.deps.begin(), B.deps.end()), B.deps.end());
+            }
+            for (NI& x : ni) if (x.kind != K_CONST && x.island >= 0) x.island = newIdx[x.island];
+            ib.swap(nb);
+        }
     }
     int numLevels = 0;
     for (auto& i : ib) numLevels = std::max(numLevels, i.level + 1);
@@ -717,6 +791,20 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             }
             emitRanges(OP_COPY, 0, first, (uint32_t)imports.size(), {0, 1, 2, 3});
         }
+        auto constMaskOf = [&](const NI& x) -> uint32_t {
+            uint32_t mask = 0;
+            for (size_t q = 0; q < x.n->inlets.size() && q < 8; ++q) {
+                auto it = idx.find(K(x.n->inlets[q].source, x.n->inlets[q].channel));
+                if (it == idx.end()) { mask |= 1u << q; continue; }   // zero operand
+                if (ni[it->second].kind == K_CONST) mask |= 1u << q;
+            }
+            return mask;
+        };
+        // constant-frequency phasors and blepsaw / blepsquare phase recurrences of one stage share ONE task (device.h OP_PHASE)
+        auto phaseMergeable = [&](const NI& x) {
+            const uint16_t op = x.n->op;
+            return e.mergePhases && (op == OP_PHASOR || blepSplit(op)) && !x.n->inlets.empty() && (constMaskOf(x) & 1u);
+        };
         uint32_t waveLoad[kWaves] = {};   // estimated cycles per block
         // waves that would stay empty with one wave per (stage, task group): a small island hands them to its heavy
         // sample-parallel stages (a finer split), where a big one needs every wave for a slot of its own
@@ -727,7 +815,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             for (int k : B.nodes) {
                 const NI& x = ni[k];
                 const uint16_t op = x.n->op;
-                if (x.kind == K_CHAIN) groups.insert({x.level - (blepSplit(op) ? 1 : 0), 0x10000u | op});
+                if (x.kind == K_CHAIN) groups.insert({x.level - (blepSplit(op) ? 1 : 0), 0x10000u | (phaseMergeable(x) ? (uint32_t)OP_PHASE : (uint32_t)op)});
                 else if (x.kind == K_SINGLE) groups.insert({x.level, 0x20000u | (uint32_t)k});
                 else if (x.kind == K_PAR) parTotal[x.level] += taskCost(op, 8, 1);
                 if (blepSplit(op)) parTotal[x.level] += taskCost(op == OP_BLEPSAW ? OP_SAW_SHAPE : OP_SQUARE_SHAPE, 8, 1);
@@ -742,22 +830,18 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             std::map<uint32_t, std::vector<int>> chain;   // key: opcode | constMask << 16
             std::map<uint16_t, std::vector<int>> single;
             std::map<std::pair<int, uint16_t>, std::vector<int>> par;   // (fusion depth, opcode): emitted in dependency order
-            auto constMaskOf = [&](NI& x) -> uint32_t {
-                uint32_t mask = 0;
-                for (size_t q = 0; q < x.n->inlets.size() && q < 8; ++q) {
-                    auto it = idx.find(K(x.n->inlets[q].source, x.n->inlets[q].channel));
-                    if (it == idx.end()) { mask |= 1u << q; continue; }   // zero operand
-                    if (ni[it->second].kind == K_CONST) mask |= 1u << q;
-                }
-                return mask;
-            };
+            std::vector<int> phasePhasors, phaseOscs;          // members of this stage's OP_PHASE task
             for (int k : B.nodes) {
                 NI& x = ni[k];
                 if (x.level == stage + 1 && x.n->op == OP_SVF) par[{1 << 20, OP_SVF_COEF}].push_back(k);
                 if (x.level == stage + 1 && x.n->op == OP_SVFSHELF) par[{1 << 20, OP_SHELF_COEF}].push_back(k);
-                if (x.level == stage + 1 && blepSplit(x.n->op)) chain[(uint32_t)x.n->op | (constMaskOf(x) << 16)].push_back(k);
+                if (x.level == stage + 1 && blepSplit(x.n->op)) {
+                    if (phaseMergeable(x)) phaseOscs.push_back(k);
+                    else chain[(uint32_t)x.n->op | (constMaskOf(x) << 16)].push_back(k);
+                }
                 if (x.level != stage) continue;
                 if (blepSplit(x.n->op)) par[{0, x.n->op == OP_BLEPSAW ? OP_SAW_SHAPE : OP_SQUARE_SHAPE}].push_back(k);
+                else if (x.n->op == OP_PHASOR && phaseMergeable(x)) phasePhasors.push_back(k);
                 else if (x.kind == K_CHAIN) chain[(uint32_t)x.n->op | (constMaskOf(x) << 16)].push_back(k);
                 else if (x.kind == K_SINGLE) single[x.n->op].push_back(k);
                 else par[{x.sub, x.n->op}].push_back(k);
@@ -776,10 +860,26 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                     if (busy[w] < busy[b] || (busy[w] == busy[b] && waveLoad[w] < waveLoad[b])) b = w;
                 return b;
             };
+            {   // OP_PHASE: up to 64 lanes per task, phasors in front (Task::s0 = how many)
+                size_t pi = 0, oi = 0;
+                while (pi < phasePhasors.size() || oi < phaseOscs.size()) {
+                    const uint32_t first = (uint32_t)members.size();
+                    uint32_t np = 0, cnt = 0;
+                    for (; pi < phasePhasors.size() && cnt < 64; ++pi, ++np, ++cnt) members.push_back(makeMember(ni[phasePhasors[pi]]));
+                    for (; oi < phaseOscs.size() && cnt < 64; ++oi, ++cnt) members.push_back(makeMember(ni[phaseOscs[oi]]));
+                    const int w = pickWave();
+                    busy[w] += 1; waveLoad[w] += taskCost(OP_PHASE, 8, 1);
+                    tasks.push_back(Task{OP_PHASE, (uint8_t)stage, 1u, (uint16_t)np, (uint16_t)bs, first, cnt, 0, 0, 0, 0, 0});
+                    taskWave.push_back(w);
+                }
+            }
             for (auto& kv : chain) {
                 const uint16_t cop = (uint16_t)(kv.first & 0xFFFFu);
-                for (size_t off = 0; off < kv.second.size(); off += 64) {
-                    const uint32_t cnt = (uint32_t)std::min<size_t>(64, kv.second.size() - off);
+                // the double-state filters are wave scans, one node after the other: every node is a task of its own, so that the
+                // nodes of a stage (a packed island has one per voice) spread over the waves instead of queueing on one
+                const size_t lanes = (cop == OP_SVF || cop == OP_SVFSHELF || cop == OP_MM1P) ? 1 : 64;
+                for (size_t off = 0; off < kv.second.size(); off += lanes) {
+                    const uint32_t cnt = (uint32_t)std::min<size_t>(lanes, kv.second.size() - off);
                     const uint32_t first = (uint32_t)members.size();
                     for (uint32_t c = 0; c < cnt; ++c) members.push_back(makeMember(ni[kv.second[off + c]]));
                     const int w = pickWave();
@@ -920,13 +1020,13 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 Task& t = tasks[I.waveTask[w]];
                 const uint16_t op = t.opcode;
                 const bool plain = op == OP_PHASOR || op == OP_SPHASOR || op == OP_POLE || op == OP_ENV || op == OP_BIQUAD || op == OP_COUNTER ||
-                                   op == OP_ACCUM || op == OP_LATCH || op == OP_MAXHOLD;
+                                   op == OP_ACCUM || op == OP_LATCH || op == OP_MAXHOLD || op == OP_PHASE;
                 const bool osc = blepSplit(op) && (t.flags & 1u);            // constant frequency: no per-block pre-pass
                 if (!plain && !osc) continue;
                 bool ok = (t.flags & 0xC0u) == 0u;
                 for (uint32_t k = 0; k < t.count && ok; ++k) {
                     const Member& m = members[t.first + k];
-                    if (m.outHbm != kNone || m.outLds == kNone || m.nin == kNone || m.nin < leafArity(op)) ok = false;
+                    if (m.outHbm != kNone || m.outLds == kNone || m.nin == kNone || m.nin < leafArityOfOp(op)) ok = false;
                 }
                 if (ok) t.flags |= (uint8_t)kTaskOwnsWave;
             }
@@ -1041,14 +1141,14 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 if (ni[k].exported) return ni[k].hbm;
                 auto it = streamOf.find(k);
                 if (it != streamOf.end()) return it->second;
-                const uint32_t b = p.numHbmBuffers++;
+                const uint32_t b = kOpStream | p.numStreamBuffers++;     // a buffer of the stream ring (device.h kOpStream)
                 streamOf.emplace(k, b);
                 return b;
             };
             auto streamFamily = [&](const Task& t) {
                 switch (t.opcode) {
                     case OP_PHASOR: case OP_SPHASOR: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_COUNTER: case OP_ACCUM:
-                    case OP_LATCH: case OP_MAXHOLD: return true;
+                    case OP_LATCH: case OP_MAXHOLD: case OP_PHASE: return true;
                     case OP_BLEPSAW: case OP_BLEPSQUARE: return (t.flags & 1u) != 0u;   // constant frequency: no in-place pre-pass
                     default: return false;
                 }
@@ -1061,18 +1161,21 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 bool ok = true;
                 for (uint32_t k = 0; k < t.count; ++k) {
                     const Member& m = members[t.first + k];
-                    if (m.nin == kNone || m.nin < leafArity(t.opcode) || memberNode[t.first + k] < 0) ok = false;
+                    if (m.nin == kNone || m.nin < leafArityOfOp(t.opcode) || memberNode[t.first + k] < 0) ok = false;
                 }
                 if (!ok) continue;
-                sp.gdirect[q] = 1;
+                // (option "chain_lds_out": only the operands stream through the arena; the output block stays in its LDS slot)
+                sp.gdirect[q] = e.chainLdsOut ? 0 : 1;
                 for (uint32_t k = 0; k < t.count; ++k) {
                     const uint32_t mi = t.first + k;
                     const int x = memberNode[mi];
-                    const bool osc = blepSplit(t.opcode);
-                    uint32_t b;
-                    if (osc) { b = p.numHbmBuffers++; phaseStream.emplace(x, b); }
-                    else { b = stream(x); streamed.insert(x); }
-                    sp.members[mi].outHbm = b;
+                    const bool osc = blepSplit(ni[x].n->op);            // (an OP_PHASE task carries both kinds)
+                    if (!e.chainLdsOut) {
+                        uint32_t b;
+                        if (osc) { b = kOpStream | p.numStreamBuffers++; phaseStream.emplace(x, b); }
+                        else { b = stream(x); streamed.insert(x); }
+                        sp.members[mi].outHbm = b;
+                    }
                     for (uint32_t j = 0; j < members[mi].nin; ++j) {
                         const uint32_t oi = members[mi].opnd + j;
                         if ((operands[oi] & kOpKindMask) != kOpLds) continue;
@@ -1104,8 +1207,11 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             }
             // the oscillator's recurrence member and its waveform member are the same node: only the waveform member exports it
             for (size_t q = 0; q < tasks.size(); ++q)
-                if (blepSplit(tasks[q].opcode) && !sp.gdirect[q])
-                    for (uint32_t k = 0; k < tasks[q].count; ++k) sp.members[tasks[q].first + k].outHbm = members[tasks[q].first + k].outHbm;
+                if ((blepSplit(tasks[q].opcode) || tasks[q].opcode == OP_PHASE) && !sp.gdirect[q])
+                    for (uint32_t k = 0; k < tasks[q].count; ++k) {
+                        const int x = memberNode[tasks[q].first + k];
+                        if (x >= 0 && blepSplit(ni[x].n->op)) sp.members[tasks[q].first + k].outHbm = members[tasks[q].first + k].outHbm;
+                    }
             // arena table: every absolute arena index the variant names, in order of first appearance
             auto ref = [&](uint32_t abs) { for (uint32_t v : sp.hbmTab) if (v == abs) return; sp.hbmTab.push_back(abs); };
             for (const Member& m : sp.members) if (m.outHbm != kNone) ref(m.outHbm);
@@ -1121,6 +1227,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         I.opndOff = I.memOff + (uint32_t)members.size() * 8u;
         I.copyDwords = (I.opndOff + (uint32_t)operands.size() + 3u) & ~3u;
         I.copies = copies;
+        if (packCount[ii] > 1u) minPackedCopies = minPackedCopies ? std::min(minPackedCopies, copies) : copies;
+        p.maxCopies = std::max(p.maxCopies, copies);
         I.slotArea = slotArea;
         I.stateless = statelessIsland ? 1u : 0u;
         I.cellOff = I.copyDwords * copies;
@@ -1168,7 +1276,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             // signature of everything the text is a function of (arena indices by their position in the island's arena table)
             uint64_t h = 1469598103934665603ull;
             auto mix = [&](uint32_t v) { h ^= v; h *= 1099511628211ull; h ^= h >> 29; };
-            auto arenaPos = [&](uint32_t abs) { for (size_t k = 0; k < sp.hbmTab.size(); ++k) if (sp.hbmTab[k] == abs) return (uint32_t)k; return 0xFFFFu; };
+            auto arenaPos = [&](uint32_t abs) { for (size_t k = 0; k < sp.hbmTab.size(); ++k) if (sp.hbmTab[k] == abs) return (uint32_t)k | (abs & kOpStream); return 0xFFFFu; };
             const uint32_t* iw = reinterpret_cast<const uint32_t*>(&I);
             for (size_t k = 0; k < sizeof(Island) / 4; ++k) if (k != offsetof(Island, progBegin) / 4 && k != offsetof(Island, rootRec) / 4) mix(iw[k]);
             for (const Task& t : tasks) { const uint32_t* w = reinterpret_cast<const uint32_t*>(&t); for (int k = 0; k < 8; ++k) mix(k == 7 ? 0u : w[k]); }   // (t.outHbm: absolute, not part of the text)
@@ -1240,14 +1348,27 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     const uint32_t ldsLimit = 160u * 1024u - 1024u;
     // the text cache is only ever trimmed BETWEEN builds (texts in use stay alive through the shared objects the plan holds)
     if (specTextCache.size() > 4096) specTextCache.clear();
-    for (uint32_t limit = 56; limit >= 4; limit /= 2) {
-        PlanBuilder b(*this);
-        // a dry handle (no device) only generates / compiles kernels when asked to wait for them (cache warming, tests)
-        b.wantSpec = specialize != 0 && (!dry || specialize >= 2);
-        plan = b.build(limit, (uint32_t)std::max(1, pipelineCopies));
-        if (!plan) return nullptr;
-        if (plan->maxLdsBytes <= ldsLimit) break;
-        plan.reset();
+    // Lane-packing (option "pack_islands": 0 auto, 1 off, K): the first attempt packs as the option says; a packed island
+    // that does not fit in LDS, or fits with a single buffer set (no blocks in flight: the stages of a block would run back
+    // to back), sends the build back with one island fewer per pack.
+    uint32_t packK = (uint32_t)packIslands;
+    for (;;) {
+        uint32_t usedK = 1, minCopies = 0;
+        for (uint32_t limit = 56; limit >= 4; limit /= 2) {
+            PlanBuilder b(*this);
+            // a dry handle (no device) only generates / compiles kernels when asked to wait for them (cache warming, tests)
+            b.wantSpec = specialize != 0 && (!dry || specialize >= 2);
+            b.packK = packK; b.packMax = (uint32_t)std::max(1, packMax); b.cuCount = (uint32_t)std::max(1, cuCount);
+            plan = b.build(limit, (uint32_t)std::max(1, pipelineCopies));
+            if (!plan) return nullptr;
+            usedK = b.packK; minCopies = b.minPackedCopies;
+            plan->packK = b.packedIslands ? usedK : 1u;
+            if (plan->maxLdsBytes <= ldsLimit) break;
+            plan.reset();
+            if (usedK > 1) break;          // (a packed island too big for LDS: pack fewer rather than cut the islands up)
+        }
+        if (usedK > 1 && (!plan || (minCopies != 0 && minCopies < 2 && pipelineCopies >= 2))) { plan.reset(); packK = usedK - 1; continue; }
+        break;
     }
     if (!plan) { std::fprintf(stderr, "[elemhip] plan: could not fit islands into LDS\n"); return nullptr; }
     Plan& p = *plan;
@@ -1358,7 +1479,8 @@ std::string Engine::describePlan() {
     auto kv = [&](const char* k, uint64_t v, bool comma = true) { s += "\"" + std::string(k) + "\":" + std::to_string(v) + (comma ? "," : ""); };
     kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.numTasks);
     kv("num_members", p.numMembers); kv("num_operands", p.numOperands); kv("num_nodes", p.nodeIds.size());
-    kv("num_hbm_buffers", p.numHbmBuffers); kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());
+    kv("num_hbm_buffers", p.numHbmBuffers); kv("num_stream_buffers", p.numStreamBuffers); kv("pack_k", p.packK);
+    kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());
     kv("num_taps", p.taps.size()); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());
     s += "\"level_sizes\":[";
     for (size_t l = 0; l + 1 < p.levelOffsets.size(); ++l) { if (l) s += ","; s += std::to_string(p.levelOffsets[l + 1] - p.levelOffsets[l]); }

@@ -1,0 +1,80 @@
+"""Lane-packing of isomorphic islands (plan.cpp step 2b): K same-shape islands of a launch level merged into one workgroup,
+their float recurrences sharing a wavefront lane by lane. Packing only changes where a node is rendered, never a sample:
+every packed engine must equal the unpacked engine BIT FOR BIT, and the reference engine within 1e-6."""
+import numpy as np
+import pytest
+
+from elementary_amd import graphs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _checker(sr, bs):
+    import oracle
+    return oracle.RefRuntime(sr, bs) if oracle.have_ref() else oracle.PortRuntime(sr, bs)
+
+
+def _hip(sr, **opts):
+    from elementary_amd.runtime import Runtime
+    rt = Runtime(sr, 512, device=0)
+    for k, v in opts.items():
+        rt.set_option(k, v)
+    return rt
+
+
+def _planar(rt, n_out, blocks):
+    return rt.process_blocks_host(None, n_out, blocks * 512)
+
+
+@pytest.mark.parametrize("spec", [0, 2])
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_packed_voices_equal_unpacked(gpu_required, spec, k):
+    """48 C2 voices, K voices per island when forced (K = 4 leaves room for one buffer set only: the planner settles for 3),
+    both kernel families, 150 blocks through launch sets of 32."""
+    a = _hip(graphs.C2_SAMPLE_RATE, specialize=spec, batch_blocks=32, pack_islands=k)
+    b = _hip(graphs.C2_SAMPLE_RATE, specialize=spec, batch_blocks=32, pack_islands=1)
+    c = _checker(graphs.C2_SAMPLE_RATE, 512)
+    roots = graphs.c2_graph(voices=48)
+    for rt in (a, b, c):
+        assert rt.render(*roots)["result"] == 0
+    pa, pb = a.describe_plan(), b.describe_plan()
+    assert pb["pack_k"] == 1 and pb["level_sizes"][0] == 48
+    assert pa["pack_k"] == min(k, 3) and pa["level_sizes"][0] == -(-48 // min(k, 3))
+    assert pa["islands"][0]["copies"] >= 2
+    got, ref_hip = _planar(a, 2, 150), _planar(b, 2, 150)
+    assert np.array_equal(got, ref_hip)
+    ref = np.concatenate([c.process(None, 2, 512) for _ in range(150)], axis=1)
+    assert float(np.abs(got - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
+    if spec:
+        st = a.stats()
+        assert st["spec_launches"] > 0 and all(a.spec_info(q)["state"] == 1 for q in range(st["spec_shapes"])), st
+
+
+def test_auto_packing_follows_the_cu_count(gpu_required):
+    """Auto mode packs when a launch level has more stateful islands than the device has CUs: with the CU count it plans for
+    set to 16 and up to 3 per island allowed, 40 voices become 14 islands of 3 (ceil(40 / 16) = 3), 16 voices stay one per island."""
+    a, b = _hip(graphs.C2_SAMPLE_RATE, cu_count=16, pack_max=3, batch_blocks=16), _hip(graphs.C2_SAMPLE_RATE, cu_count=16, pack_max=3, batch_blocks=16)
+    c = _checker(graphs.C2_SAMPLE_RATE, 512)
+    assert a.render(*graphs.c2_graph(voices=40))["result"] == 0 and c.render(*graphs.c2_graph(voices=40))["result"] == 0
+    assert b.render(*graphs.c2_graph(voices=16))["result"] == 0
+    assert a.describe_plan()["pack_k"] == 3 and a.describe_plan()["level_sizes"][0] == 14
+    assert b.describe_plan()["pack_k"] == 1 and b.describe_plan()["level_sizes"][0] == 16
+    got = _planar(a, 2, 70)
+    ref = np.concatenate([c.process(None, 2, 512) for _ in range(70)], axis=1)
+    assert float(np.abs(got - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
+
+
+def test_render_jobs_with_a_root_each_are_not_packed(gpu_required):
+    """Islands are only merged within one root sequence (an island renders while ITS root runs): C4 render jobs, a root per
+    job, stay one per workgroup whatever the option says — and render as before."""
+    a = _hip(graphs.C4_SAMPLE_RATE, batch_blocks=16, pack_islands=4)
+    c = _checker(graphs.C4_SAMPLE_RATE, 512)
+    roots = [graphs.c4_instance(k) for k in range(10)]
+    for rt in (a, c):
+        assert rt.render(*roots)["result"] == 0
+    p = a.describe_plan()
+    assert p["pack_k"] == 1 and p["level_sizes"][0] == 10
+    got = _planar(a, 10, 40)
+    ref = np.concatenate([c.process(None, 10, 512) for _ in range(40)], axis=1)
+    assert float(np.abs(got - ref).max()) <= TOL

@@ -96,6 +96,23 @@ def test_plan_shape_for_the_benchmark_graph():
     assert p["num_hbm_buffers"] == 32 + 256 + 2     # host inputs + voice exports + roots
 
 
+def test_lane_packing_plan_shapes():
+    """Auto lane-packing: 256 voices = one island per CU, untouched; 512 voices = 2 per island (3 buffer sets); 1024 voices: still 2
+    per island (auto never goes beyond 2: with 3 only two buffer sets fit and the block pipeline starves); 4 per island asked for
+    explicitly: only one buffer set would fit in LDS, so the planner settles for 3 (342 islands); pack_islands = 1 switches it
+    off. The two mixers stay as they are."""
+    for voices, opts, want_k, want_islands in ((256, {}, 1, 256), (512, {}, 2, 256), (1024, {}, 2, 512), (1024, {"pack_islands": 4}, 3, 342),
+                                               (512, {"pack_islands": 1}, 1, 512)):
+        rt = dry(graphs.C2_SAMPLE_RATE)
+        for k, v in opts.items():
+            rt.set_option(k, v)
+        assert rt.render(*graphs.c2_graph(voices=voices))["result"] == 0
+        p = rt.describe_plan()
+        assert p["pack_k"] == want_k and p["level_sizes"] == [want_islands, 4], (voices, p["pack_k"], p["level_sizes"])
+        assert p["islands"][0]["copies"] >= 2 and p["max_lds_bytes"] <= 159 * 1024
+        assert p["num_nodes"] == voices * 16 + 11
+
+
 def _op_names():
     import os, re
     src = open(os.path.join(os.path.dirname(__file__), "..", "elementary_amd", "csrc", "device.h")).read()
@@ -105,7 +122,7 @@ def _op_names():
 
 def test_voice_island_schedule():
     """Planner rules visible in the per-wave task lists of a C2 voice island: the oscillator is two tasks (phase
-    recurrence, then the waveform with its consumers in the next stage), the filter-coefficient pre-pass shares
+    recurrence — merged with the gate phasor's — then the waveform with its consumers in the next stage), the filter-coefficient pre-pass shares
     a stage with its producers and is split over two waves, every recurrence has a wave to itself, and no stage
     order is violated inside a wave."""
     names = _op_names()
@@ -116,12 +133,13 @@ def test_voice_island_schedule():
     flat = [t for w in waves for t in w]
     assert isl["stages"] == 6 and len(flat) == isl["tasks"]
     stage_of = lambda name: sorted({st for n, st in flat if n == name})
-    assert stage_of("blepsaw") == [0] and stage_of("saw_shape") == [1]
+    # the gate phasor and both oscillator phases (constant frequencies) share ONE recurrence task (device.h OP_PHASE)
+    assert stage_of("phase") == [0] and stage_of("saw_shape") == [1] and stage_of("blepsaw") == [] and stage_of("phasor") == []
     (coef_stage,) = stage_of("svf_coef")
     assert stage_of("svf") == [coef_stage + 1]
     coef_waves = [w for w in waves if ("svf_coef", coef_stage) in w]
     assert len(coef_waves) == 2 and all(w[-1][0] == "svf_coef" and len(w) == 3 for w in coef_waves)   # mul, add, coef
-    for rec in ("blepsaw", "phasor", "pole", "svf"):
+    for rec in ("phase", "pole", "svf"):
         assert [w for w in waves if any(n == rec for n, _ in w)] == [[(rec, stage_of(rec)[0])]], rec
     for w in waves:
         assert [st for _, st in w] == sorted(st for _, st in w)

@@ -24,6 +24,10 @@ rt = Runtime(sr, 512, device=0)
 rt.set_option("specialize", spec)
 rt.set_option("batch_blocks", batch)
 rt.set_option("time_batch", batch)
+import os
+for kv in os.environ.get("ELEMHIP_TRACE_OPTS", "").split():      # extra engine options: "key=value key=value"
+    k, v = kv.split("=", 1)
+    rt.set_option(k, float(v))
 assert rt.render(*roots)["result"] == 0
 out = torch.zeros((batch * 4, nout, 512), dtype=torch.float32, device="cuda")
 rt.process_blocks(batch * 4, nout, out_ptr=out.data_ptr())      # settle fades, warm caches
