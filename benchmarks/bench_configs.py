@@ -42,9 +42,9 @@ def _time_cpu(rt, n_in, n_out, x=None, budget=6.0, warm=8):
     return (time.perf_counter() - t0) / m, m
 
 
-def _time_gpu(rt, n_in, n_out, blocks, xin=None):
+def _time_gpu(rt, n_in, n_out, blocks, xin=None, chunk=256):
     import torch
-    out = torch.empty((min(blocks, 256), n_out, BLOCK), dtype=torch.float32, device="cuda")
+    out = torch.empty((min(blocks, chunk), n_out, BLOCK), dtype=torch.float32, device="cuda")
     chunk = out.shape[0]
 
     def run(total):
@@ -94,9 +94,11 @@ def c3(args):
     for c in range(ch):
         assert rt.add_shared_resource(f"ir{c}", irs[c])
     assert rt.render(*graphs.c3_graph(ch))["result"] == 0
+    set_blocks = args.batch_blocks or 1024
+    rt.set_option("batch_blocks", set_blocks)
     x = graphs.c3_input(ch, 64 * BLOCK)
-    xin = torch.from_numpy(np.ascontiguousarray(x.reshape(ch, 64, BLOCK).transpose(1, 0, 2))).cuda().repeat(4, 1, 1).contiguous()
-    g = _time_gpu(rt, ch, ch, args.blocks, xin)
+    xin = torch.from_numpy(np.ascontiguousarray(x.reshape(ch, 64, BLOCK).transpose(1, 0, 2))).cuda().repeat(max(4, set_blocks // 64), 1, 1).contiguous()
+    g = _time_gpu(rt, ch, ch, args.blocks, xin, chunk=max(256, set_blocks))
     lv = rt.time_launches(ch, 200)
     cpu, kind = _cpu_engine(graphs.C3_SAMPLE_RATE, use_ref=False)   # convolve exists only in the restatement (and the wasm build)
     for c in range(ch):
@@ -113,7 +115,7 @@ def c3(args):
     except Exception:
         pass
     return {"config": "C3 8-channel convolution reverb, 96 000-tap IRs, sr 48000", "gpu_us_per_block": 1e6 * g,
-            "gpu_path": "elemhip_process_blocks: multi-block convolve kernels (fft / mac / finish per 64-block launch set)",
+            "gpu_path": f"elemhip_process_blocks: multi-block convolve kernels (fft / mac / ifft / finish per {set_blocks}-block launch set)",
             "gpu_launch_set_profile": getattr(_time_gpu, "last_profile", None), "batch_launches": rt.stats()["batch_launches"],
             "single_block_launch_note": "launch_us / conv_kernel_us below time the block-at-a-time path (elemhip_process)",
             "reference_wasm_cpu": wasm,
@@ -291,6 +293,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("configs", nargs="*", default=["c1", "c3", "c4", "c5"])
     ap.add_argument("--blocks", type=int, default=2048)
+    ap.add_argument("--batch-blocks", type=int, default=0, help="blocks per launch set (0: c3 uses 1024, the others the engine default)")
     ap.add_argument("--instances", type=int, default=128)
     ap.add_argument("--batches", type=int, default=400)
     ap.add_argument("--seconds", type=float, default=8.0)

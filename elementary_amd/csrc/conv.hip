@@ -274,14 +274,15 @@ void elemhip_convolve_kernel(PlanView pv, uint32_t* recs, float* hbm, const Glob
 // Three launches per launch set instead of two per block. The helpers' pre-multiplied sums are not produced: the first
 // per-block call after a batch takes conv_main's own older_sum path once. The host only uses this path while every
 // call so far rendered whole 512-frame blocks (fill == 0, Engine::convAligned).
-// Scratch per node (floats): [0] b0 | 16 + Xnew[B][512] c2 | tails[B + 1][512]
+// Scratch per node (floats): [0] b0 | 16 + Xnew[B][512] c2 | tails[B + 1][512] | Ysum[kMacParts][B][512] c2
 namespace {
 
 constexpr uint32_t kBatchHdr = 16;
-__device__ __forceinline__ size_t batch_scratch_floats(uint32_t maxBatch) { return kBatchHdr + (size_t)maxBatch * 1024u + (size_t)(maxBatch + 1u) * 512u; }
+constexpr uint32_t kMacParts = 2;       // workgroups the partitions of one (node, bin tile, 64-block chunk) are cut into
+__device__ __forceinline__ size_t batch_scratch_floats(uint32_t maxBatch) { return kBatchHdr + (size_t)maxBatch * 1024u + (size_t)(maxBatch + 1u) * 512u + (size_t)kMacParts * maxBatch * 1024u; }
 
 struct BatchCtx {
-    State st; bool live; uint32_t inKind, inBuf; float cval; gfp scratch; gf2p xnew; gfp tails; float gain;
+    State st; bool live; uint32_t inKind, inBuf; float cval; gfp scratch; gf2p xnew; gfp tails; gf2p ysum; float gain;
 };
 
 // decode shared by the three kernels; live == false: the node writes zeros (Convolve.h:70-71) or does nothing
@@ -300,6 +301,7 @@ __device__ __forceinline__ bool batch_ctx(const ConvDesc& d, gup recs, const Glo
     c.scratch = (gfp)(scratchAll + (size_t)convIdx * batch_scratch_floats(maxBatch));
     c.xnew = (gf2p)(c.scratch + kBatchHdr);
     c.tails = c.scratch + kBatchHdr + (size_t)maxBatch * 1024u;
+    c.ysum = (gf2p)(c.tails + (size_t)(maxBatch + 1u) * 512u);
     c.live = false;
     if (sp == 0ull || c.inKind == 0u) return false;
     c.st = state_of((gup)reinterpret_cast<uint32_t*>(sp));
@@ -341,9 +343,127 @@ void elemhip_convolve_batch_fft(PlanView pv, uint32_t* recs, float* hbm, const G
     }
 }
 
+// K2a: the partition sums of a launch set, H read ONCE per set. For one bin k the sums of the set's blocks are a convolution
+// along the block index: Y_j[k] = sum_p H_p[k] X_{b0+j-p}[k]. A workgroup owns 16 bins of one node and (up to) 64
+// consecutive blocks: thread (bin, jg) accumulates the four blocks j0 .. j0 + 3 (j0 = 4 jg) while p runs over the
+// partitions — per step ONE new input spectrum value (the window X_{j0+q-p}, q = 0..3, slides by one: three of its
+// values stay in registers), one H value shared by the 16 threads of the bin group, four complex multiply-adds.
+// r02's kernel ran one workgroup per (node, block) over all partitions: every block re-read all of H and its whole input
+// window (12.3 MB per block against 1.28 MB algorithmic); here a 64-block set reads H and the ring once and the 64
+// new spectra once per bin tile.
+template <bool HasPacked>
+__device__ __forceinline__ void batch_mac_tile(const BatchCtx& c, uint32_t tile, uint32_t jBase, uint32_t batch, uint32_t tid,
+                                               uint32_t part, uint32_t maxBatch) {
+    // LDS: a ring of input-spectrum rows (16 bins each) indexed by block time, and two chunks of H rows. A chunk is 8
+    // partitions; per chunk the workgroup brings in 8 new ring rows and 8 H rows — ONE 8-byte value per thread — while the
+    // 64 x 16 outputs it accumulates read everything else from LDS.
+    constexpr uint32_t U = 8, R = 128, DP = 3;             // partitions per chunk, ring rows, chunks the global loads run ahead
+    // (row pitch 20 values = 40 dwords: the four block groups of a wave read rows 4 apart — 160 dwords = 32 banks on — so each
+    //  half-wave's 8-byte reads cover all 64 banks once; a 16-value pitch put all four on the same 32 banks)
+    __shared__ c2 Xs[R][20];
+    __shared__ c2 Hs[DP + 1u][U][16];
+    const uint32_t bin = tid & 15u, row = tid >> 4, kb = tile * 16u + bin, jg = row;      // bin, load row / block group
+    const uint32_t j0 = jBase + jg * 4u;
+    const uint32_t P = c.st.P, b0 = c.st.hdr[conv::H_BLK];
+    const bool packed = HasPacked && kb == 0u;                            // bin 0 carries two real bins (DC, Nyquist)
+    gcf2p H = (gcf2p)c.st.H + kb, X = (gcf2p)c.st.X + kb, N = (gcf2p)c.xnew + kb;
+    // x(t): input spectrum of block b0 + t — 0 <= t < batch: a block of this set; t < 0: the ring (slot of block b is b mod P)
+    const uint32_t bm = b0 % P;
+    auto xat = [&](int t) -> c2 {
+        if (t >= (int)batch) return mk(0.0f, 0.0f);                      // (rows only the unused lanes of a ragged last group look at)
+        if (t >= 0) return N[(size_t)t * 512u];
+        uint32_t back = (uint32_t)(-t);                                   // 1 .. P - 1: blocks older than P never contribute
+        if (back > P) back = P;                                           // (a padded step past the last partition: any valid slot)
+        const uint32_t slot = bm >= back ? bm - back : bm + P - back;
+        return X[(size_t)slot * 512u];
+    };
+    // the partitions are cut into kMacParts runs, a workgroup each; every run leaves its own partial sum, the inverse-FFT
+    // kernel adds them up
+    const uint32_t perPart = (P + kMacParts - 1u) / kMacParts, pBegin = part * perPart, pEnd = pBegin + perPart < P ? pBegin + perPart : P;
+    gf2p Y = c.ysum + (size_t)part * maxBatch * 512u + kb;
+    if (pBegin >= pEnd) {
+        for (uint32_t q = 0; q < 4u; ++q) if (j0 + q < batch) Y[(size_t)(j0 + q) * 512u] = mk(0.0f, 0.0f);
+        return;
+    }
+    auto hrow = [&](uint32_t p) -> c2 { return p < pEnd ? H[(size_t)p * 512u] : mk(0.0f, 0.0f); };   // partitions past the end multiply by zero
+    // initial fill: ring rows t in [jBase - 8 DP - pBegin, jBase + 63 - pBegin] (the first DP chunks' new entries and every
+    // thread's starting window), H rows of the first DP chunks
+    {   // (every load issued before the first LDS write: the fill costs one memory round trip, not one per row)
+        const int tLo = (int)jBase - (int)(U * DP) - (int)pBegin;
+        constexpr uint32_t NX = (64u + U * DP + 15u) / 16u, NH = (U * DP + 15u) / 16u;
+        c2 fx[NX], fh[NH];
+#pragma unroll
+        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; fx[i] = r < 64u + U * DP ? xat(tLo + (int)r) : mk(0.0f, 0.0f); }
+#pragma unroll
+        for (uint32_t i = 0; i < NH; ++i) { const uint32_t r = row + 16u * i; fh[i] = r < U * DP ? hrow(pBegin + r) : mk(0.0f, 0.0f); }
+#pragma unroll
+        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; if (r < 64u + U * DP) Xs[(uint32_t)(tLo + (int)r) & (R - 1u)][bin] = fx[i]; }
+#pragma unroll
+        for (uint32_t i = 0; i < NH; ++i) { const uint32_t r = row + 16u * i; if (r < U * DP) Hs[r / U][r % U][bin] = fh[i]; }
+    }
+    __syncthreads();
+    auto xs = [&](int t) -> c2 { return Xs[(uint32_t)t & (R - 1u)][bin]; };
+    c2 w0 = xs((int)j0 - (int)pBegin), w1 = xs((int)j0 + 1 - (int)pBegin), w2 = xs((int)j0 + 2 - (int)pBegin), w3 = xs((int)j0 + 3 - (int)pBegin);
+    c2 a0 = mk(0.0f, 0.0f), a1 = a0, a2 = a0, a3 = a0;
+    auto mac = [&](c2& acc, c2 h, c2 x) {
+        if (HasPacked && packed) { acc.x = __builtin_fmaf(h.x, x.x, acc.x); acc.y = __builtin_fmaf(h.y, x.y, acc.y); }
+        else {
+            acc.x = __builtin_fmaf(h.x, x.x, acc.x); acc.x = __builtin_fmaf(-h.y, x.y, acc.x);
+            acc.y = __builtin_fmaf(h.x, x.y, acc.y); acc.y = __builtin_fmaf(h.y, x.x, acc.y);
+        }
+    };
+    // this thread's piece of chunk `ck` (rows 0..7: a new ring row, rows 8..15: an H row)
+    auto piece = [&](uint32_t ck) -> c2 {
+        const uint32_t pk = pBegin + ck * U;
+        if (pk >= pEnd) return mk(0.0f, 0.0f);
+        return row < U ? xat((int)jBase - (int)U - (int)pk + (int)row) : hrow(pk + row - U);
+    };
+    auto stash = [&](uint32_t ck, c2 v) {
+        const uint32_t pk = pBegin + ck * U;
+        if (pk >= pEnd) return;
+        if (row < U) Xs[(uint32_t)((int)jBase - (int)U - (int)pk + (int)row) & (R - 1u)][bin] = v; else Hs[ck % (DP + 1u)][row - U][bin] = v;
+    };
+    // chunk ck's piece is loaded while chunk ck - DP is computed and put into LDS DP - 1 chunks later (one barrier before its
+    // first reader): the load has two whole chunks of arithmetic to come back
+    c2 q1 = piece(DP), q2 = mk(0.0f, 0.0f);                  // in flight: chunk DP (for the end of chunk 0), chunk DP + 1 (end of chunk 1)
+    uint32_t ck = 0u;
+    for (uint32_t p0 = pBegin; p0 < pEnd; p0 += U, ++ck) {
+        q2 = piece(ck + DP + 1u);
+        const uint32_t hb = ck % (DP + 1u);
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const c2 h = Hs[hb][u][bin];
+            const c2 xn = xs((int)j0 - 1 - (int)(p0 + u));                   // enters the window after partition p0 + u
+            mac(a0, h, w0); mac(a1, h, w1); mac(a2, h, w2); mac(a3, h, w3);
+            w3 = w2; w2 = w1; w1 = w0; w0 = xn;
+        }
+        stash(ck + DP, q1);
+        q1 = q2;
+        __syncthreads();
+    }
+    if (j0 < batch) Y[(size_t)j0 * 512u] = a0;
+    if (j0 + 1u < batch) Y[(size_t)(j0 + 1u) * 512u] = a1;
+    if (j0 + 2u < batch) Y[(size_t)(j0 + 2u) * 512u] = a2;
+    if (j0 + 3u < batch) Y[(size_t)(j0 + 3u) * 512u] = a3;
+}
+
 __global__ __launch_bounds__(256)
 void elemhip_convolve_batch_mac(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch) {
+                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t batch) {
+    const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, tile = blockIdx.y, tid = threadIdx.x;
+    const uint32_t part = blockIdx.z % kMacParts, jBase = (blockIdx.z / kMacParts) * 64u;
+    const ConvDesc d = pv.convs[convIdx];
+    if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
+    BatchCtx c;
+    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) return;     // (the ifft kernel writes the zeros)
+    if (tile == 0u) batch_mac_tile<true>(c, tile, jBase, batch, tid, part, maxBatch);
+    else batch_mac_tile<false>(c, tile, jBase, batch, tid, part, maxBatch);
+}
+
+// K2b (node, j): inverse FFT of the block's partition sum; head half -> the node's output buffer of block j, tail half -> tails[j + 1]
+__global__ __launch_bounds__(256)
+void elemhip_convolve_batch_ifft(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
+                                 uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch) {
     __shared__ c2 A[conv::kFft], B[conv::kFft], W[conv::kFft];
     const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, j = blockIdx.y, tid = threadIdx.x;
     const ConvDesc d = pv.convs[convIdx];
@@ -356,33 +476,12 @@ void elemhip_convolve_batch_mac(PlanView pv, uint32_t* recs, float* hbm, const G
         return;
     }
     for (uint32_t i = tid; i < conv::kFft; i += 256u) W[i] = kTwiddle[i];
-    const uint32_t P = c.st.P, b0 = c.st.hdr[conv::H_BLK], bm = (b0 + j) % P;
-    // bins 2 tid, 2 tid + 1: one 16-byte load per spectrum and partition
+    // bins 2 tid, 2 tid + 1 of the sum; the conjugate-symmetric half makes the 1024-point transform's input
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(1))) const f4* gcf4p;
-    gcf4p H4 = (gcf4p)c.st.H + tid, X4 = (gcf4p)c.st.X + tid, N4 = (gcf4p)c.xnew + tid;
-    c2 acc0 = mk(0.0f, 0.0f), acc1 = mk(0.0f, 0.0f);
-    auto src = [&](uint32_t p) -> f4 {   // X_{b0 + j - p}: a spectrum of this batch, or the ring
-        if (p <= j) return N4[(size_t)(j - p) * 256u];
-        const uint32_t slot = bm >= p ? bm - p : bm + P - p;
-        return X4[(size_t)slot * 256u];
-    };
-    uint32_t p = 0;
-    for (; p + 8u <= P; p += 8u) {
-        f4 h[8], x[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) { h[u] = H4[(size_t)(p + u) * 256u]; x[u] = src(p + u); }
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-            acc0 = cadd(acc0, smul(mk(h[u].x, h[u].y), mk(x[u].x, x[u].y), tid == 0u));
-            acc1 = cadd(acc1, cmul(mk(h[u].z, h[u].w), mk(x[u].z, x[u].w)));
-        }
-    }
-    for (; p < P; ++p) {
-        const f4 h = H4[(size_t)p * 256u], x = src(p);
-        acc0 = cadd(acc0, smul(mk(h.x, h.y), mk(x.x, x.y), tid == 0u));
-        acc1 = cadd(acc1, cmul(mk(h.z, h.w), mk(x.z, x.w)));
-    }
+    f4 y = ((gcf4p)(c.ysum + (size_t)j * 512u))[tid];
+    for (uint32_t q = 1; q < kMacParts; ++q) y += ((gcf4p)(c.ysum + ((size_t)q * maxBatch + j) * 512u))[tid];       // the runs' partial sums
+    const c2 acc0 = mk(y.x, y.y), acc1 = mk(y.z, y.w);
     const uint32_t k0 = 2u * tid, k1 = k0 + 1u;
     if (tid == 0u) { A[0] = mk(acc0.x, 0.0f); A[512] = mk(acc0.y, 0.0f); }
     else { A[k0] = mk(acc0.x, -acc0.y); A[1024u - k0] = acc0; }
@@ -427,13 +526,15 @@ void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* h
     hipLaunchKernelGGL(elemhip_convolve_kernel, dim3(numWorkgroups), dim3(256), 0, s, pv, recs, hbm, g, workBegin);
 }
 
-size_t convolve_batch_scratch_floats(uint32_t maxBatch) { return 16u + (size_t)maxBatch * 1024u + (size_t)(maxBatch + 1u) * 512u; }
+size_t convolve_batch_scratch_floats(uint32_t maxBatch) { return 16u + (size_t)maxBatch * 1024u + (size_t)(maxBatch + 1u) * 512u + (size_t)kMacParts * maxBatch * 1024u; }
 
 void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
                            uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch) {
     const dim3 grid(numNodes, batch), block(256);
     hipLaunchKernelGGL(elemhip_convolve_batch_fft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
-    hipLaunchKernelGGL(elemhip_convolve_batch_mac, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
+    // (node, 16-bin tile, 64-block chunk x partition run): 1024 workgroups for 8 channels
+    hipLaunchKernelGGL(elemhip_convolve_batch_mac, dim3(numNodes, conv::kBlock / 16u, kMacParts * ((batch + 63u) / 64u)), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch);
+    hipLaunchKernelGGL(elemhip_convolve_batch_ifft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
     hipLaunchKernelGGL(elemhip_convolve_batch_finish, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
 }
 

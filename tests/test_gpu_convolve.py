@@ -106,6 +106,20 @@ def test_c3_multi_block_launches_vs_restatement(gpu_required):
     assert float(np.abs(got.astype(np.float64) - ref).max()) <= TOL
 
 
+@pytest.mark.parametrize("ch,batch,blocks", [(8, 256, 600), (2, 1024, 1024 + 1024 + 90)])
+def test_c3_large_launch_sets_vs_restatement(gpu_required, ch, batch, blocks):
+    """Launch sets longer than the IR has partitions (188): every spectrum a late block needs comes from the same set, and
+    the set leaves only its last 188 spectra in the ring. The geometry benchmarks/bench_configs.py c3 times."""
+    rt, x = _c3(hip, ch, blocks)
+    rt.set_option("batch_blocks", batch)
+    got = np.concatenate([_blocks(rt, x, k0, min(batch + 37, blocks - k0), ch) for k0 in range(0, blocks, batch + 37)])
+    assert rt.stats()["batch_launches"] >= 2
+    ref_rt, _ = _c3(lambda sr, bs: oracle.PortRuntime(sr, bs), ch, blocks)
+    ref = np.stack([ref_rt.process(x[:, k * 512:(k + 1) * 512], ch, 512) for k in range(blocks)])
+    err = np.abs(got.astype(np.float64) - ref).max(axis=(1, 2))
+    assert float(err.max()) <= TOL, f"block {int(err.argmax())}: {err.max():.3e}"
+
+
 @pytest.mark.parametrize("taps", [300, 700, 3000, 40000])
 def test_multi_block_and_single_block_calls_interleave(gpu_required, taps):
     """One stream rendered by alternating elemhip_process_blocks (multi-block kernels) and elemhip_process (main +
