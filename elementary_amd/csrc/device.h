@@ -67,6 +67,8 @@ enum Op : uint16_t {
     OP_METER, OP_SNAPSHOT, OP_SCOPE,              // event side-channel (Analyzers.h)
     OP_MCSAMPLE,                                  // one output channel of mc.sample (mc/Sample.h); mc.table and
                                                   // mc.sampleseq channels reuse the table / sampleseq ops (flag in the record)
+    OP_SPARSEQ,                                   // SparSeq.h:17-372 (tick-time keyed sequence: loop points, follow, interpolation)
+    OP_CAPTURE,                                   // Capture.h:13-104 (gated recording relayed as a "capture" event)
     // plan pseudo-ops
     OP_COPY,          // out = in0 (import HBM->LDS, export LDS->HBM)
     OP_SVF_COEF,      // SVF coefficient pre-pass (a1,a2,a3 as double into the member's scratch), sample-parallel
@@ -260,6 +262,15 @@ enum : uint32_t {
     TBL_BUF = P0, TBL_LEN = P2,
     // sparseq2 (SparSeq2.h:17-141): interpolate flag, event table [len doubles | len floats]
     SPS_INTERP = P0, SPS_SEQ = P4, SPS_LEN = P6,
+    // sparseq (SparSeq.h): host-written: offset, follow, interpolate, new-sequence flag, event table [len int32 tick times | len
+    // floats], its length, new-loop-points flag + the points, tickInterval in samples (double); state: edge count, samples since
+    // the clock edge, held event index (-1: none), change detectors, have-sequence, loop points, pending loop points
+    SQ_OFFSET = P0, SQ_FOLLOW = P1, SQ_INTERP = P2, SQ_SEQ_PENDING = P3, SQ_SEQ = P4, SQ_LEN = P6, SQ_LOOP_PENDING = P7,
+    SQ_EDGES = S0, SQ_SINCE = S1, SQ_HOLD = S2, SQ_CHANGE = S3, SQ_RCHANGE = S4, SQ_HAVE = S5, SQ_LOOP_START = S6, SQ_LOOP_END = S7,
+    SQ_NEW_START = 16, SQ_NEW_END = 17, SQ_TICK = 18, SQ_PEND_FLAG = 20, SQ_PEND_START = 21, SQ_PEND_END = 22,
+    // capture (Capture.h): device ring of bitceil(sr) floats, its mask; ring write / read positions (MultiChannelRingBuffer.h), frames
+    // in the 128-frame scratch (they sit in the ring ahead of the write position), change detector, relay-ready flag
+    CAP_RING = P0, CAP_MASK = P2, CAP_WRITE = 8, CAP_READ = 9, CAP_SCRATCH = 10, CAP_CHANGE = 11, CAP_READY = 12,
     // meter: S0 min, S1 max, S2 readout count; snapshot: S0 previous trigger sample, S1 captured value, S2 capture count
     EVT_A = 8, EVT_B = 9, EVT_COUNT = 10,
     // scope: device ring [4 channels][8192] (MultiChannelRingBuffer.h), write / read positions shared with the host relay

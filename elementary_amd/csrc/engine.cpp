@@ -56,7 +56,7 @@ static const std::unordered_map<std::string, uint16_t>& opTable() {
         {"pole", OP_POLE}, {"env", OP_ENV}, {"biquad", OP_BIQUAD}, {"prewarp", OP_PREWARP}, {"mm1p", OP_MM1P}, {"svf", OP_SVF}, {"svfshelf", OP_SVFSHELF},
         {"tapIn", OP_TAPIN}, {"tapOut", OP_TAPOUT},
         {"blepsaw", OP_BLEPSAW}, {"blepsquare", OP_BLEPSQUARE}, {"bleptriangle", OP_BLEPTRIANGLE},
-        {"mc.table", OP_TABLE}, {"mc.sample", OP_MCSAMPLE}, {"mc.sampleseq", OP_SAMPLESEQ}, {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2}, {"sample", OP_SAMPLE}, {"meter", OP_METER}, {"snapshot", OP_SNAPSHOT}, {"scope", OP_SCOPE},
+        {"mc.table", OP_TABLE}, {"mc.sample", OP_MCSAMPLE}, {"mc.sampleseq", OP_SAMPLESEQ}, {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2}, {"sparseq", OP_SPARSEQ}, {"capture", OP_CAPTURE}, {"sample", OP_SAMPLE}, {"meter", OP_METER}, {"snapshot", OP_SNAPSHOT}, {"scope", OP_SCOPE},
     };
     return t;
 }
@@ -467,6 +467,10 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
         case OP_MAXHOLD: r[rec::P0] = 0xFFFFFFFFu; break;                         // Core.h:336
         case OP_SEQ:     r[rec::SEQ_HOLD] = 0; r[rec::SEQ_LOOP] = 1; break;       // Core.h:566-568
         case OP_SEQ2:    r[rec::SEQ_HOLD] = 0; r[rec::SEQ_LOOP] = 1; break;       // Seq2.h:157-159
+        case OP_SPARSEQ:                                                          // SparSeq.h:340-368: edgeCount = -1, no loop points, no held event
+            r[rec::SQ_EDGES] = (uint32_t)-1; r[rec::SQ_HOLD] = (uint32_t)-1;
+            r[rec::SQ_LOOP_START] = r[rec::SQ_LOOP_END] = (uint32_t)-1;
+            break;
         case OP_SCOPE:   // Analyzers.h:142-149: ringBuffer(4) of 8192 frames, channels = 1, size = 512
             n.props["channels"] = Value::number(1.0); n.props["size"] = Value::number(512.0);
             break;
@@ -508,6 +512,10 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
     } else if (nn.op == OP_SCOPE) {                                               // Analyzers.h:145: MultiChannelRingBuffer(4) x 8192
         rc = allocRing(nn, 4u * 8192u);
         if (rc == kOk) writeParamPtr(nn, rec::SCP_RING, nn.ring.ptr);
+    } else if (nn.op == OP_CAPTURE) {                                             // Capture.h:17: ringBuffer(1, bitceil(sr))
+        const size_t cap = (size_t)bitceil((int)(size_t)sampleRate);
+        rc = allocRing(nn, cap);
+        if (rc == kOk) { writeParamPtr(nn, rec::CAP_RING, nn.ring.ptr); writeParam(nn, rec::CAP_MASK, (uint32_t)(cap - 1)); }
     }
     return rc;
 }
@@ -782,6 +790,55 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
                 writeParam(n, rec::SPS_INTERP, (uint32_t)(int32_t)v.num);
             }
             break;
+        case OP_SPARSEQ:                                           // SparSeq.h:40-131
+            if (key == "offset") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                if (v.num < 0.0) return kInvalidPropertyValue;
+                writeParam(n, rec::SQ_OFFSET, (uint32_t)(int32_t)(size_t)v.num);
+            }
+            if (key == "loop") {
+                int32_t ls = -1, le = -1;
+                if (!(v.type == Value::Null || (v.isBool() && !v.b))) {
+                    if (!v.isArray()) return kInvalidPropertyType;
+                    if (v.arr.size() < 2 || !v.arr[0].isNumber() || !v.arr[1].isNumber()) return kInvalidPropertyType;   // (the reference reads points[0], points[1] unchecked)
+                    ls = (int32_t)v.arr[0].num; le = (int32_t)v.arr[1].num;
+                }
+                writeParam(n, rec::SQ_NEW_START, (uint32_t)ls);
+                writeParam(n, rec::SQ_NEW_END, (uint32_t)le);
+                writeParam(n, rec::SQ_LOOP_PENDING, 1u);
+            }
+            if (key == "follow") { if (!v.isBool()) return kInvalidPropertyType; writeParam(n, rec::SQ_FOLLOW, v.b ? 1u : 0u); }
+            if (key == "interpolate") { if (!v.isNumber()) return kInvalidPropertyType; writeParam(n, rec::SQ_INTERP, (uint32_t)(int32_t)v.num); }
+            if (key == "tickInterval") {
+                if (!v.isNumber()) return kInvalidPropertyType;
+                if (v.num < 0.0) return kInvalidPropertyValue;
+                const double samples = (double)(float)sampleRate * v.num;       // GraphNode<float>::getSampleRate() * ti
+                uint64_t bits; std::memcpy(&bits, &samples, 8);
+                writeParam(n, rec::SQ_TICK, (uint32_t)(bits & 0xFFFFFFFFu));
+                writeParam(n, rec::SQ_TICK + 1, (uint32_t)(bits >> 32));
+            }
+            if (key == "seq") {
+                if (!v.isArray()) return kInvalidPropertyType;
+                std::map<int32_t, float> events;                                 // std::map::insert: the first event of a tick time stays
+                for (const Value& e : v.arr) {
+                    if (!e.isObject()) return kInvalidPropertyType;
+                    const Value* val = e.find("value"); const Value* tm = e.find("tickTime");
+                    if (!val || !tm || !val->isNumber() || !tm->isNumber()) return kInvalidPropertyType;
+                    events.insert({(int32_t)tm->num, (float)val->num});
+                }
+                const size_t len = events.size();
+                std::vector<uint32_t> blob(2 * len + 1, 0u);                     // [len int32 tick times][len floats]
+                size_t k = 0;
+                for (auto& kv : events) { std::memcpy(&blob[k], &kv.first, 4); std::memcpy(&blob[len + k], &kv.second, 4); ++k; }
+                int rc = allocRing(n, blob.size());
+                if (rc != kOk) return rc;
+                if (dry) std::memcpy(n.ring.ptr, blob.data(), blob.size() * 4);
+                else HIP_OK(hipMemcpy(n.ring.ptr, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+                writeParamPtr(n, rec::SQ_SEQ, n.ring.ptr);
+                writeParam(n, rec::SQ_LEN, (uint32_t)len);
+                writeParam(n, rec::SQ_SEQ_PENDING, 1u);
+            }
+            break;
         case OP_CONVOLVE:                                          // wasm/Convolve.h:34-56
             if (key == "path") {
                 if (!v.isString()) return kInvalidPropertyType;
@@ -987,6 +1044,37 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
             cb("scope", j.c_str(), user);
             continue;
         }
+        if (n.op == OP_CAPTURE) {                                         // Capture.h:60-95: drain the ring into the relay, emit once the gate fell
+            uint32_t cs[5] = {0, 0, 0, 0, 0};                             // write, read, scratch, change, ready
+            HIP_OK(hipMemcpy(cs, dRecs + (size_t)n.rec * kRecDwords + rec::CAP_WRITE, sizeof cs, hipMemcpyDeviceToHost));
+            const uint32_t mask = shadow[(size_t)n.rec * kRecDwords + rec::CAP_MASK], cap = mask + 1u;
+            const uint32_t w = cs[0], r = cs[1];
+            const uint32_t avail = w > r ? w - r : ((cap - (r - w)) & mask);
+            if (avail > 0 && n.ring.ptr) {
+                const size_t at = n.relay.size();
+                n.relay.resize(at + avail);
+                const uint32_t first = std::min(avail, cap - r);
+                HIP_OK(hipMemcpy(n.relay.data() + at, (const float*)n.ring.ptr + r, (size_t)first * 4, hipMemcpyDeviceToHost));
+                if (avail > first) HIP_OK(hipMemcpy(n.relay.data() + at + first, n.ring.ptr, (size_t)(avail - first) * 4, hipMemcpyDeviceToHost));
+                const uint32_t nr = (r + avail) & mask;
+                HIP_OK(hipMemcpy(dRecs + (size_t)n.rec * kRecDwords + rec::CAP_READ, &nr, 4, hipMemcpyHostToDevice));
+                shadow[(size_t)n.rec * kRecDwords + rec::CAP_READ] = nr;
+            }
+            if (cs[4]) {
+                const uint32_t zero = 0u;
+                HIP_OK(hipMemcpy(dRecs + (size_t)n.rec * kRecDwords + rec::CAP_READY, &zero, 4, hipMemcpyHostToDevice));
+                shadow[(size_t)n.rec * kRecDwords + rec::CAP_READY] = 0u;
+                std::string src = "null";
+                auto nm = n.props.find("name");
+                if (nm != n.props.end() && nm->second.isString()) { src = "\""; for (char ch : nm->second.str) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; } src += "\""; }
+                std::string j = "{\"source\": " + src + ", \"data\": [";
+                for (size_t i = 0; i < n.relay.size(); ++i) { if (i) j += ", "; j += numStr(n.relay[i]); }
+                j += "]}";
+                n.relay.clear();
+                cb("capture", j.c_str(), user);
+            }
+            continue;
+        }
         uint32_t st[3] = {0, 0, 0};
         HIP_OK(hipMemcpy(st, dRecs + (size_t)n.rec * kRecDwords + rec::EVT_A, sizeof st, hipMemcpyDeviceToHost));
         if (st[2] == n.eventCount) continue;                             // nothing new since the last relay
@@ -1164,6 +1252,8 @@ int Engine::setOption(const std::string& key, double value) {
     std::lock_guard<std::mutex> control(ctl);
     std::lock_guard<std::mutex> lock(mu);
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
+    if (key == "host_out_direct") { hostOutDirect = value != 0; return kOk; }   // elemhip_process: epilogue writes the pinned host block itself
+    if (key == "spec_blocks") { specBlocks = value != 0; return kOk; }      // elemhip_process through the specialised kernels when it can
     if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(1024, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
     if (key == "debug_build_delay_ms") { debugBuildDelayMs = std::max(0, (int)value); return kOk; }   // tests: stretches the unlocked part of a plan build
     if (key == "mixer_split") { const int v = (int)value; mixerSplit = (v == 2 || v == 4 || v == 8) ? (uint32_t)v : 1u; planStale = true; return kOk; }
@@ -1285,7 +1375,8 @@ int Engine::swapInPending() {   // Runtime.h:277-285: newest sequence wins
     return kOk;
 }
 
-void Engine::enqueueBlock(const Plan& p) {
+void Engine::enqueueBlock(const Plan& p, float* outRing) {
+    if (!outRing) outRing = dOutRing;
     const size_t L = p.levelOffsets.size() - 1;
     for (size_t l = 0; l < L; ++l) {
         const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
@@ -1294,7 +1385,7 @@ void Engine::enqueueBlock(const Plan& p) {
         if (ce > cb) launch_convolve(stream, p.view, dRecs, dHbm, dGlobals, cb, ce - cb);
         if (!p.hosts.empty()) (void)renderHostNodes(p, l);
     }
-    launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, dOutRing);
+    launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, outRing);
 }
 
 // Call-out nodes of launch level `l` (GraphNode::process on the CPU, GraphNode.h:72): drain the stream, bring each node's
@@ -1374,6 +1465,13 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     setInRing(nullptr, 0);
     rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize);
     if (rc != kOk) return rc;
+    // A whole block of a settled sequence whose island shapes are all compiled goes through the specialised kernels as a
+    // launch set of one (stages pipelined inside the workgroup, no interpreter image); everything else block by block.
+    const bool specBlock = specBlocks && n == (size_t)blockSize && p.convs.empty() && specReady(p) && batchEligible(p, nOut);
+    if (specBlock) {
+        rc = ensureHbm(arenaBuffers(p, 1));
+        if (rc != kOk) return rc;
+    }
 
     if (nIn > 0) {
         const size_t floats = nIn * (size_t)blockSize;
@@ -1391,18 +1489,27 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     rc = flushPending();
     if (rc != kOk) return rc;
     curBlockTime = sampleTime;
-    enqueueBlock(p);
+    // the epilogue writes the output block straight into the pinned host buffer (mapped into the device's address space): one
+    // launch and one PCIe write burst less than rendering into HBM and copying back
+    float* outDev = nullptr;
     if (nOut > 0) {
-        const size_t floats = nOut * (size_t)blockSize;
+        const size_t floats = std::max<size_t>(nOut, 1) * (size_t)blockSize;
         if (floats > hOutFloats) {
+            HIP_OK(hipStreamSynchronize(stream));
             if (hOut) (void)hipHostFree(hOut);
+            hOut = nullptr; hOutFloats = 0; hOutDev = nullptr;
             HIP_OK(hipHostMalloc((void**)&hOut, floats * sizeof(float), hipHostMallocDefault));
             hOutFloats = floats;
+            if (hipHostGetDevicePointer((void**)&hOutDev, hOut, 0) != hipSuccess) hOutDev = nullptr;
         }
-        HIP_OK(hipMemcpyAsync(hOut, dOutRing, floats * sizeof(float), hipMemcpyDeviceToHost, stream));
+        outDev = hostOutDirect ? hOutDev : nullptr;
     }
+    if (specBlock) enqueueBatch(p, 1u, outDev);
+    else enqueueBlock(p, outDev);
+    if (nOut > 0 && !outDev) HIP_OK(hipMemcpyAsync(hOut, dOutRing, nOut * (size_t)blockSize * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     HIP_OK(hipGetLastError());
+    if (profUsed) profCollect();
     for (size_t c = 0; c < nOut; ++c) std::memcpy(out[c], hOut + c * blockSize, n * sizeof(float));
     mirrorRootFades(p, (uint32_t)n, (uint32_t)nOut, (uint32_t)nIn);
     hGlobals.sampleTime += (int64_t)n;
@@ -1524,6 +1631,13 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
 
 // A multi-block launch carries no per-block root/tap/convolver bookkeeping: it is used only while every
 // running root's fade is settled (Core.h:28-31) and the plan has neither taps nor convolvers.
+// every island shape of the sequence has its kernel loaded on this device (stateless islands stay with the interpreter kernel)
+bool Engine::specReady(const Plan& p) const {
+    if (specialize == 0 || p.shapes.empty()) return false;
+    for (const Plan::SpecShape& sh : p.shapes) if (!sh.entry->function(device)) return false;
+    return true;
+}
+
 bool Engine::batchEligible(const Plan& p, size_t nOut) const {
     if (!p.taps.empty() || !p.hosts.empty()) return false;
     // convolvers: the multi-block kernels (conv.hip) assume every node's 512-frame input block is empty at the start of a
@@ -1661,7 +1775,8 @@ void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32
     if (mains) launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks);
 }
 
-void Engine::enqueueBatch(const Plan& p, uint32_t batch) {
+void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
+    if (!outRing) outRing = dOutRing;
     const uint32_t arenaFloats = p.numHbmBuffers * (uint32_t)blockSize;
     const size_t L = p.levelOffsets.size() - 1;
     const bool prof = profileLaunches;
@@ -1674,7 +1789,7 @@ void Engine::enqueueBatch(const Plan& p, uint32_t batch) {
         if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)l); }
     }
     if (prof) (void)hipEventRecord(profEvent(), stream);
-    launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, dOutRing, batch, arenaFloats);
+    launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, outRing, batch, arenaFloats);
     if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)L); profSets++; profBlocks += batch; }
 }
 

@@ -84,6 +84,7 @@ struct Node {
     uint32_t convSlices = 1;    // convolve: helper slices its current impulse response wants (conv.hip)
     bool mc = false;            // multi-output node (mc.*): one record per output channel, planned as one entry per channel
     std::vector<uint32_t> chanRecs;   // records of output channels 1, 2, ... (allocated when a plan first needs them)
+    std::vector<float> relay;   // OP_CAPTURE: samples drained from the device ring, waiting for the gate's falling edge (Capture.h:102)
     void* hostInst = nullptr;   // OP_HOST: the instance its type's create() returned
     const HostVTable* hostVt = nullptr;
 };
@@ -216,6 +217,7 @@ private:
     float* dHbm = nullptr; size_t hbmBuffers = 0;
     float* dOutRing = nullptr; size_t outRingFloats = 0;
     float* hOut = nullptr; size_t hOutFloats = 0;     // pinned
+    float* hOutDev = nullptr;                          // hOut as the device sees it (mapped)
     float* hIn = nullptr; size_t hInFloats = 0;       // pinned
     std::vector<void*> deferredFree;
 
@@ -233,6 +235,8 @@ private:
     uint32_t maxLdsConfigured = 0;
     bool useGraph = true;
     int  graphBlocks = 8;
+    bool hostOutDirect = true;             // process(): the epilogue kernel writes into the mapped pinned output block
+    bool specBlocks = true;                // process(): whole blocks of a settled, fully compiled sequence use the specialised kernels
     int  batchBlocks = 64;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)
     int  pipelineCopies = 6;               // blocks a stateful island keeps in flight inside a multi-block launch
     bool convAligned = true;               // every process call so far rendered whole 512-frame blocks (conv.hip batch path)
@@ -282,12 +286,13 @@ private:
     size_t maxSetBlocks(const Plan& p) const;
     int  ensureOutRing(size_t floats);
     int  swapInPending();
-    void enqueueBlock(const Plan& p);
+    void enqueueBlock(const Plan& p, float* outRing = nullptr);
     int  renderHostNodes(const Plan& p, size_t level);   // call-out nodes of one launch level (synchronises the stream)
-    void enqueueBatch(const Plan& p, uint32_t batch);
+    void enqueueBatch(const Plan& p, uint32_t batch, float* outRing = nullptr);
     void launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32_t arenaFloats);
     void launchLevelBatch(const Plan& p, size_t level, uint32_t batch, uint32_t arenaFloats);   // specialised kernels when ready, else the interpreter
     bool batchEligible(const Plan& p, size_t nOut) const;
+    bool specReady(const Plan& p) const;
     void mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn);
     int  setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime);
     void setInRing(const float* ring, uint32_t blocks);

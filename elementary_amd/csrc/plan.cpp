@@ -33,11 +33,11 @@ enum Kind : uint8_t { K_CONST, K_PAR, K_SINGLE, K_CHAIN, K_CONV, K_HOST };
 Kind kindOf(uint16_t op) {
     switch (op) {
         case OP_CONST: case OP_SR: return K_CONST;
-        case OP_RAND: case OP_Z: case OP_SDELAY: case OP_DELAY: case OP_SAMPLESEQ: case OP_METER: case OP_SNAPSHOT: case OP_SCOPE: return K_SINGLE;
+        case OP_RAND: case OP_Z: case OP_SDELAY: case OP_DELAY: case OP_SAMPLESEQ: case OP_METER: case OP_SNAPSHOT: case OP_SCOPE: case OP_CAPTURE: return K_SINGLE;
         case OP_CONVOLVE: return K_CONV;   // always an island of its own, rendered by conv.hip
         case OP_HOST: return K_HOST;       // always an island of its own, rendered on the CPU between launch levels
         case OP_PHASOR: case OP_SPHASOR: case OP_COUNTER: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD:
-        case OP_ONCE: case OP_SEQ: case OP_SEQ2: case OP_SAMPLE: case OP_MCSAMPLE: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
+        case OP_ONCE: case OP_SEQ: case OP_SEQ2: case OP_SPARSEQ: case OP_SAMPLE: case OP_MCSAMPLE: case OP_POLE: case OP_ENV: case OP_BIQUAD: case OP_MM1P: case OP_SVF:
         case OP_SVFSHELF: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE: case OP_PHASE:
             return K_CHAIN;
         default: return K_PAR;
@@ -60,7 +60,7 @@ uint32_t leafArity(uint16_t op) {
     switch (op) {
         case OP_PHASOR: case OP_COUNTER: case OP_ONCE: case OP_BLEPSAW: case OP_BLEPSQUARE: case OP_BLEPTRIANGLE:
         case OP_Z: case OP_SDELAY: case OP_PREWARP: case OP_ROOT: case OP_TAPOUT: case OP_SAMPLESEQ: case OP_MCSAMPLE: return 1;
-        case OP_SPHASOR: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_SEQ: case OP_SEQ2: case OP_SAMPLE: case OP_POLE: case OP_MM1P: case OP_SNAPSHOT: return 2;
+        case OP_SPHASOR: case OP_ACCUM: case OP_LATCH: case OP_MAXHOLD: case OP_SEQ: case OP_SEQ2: case OP_SPARSEQ: case OP_CAPTURE: case OP_SAMPLE: case OP_POLE: case OP_MM1P: case OP_SNAPSHOT: return 2;
         case OP_ENV: case OP_SVF: case OP_DELAY: return 3;
         case OP_SCOPE: return 4;
         case OP_SVFSHELF: return 4;
@@ -1327,7 +1327,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         p.roots.push_back(RootEntry{r->rec, x.hbm});
         p.rootIds.push_back(r->id);
         for (int k : seqNodes[s]) if (ni[k].n->op == OP_TAPOUT) p.taps.push_back(TapEntry{ni[k].n->rec, r->rec});
-        for (int k : seqNodes[s]) if (ni[k].n->op == OP_METER || ni[k].n->op == OP_SNAPSHOT || ni[k].n->op == OP_SCOPE) p.eventNodes.push_back({ni[k].n->id, r->id});
+        for (int k : seqNodes[s]) if (ni[k].n->op == OP_METER || ni[k].n->op == OP_SNAPSHOT || ni[k].n->op == OP_SCOPE || ni[k].n->op == OP_CAPTURE) p.eventNodes.push_back({ni[k].n->id, r->id});
     }
     phase("levels, roots");
     return plan;

@@ -107,6 +107,16 @@ def sparseq2(props: Dict[str, Any], t: ElemNode) -> NodeRepr:
     return _n("sparseq2", props, t)
 
 
+def sparseq(props: Dict[str, Any], trigger: ElemNode, reset: ElemNode) -> NodeRepr:
+    """core.ts:131-144: props {seq: [{value, tickTime}], offset, loop: False | [start, end], follow, interpolate, tickInterval}."""
+    return _n("sparseq", props, trigger, reset)
+
+
+def capture(props: Dict[str, Any], g: ElemNode, x: ElemNode) -> NodeRepr:
+    """core.ts:348-356: records x while the gate g is non-zero; the recording arrives as a "capture" event."""
+    return _n("capture", props, g, x)
+
+
 def sampleseq(props: Dict[str, Any], t: ElemNode) -> NodeRepr:
     return _n("sampleseq", props, t)
 

@@ -120,7 +120,7 @@ enum Kind {
     K_ADD, K_SUB, K_MUL, K_DIV, K_MOD, K_MIN, K_MAX,
     K_ROOT, K_CONST, K_PHASOR, K_SPHASOR, K_SR, K_SEQ, K_COUNTER, K_ACCUM, K_LATCH, K_MAXHOLD, K_ONCE, K_RAND,
     K_DELAY, K_SDELAY, K_Z, K_POLE, K_ENV, K_BIQUAD, K_PREWARP, K_MM1P, K_SVF, K_SVFSHELF, K_TAPIN, K_TAPOUT,
-    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ, K_CONVOLVE, K_TABLE, K_SEQ2, K_SPARSEQ2, K_SAMPLE, K_METER, K_SNAPSHOT, K_SCOPE,
+    K_BLEPSAW, K_BLEPSQUARE, K_BLEPTRIANGLE, K_TIME, K_METRO, K_SAMPLESEQ, K_CONVOLVE, K_TABLE, K_SEQ2, K_SPARSEQ2, K_SAMPLE, K_METER, K_SNAPSHOT, K_SCOPE, K_SPARSEQ, K_CAPTURE,
 };
 
 // registry names: runtime/elem/DefaultNodeTypes.h:49-144 (hot-path subset) + wasm/Main.cpp:47-61
@@ -136,7 +136,7 @@ const std::unordered_map<std::string, Kind>& registry() {
         {"sdelay", K_SDELAY}, {"z", K_Z}, {"pole", K_POLE}, {"env", K_ENV}, {"biquad", K_BIQUAD}, {"prewarp", K_PREWARP},
         {"mm1p", K_MM1P}, {"svf", K_SVF}, {"svfshelf", K_SVFSHELF}, {"tapIn", K_TAPIN}, {"tapOut", K_TAPOUT},
         {"blepsaw", K_BLEPSAW}, {"blepsquare", K_BLEPSQUARE}, {"bleptriangle", K_BLEPTRIANGLE}, {"time", K_TIME},
-        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ}, {"convolve", K_CONVOLVE}, {"table", K_TABLE}, {"seq2", K_SEQ2}, {"sparseq2", K_SPARSEQ2}, {"sample", K_SAMPLE}, {"meter", K_METER}, {"snapshot", K_SNAPSHOT}, {"scope", K_SCOPE},
+        {"metro", K_METRO}, {"sampleseq", K_SAMPLESEQ}, {"convolve", K_CONVOLVE}, {"table", K_TABLE}, {"seq2", K_SEQ2}, {"sparseq2", K_SPARSEQ2}, {"sample", K_SAMPLE}, {"meter", K_METER}, {"snapshot", K_SNAPSHOT}, {"scope", K_SCOPE}, {"sparseq", K_SPARSEQ}, {"capture", K_CAPTURE},
     };
     return r;
 }
@@ -199,6 +199,14 @@ struct Node {
     SeqReader readers[2]; size_t activeReader = 0; size_t sampleLen = 0, pendingSampleLen = 0;
     size_t sampleBufSize() const { return sampleLen; }
     int32_t interp = 0;          // sparseq2
+    // sparseq (SparSeq.h:17-372): change queue restated as "pending" fields drained at the top of process()
+    std::map<int32_t, float> tickSeq, newTickSeq; bool pendingTickSeq = false, haveTickSeq = false;
+    int32_t loopStart = -1, loopEnd = -1, newLoopStart = -1, newLoopEnd = -1; bool loopEvent = false, pendingLoop = false;
+    int32_t pendLoopStart = -1, pendLoopEnd = -1;
+    bool follow = false; int32_t holdOrder = 0; double tickInterval = 0.0;
+    int32_t edgeCount = -1; size_t samplesSinceEdge = 0; bool holdValid = false; int32_t holdKey = 0;
+    // capture (Capture.h:13-104): 128-frame scratch -> ring of bitceil(sr) frames -> relay
+    std::vector<float> capRing, capRelay; size_t capW = 0, capR = 0, capScratchSize = 0; float capScratch[128]; bool capReady = false;
     // meter / snapshot readouts (Analyzers.h): the relay reports the newest one and clears the queue
     bool haveReadout = false; float roMin = 0, roMax = 0, roVal = 0;
     // scope (Analyzers.h:137-250): MultiChannelRingBuffer(4) of 8192 frames
@@ -357,6 +365,32 @@ struct Oracle {
                 if (key == "mode") { if (!str) return 5; if (v.s == "trigger") n.sampleMode = 0; if (v.s == "gate") n.sampleMode = 1; if (v.s == "loop") n.sampleMode = 2; }
                 if (key == "startOffset") { if (!num) return 5; const int vi = (int)v.n; if (vi < 0) return 6; n.startOffset = (size_t)vi; }
                 if (key == "stopOffset") { if (!num) return 5; const int vi = (int)v.n; if (vi < 0) return 6; n.stopOffset = (size_t)vi; }
+                break;
+            case K_SPARSEQ:                                                                               // SparSeq.h:40-131
+                if (key == "offset") { if (!num) return 5; if (v.n < 0) return 6; n.seqOffset = (size_t)v.n; }
+                if (key == "loop") {
+                    if (v.t == JV::Null || (boo && !v.b)) { n.newLoopStart = -1; n.newLoopEnd = -1; n.loopEvent = true; }
+                    else {
+                        if (v.t != JV::Arr) return 5;
+                        if (v.a.size() < 2 || v.a[0].t != JV::Num || v.a[1].t != JV::Num) return 5;
+                        n.newLoopStart = (int32_t)v.a[0].n; n.newLoopEnd = (int32_t)v.a[1].n; n.loopEvent = true;
+                    }
+                }
+                if (key == "follow") { if (!boo) return 5; n.follow = v.b; }
+                if (key == "interpolate") { if (!num) return 5; n.holdOrder = (int32_t)v.n; }
+                if (key == "tickInterval") { if (!num) return 5; if (v.n < 0) return 6; n.tickInterval = (double)(float)sr * v.n; }
+                if (key == "seq") {
+                    if (v.t != JV::Arr) return 5;
+                    std::map<int32_t, float> m;
+                    for (const JV& e : v.a) {
+                        if (e.t != JV::Obj) return 5;
+                        const JV* val = nullptr; const JV* tm = nullptr;
+                        for (auto& kv : e.o) { if (kv.first == "value") val = &kv.second; if (kv.first == "tickTime") tm = &kv.second; }
+                        if (!val || !tm || val->t != JV::Num || tm->t != JV::Num) return 5;
+                        m.insert({(int32_t)tm->n, (float)val->n});
+                    }
+                    n.newTickSeq.swap(m); n.pendingTickSeq = true;
+                }
                 break;
             case K_SCOPE:                                                                                 // Analyzers.h:151-173
                 if (key == "size") { if (!num) return 5; if (v.n < 256 || v.n > 8192) return 6; }
@@ -853,6 +887,95 @@ struct Oracle {
                 n.scopeR = N >= freeSlots ? ((nw + 1) & mask) : r;
                 break;
             }
+            case K_SPARSEQ: {                                                                             // SparSeq.h:201-335
+                const int32_t offset = (int32_t)n.seqOffset;
+                auto getTickTime = [&]() -> int32_t {                                                     // :154-199
+                    int32_t tickTime = offset + n.edgeCount;
+                    const int32_t ls = n.loopStart, le = n.loopEnd;
+                    if (ls > -1 && le > -1 && tickTime >= le) {
+                        const int32_t dur = le - ls;
+                        if (dur > 0) {
+                            if (n.pendingLoop) {
+                                n.loopStart = n.pendLoopStart; n.loopEnd = n.pendLoopEnd; n.pendingLoop = false;
+                                const int32_t nls = n.loopStart, nle = n.loopEnd;
+                                if (nls == -1 && nle == -1) return tickTime;
+                                tickTime = nls + ((nle - nls) != 0 ? (tickTime - le) % (nle - nls) : 0);   // (% 0: undefined in the reference)
+                            } else {
+                                tickTime = ls + ((tickTime - le) % dur);
+                            }
+                            n.edgeCount = tickTime - offset;
+                        }
+                    }
+                    return tickTime;
+                };
+                auto findTickValue = [&](int32_t tickTime) {                                              // :133-152
+                    auto& m = n.tickSeq;
+                    if (m.empty()) { n.holdValid = false; return; }
+                    auto it2 = m.upper_bound(tickTime);
+                    if (it2 == m.begin()) { if (it2->first == 0) { n.holdValid = true; n.holdKey = 0; } else n.holdValid = false; return; }
+                    --it2; n.holdValid = true; n.holdKey = it2->first;
+                };
+                int32_t tickTime = getTickTime();
+                if (n.pendingTickSeq || n.loopEvent) {
+                    if (n.pendingTickSeq) { n.tickSeq.swap(n.newTickSeq); n.pendingTickSeq = false; n.haveTickSeq = true; }
+                    if (n.loopEvent) { n.pendingLoop = true; n.pendLoopStart = n.newLoopStart; n.pendLoopEnd = n.newLoopEnd; n.loopEvent = false; }
+                    if (n.haveTickSeq) findTickValue(tickTime); else n.holdValid = false;
+                }
+                if (n.pendingLoop && ((n.loopStart == -1 && n.loopEnd == -1) || !n.follow)) {
+                    n.loopStart = n.pendLoopStart; n.loopEnd = n.pendLoopEnd; n.pendingLoop = false;
+                    tickTime = getTickTime();
+                }
+                if (nIn < 1 || !n.haveTickSeq) { zero(); break; }
+                const bool hasReset = nIn > 1;
+                for (size_t i = 0; i < N; ++i) {
+                    n.samplesSinceEdge++;
+                    const float x = in[0][i], reset = hasReset ? in[1][i] : 0.0f;
+                    const bool trig = changeTick(n.f1, x) > 0.5f, rst = changeTick(n.f2, reset) > 0.5f;
+                    if (rst) n.edgeCount = 0;
+                    if (trig) {
+                        n.edgeCount = rst ? 0 : n.edgeCount + 1;
+                        n.samplesSinceEdge = 0;
+                        tickTime = getTickTime();
+                        findTickValue(tickTime);
+                    }
+                    if (!n.holdValid) { out[i] = 0.0f; continue; }
+                    auto hv = n.tickSeq.find(n.holdKey);
+                    if (n.holdOrder == 1) {
+                        auto hr = std::next(hv);
+                        if (hr == n.tickSeq.end()) { out[i] = hv->second; continue; }
+                        const int32_t tl = hv->first, tr = hr->first;
+                        const float lv = hv->second, rv = hr->second;
+                        double alpha = (double)std::max(0, tickTime - tl) / (double)(tr - tl);
+                        if (n.tickInterval > 0.0) alpha += (std::min((double)n.samplesSinceEdge, n.tickInterval) / n.tickInterval) / (double)(tr - tl);
+                        out[i] = (float)(lv + alpha * (rv - lv));
+                    } else {
+                        out[i] = hv->second;
+                    }
+                }
+                break;
+            }
+            case K_CAPTURE: {                                                                             // Capture.h:21-58
+                if (nIn < 2) { zero(); break; }
+                std::copy_n(in[1], N, out);
+                if (n.capRing.empty()) n.capRing.assign((size_t)bitceil((int)(size_t)sr), 0.0f);
+                const size_t cap = n.capRing.size(), mask = cap - 1;
+                for (size_t i = 0; i < N; ++i) {
+                    const bool g = (bool)in[0][i];
+                    const bool falling = changeTick(n.f1, in[0][i]) < -0.5f;
+                    if (falling || n.capScratchSize >= 128) {                                             // MultiChannelRingBuffer::write (:34-59)
+                        const size_t w = n.capW, r = n.capR, cnt = n.capScratchSize;
+                        const size_t freeSlots = r > w ? r - w : cap - (w - r);
+                        const size_t nw = (w + cnt) & mask;
+                        for (size_t k = 0; k < cnt; ++k) n.capRing[(w + k) & mask] = n.capScratch[k];
+                        n.capW = nw;
+                        n.capR = cnt >= freeSlots ? ((nw + 1) & mask) : r;
+                        n.capScratchSize = 0;
+                        if (falling) n.capReady = true;
+                    }
+                    if (g) n.capScratch[n.capScratchSize++] = in[1][i];
+                }
+                break;
+            }
             case K_METER: {                                                                               // Analyzers.h:23-41
                 if (nIn < 1) { zero(); break; }
                 std::copy_n(in[0], N, out);
@@ -1012,6 +1135,26 @@ struct Oracle {
                     j += "]}";
                     n.scopeR = (r + size) & mask;
                     cb("scope", j.c_str(), user);
+                    continue;
+                }
+                if (n.kind == K_CAPTURE) {                                                                // Capture.h:60-95
+                    if (!n.capRing.empty()) {
+                        const size_t cap = n.capRing.size(), mask = cap - 1, w = n.capW, r = n.capR;
+                        const size_t avail = w > r ? w - r : ((cap - (r - w)) & mask);
+                        for (size_t k = 0; k < avail; ++k) n.capRelay.push_back(n.capRing[(r + k) & mask]);
+                        n.capR = (r + avail) & mask;
+                    }
+                    if (n.capReady) {
+                        n.capReady = false;
+                        std::string src = "null";
+                        auto nm = n.props.find("name");
+                        if (nm != n.props.end() && nm->second.t == JV::Str) { src = "\""; for (char ch : nm->second.s) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; } src += "\""; }
+                        std::string j = "{\"source\": " + src + ", \"data\": [";
+                        for (size_t k = 0; k < n.capRelay.size(); ++k) { if (k) j += ", "; j += numStr(n.capRelay[k]); }
+                        j += "]}";
+                        n.capRelay.clear();
+                        cb("capture", j.c_str(), user);
+                    }
                     continue;
                 }
                 if ((n.kind != K_METER && n.kind != K_SNAPSHOT) || !n.haveReadout) continue;

@@ -81,6 +81,13 @@ NODE_CASES = {
                           el.sparseq2({"interpolate": 1, "seq": [{"time": 0, "value": 0}, {"time": 1000, "value": 1}, {"time": 3000, "value": -2}]},
                                       el.add(500, el.mod(el.time(), 2800))),
                           el.sparseq2({"interpolate": 1, "seq": [{"time": 0.25, "value": 1}, {"time": 0.5, "value": 3}]}, el.add(0.4, el.mul(0.8, X())))], 1),
+    "sparseq": (lambda: [el.sparseq({"seq": [{"value": 1, "tickTime": 0}, {"value": 2, "tickTime": 2}, {"value": -3, "tickTime": 5}, {"value": 4, "tickTime": 9},
+                                             {"value": 7, "tickTime": 2}], "loop": [2, 7]}, el.train(210.0), el.train(3.0)),
+                         el.sparseq({"seq": [{"value": 0.5, "tickTime": 1}, {"value": 2.5, "tickTime": 4}, {"value": -1, "tickTime": 12}],
+                                     "interpolate": 1, "tickInterval": 0.004, "offset": 1}, el.train(250.0), 0),
+                         el.sparseq({"seq": [{"value": 3, "tickTime": 3}, {"value": 6, "tickTime": 40}], "interpolate": 1}, el.train(900.0), el.train(11.0)),
+                         el.sparseq({"seq": [{"value": 1, "tickTime": 0}], "loop": False}, X(), 0)], 1),
+    "capture": (lambda: [el.capture({"name": "c"}, el.train(15.0), X()), el.capture({}, el.ge(X(1), 0.0), el.mul(2.0, X(0)))], 2),
     "sample": (lambda: [el.sample({"path": "/t/ramp"}, el.train(90.0), 1.0),
                         el.sample({"path": "/t/ramp", "mode": "gate"}, el.train(40.0), el.add(1.5, X())),
                         el.sample({"path": "/t/ramp", "mode": "loop", "startOffset": 20, "stopOffset": 50}, el.train(5.0), 0.37),

@@ -3,7 +3,7 @@
 
 Run in the authoring container only (needs /root/reference):  python tests/golden/make_golden.py
 Sources (jest snapshot files of the reference, recorded through its wasm engine):
-  js/packages/offline-renderer/__tests__/__snapshots__/{delays,tap,time,offline-renderer,sampleseq,maxhold,sparseq2,vfs,mc}.test.js.snap
+  js/packages/offline-renderer/__tests__/__snapshots__/{delays,tap,time,offline-renderer,sampleseq,maxhold,sparseq2,sparseq,vfs,mc}.test.js.snap
   js/packages/core/__tests__/__snapshots__/core.test.js.snap   (instruction batches with real int32 hashes)
   js/packages/core/__tests__/__snapshots__/hashing.test.js.snap (the same with masked hashes: 69-node synth voice)
 Only Float32Array snapshots and instruction-batch snapshots are transcribed; the scenarios that
@@ -40,7 +40,7 @@ def js_value(body):
 
 def main():
     audio = {}
-    for name in ("delays", "tap", "time", "offline-renderer", "sampleseq", "maxhold", "sparseq2", "vfs", "mc"):
+    for name in ("delays", "tap", "time", "offline-renderer", "sampleseq", "maxhold", "sparseq2", "sparseq", "vfs", "mc"):
         snaps = parse_snap(f"{REF}/offline-renderer/__tests__/__snapshots__/{name}.test.js.snap")
         for key, body in snaps.items():
             if body.startswith("Float32Array ["):

@@ -178,3 +178,26 @@ def test_spec_other_block_sizes(gpu_required, bs):
         _assert_ran_specialised(a)
         scale = max(1.0, float(np.abs(ref).max()))
         assert float(np.abs(got - ref).max()) <= TOL * scale, (bs, float(np.abs(got - ref).max()))
+
+
+@pytest.mark.parametrize("voices", [8, 48])
+def test_process_uses_the_specialised_kernels_block_by_block(gpu_required, voices):
+    """elemhip_process (Runtime::process, Runtime.h:274-291): once the root fades have settled and every island shape is
+    compiled, a whole block is a launch set of one through the specialised kernels; partial blocks, and everything with
+    `spec_blocks = 0`, keep to the interpreter kernels. All three agree with the reference engine and the two engines with
+    each other bit for bit (shared op bodies)."""
+    a, b, c = _spec_runtime(graphs.C2_SAMPLE_RATE, 512), _spec_runtime(graphs.C2_SAMPLE_RATE, 512), _checker(graphs.C2_SAMPLE_RATE, 512)
+    b.set_option("spec_blocks", 0)
+    roots = graphs.c2_graph(voices=voices)
+    for rt in (a, b, c):
+        assert rt.render(*roots)["result"] == 0
+    sizes = [512] * 40 + [200, 312] + [512] * 10
+    before = None
+    for k, n in enumerate(sizes):
+        ya, yb, yc = a.process(None, 2, n), b.process(None, 2, n), c.process(None, 2, n)
+        assert float(np.abs(ya - yc).max()) <= TOL * max(1.0, float(np.abs(yc).max())), k
+        assert np.array_equal(ya, yb), k
+        if k == 30:
+            before = a.stats()["spec_launches"]
+    assert before is not None and a.stats()["spec_launches"] >= before + 19        # blocks 31..39 and 42..51
+    assert b.stats()["spec_launches"] == 0

@@ -219,6 +219,109 @@ def test_sparseq2_snapshots(core_factory):
     core_factory.same(out[0], GOLD["sparseq2:sparseq2 skip ahead 1"])
 
 
+_TICKS = [{"value": 1, "tickTime": 0}, {"value": 2, "tickTime": 2}, {"value": 3, "tickTime": 4}, {"value": 4, "tickTime": 8}]
+
+
+def _sparseq_core(core_factory, props, reset=0, sample_rate=None):
+    kw = {"num_input_channels": 1, "num_output_channels": 1}
+    if sample_rate:
+        kw["sample_rate"] = sample_rate
+    core = core_factory(**kw)
+    core.render(el.sparseq(props, el.in_({"channel": 0}), reset))
+    core.process([f32(5120)], [f32(5120)])                  # past the root fade-in
+    return core
+
+
+def _clock(n):
+    return np.asarray([(i + 1) % 2 for i in range(n)], np.float32)
+
+
+def _drive(core, x):
+    out = [f32(len(x))]
+    core.process([np.asarray(x, np.float32)], out)
+    return out[0]
+
+
+def test_sparseq_snapshots(core_factory):
+    """sparseq.test.js:5-41 (basics), :43-77 (loop), :79-125 (loop on then off), :127-176 (no trigger on reset),
+    :178-214 (interpolation), :216-250 (interpolation with loop), :396-441 (loop follow)."""
+    core = _sparseq_core(core_factory, {"seq": _TICKS})
+    core_factory.same(_drive(core, [0] + [1, 0] * 12), GOLD["sparseq:sparseq basics 1"])
+
+    core = _sparseq_core(core_factory, {"seq": _TICKS, "loop": [2, 4]})
+    core_factory.same(_drive(core, _clock(32)), GOLD["sparseq:sparseq loop 1"])
+
+    core = _sparseq_core(core_factory, {"key": "test", "seq": _TICKS, "loop": [2, 4]})
+    _drive(core, _clock(32))
+    core.render(el.sparseq({"key": "test", "seq": _TICKS, "loop": False}, el.in_({"channel": 0}), 0))
+    core_factory.same(_drive(core, _clock(32)), GOLD["sparseq:sparseq loop on then off 1"])
+
+    core = _sparseq_core(core_factory, {"seq": _TICKS, "loop": False}, reset=el.const({"key": "reset", "value": 0}))
+    _drive(core, _clock(8))
+    core.render(el.sparseq({"seq": _TICKS, "loop": False}, el.in_({"channel": 0}), el.const({"key": "reset", "value": 1})))
+    core_factory.same(_drive(core, np.zeros(8)), GOLD["sparseq:sparseq no trigger on reset 1"])
+
+    core = _sparseq_core(core_factory, {"seq": _TICKS, "interpolate": 1})
+    core_factory.same(_drive(core, _clock(24)), GOLD["sparseq:sparseq interpolation 1"])
+
+    core = _sparseq_core(core_factory, {"seq": _TICKS, "interpolate": 1, "loop": [1, 3]})
+    core_factory.same(_drive(core, _clock(24)), GOLD["sparseq:sparseq interpolation with loop 1"])
+
+    seq = [{"value": k + 1, "tickTime": k} for k in range(4)]
+    core = _sparseq_core(core_factory, {"key": "test", "seq": seq, "loop": [1, 3]})
+    core_factory.same(_drive(core, _clock(32)), GOLD["sparseq:sparseq loop follow 1"])
+    core.render(el.sparseq({"key": "test", "seq": seq, "loop": [0, 2], "follow": True}, el.in_({"channel": 0}), 0))
+    core_factory.same(_drive(core, _clock(32)), GOLD["sparseq:sparseq loop follow 2"])
+
+
+def test_sparseq_sub_tick_snapshots(core_factory):
+    """sparseq.test.js:252-302 (sub-tick interpolation, then the clock stops), :304-341 (with loop), :343-394 (higher
+    resolution, el.train clock at sr 2000)."""
+    props = {"seq": _TICKS, "interpolate": 1, "tickInterval": 0.002}
+    core = _sparseq_core(core_factory, props, reset=el.const({"key": "reset", "value": 0}), sample_rate=1000)
+    core_factory.same(_drive(core, _clock(24)), GOLD["sparseq:sparseq sub-tick interpolation 1"])
+    core.render(el.sparseq(props, el.in_({"channel": 0}), el.const({"key": "reset", "value": 1})))
+    core_factory.same(_drive(core, [0 if i > 7 else (i + 1) % 2 for i in range(24)]), GOLD["sparseq:sparseq sub-tick interpolation 2"])
+
+    ramp = [{"value": 0, "tickTime": 0}, {"value": 0, "tickTime": 4}, {"value": 1, "tickTime": 8}]
+    core = _sparseq_core(core_factory, {"seq": ramp, "interpolate": 1, "tickInterval": 0.002, "loop": [4, 8], "offset": 4}, sample_rate=1000)
+    core_factory.same(_drive(core, _clock(24)), GOLD["sparseq:sparseq sub-tick interpolation with loop 1"])
+
+    core = core_factory(num_input_channels=1, num_output_channels=1, sample_rate=2000)
+    core.render(el.sparseq({"seq": ramp, "interpolate": 1, "tickInterval": 0.01, "loop": [4, 8], "offset": 4}, el.train(100), 0))
+    core.process([f32(5120)], [f32(5120)])
+    core_factory.same(_drive(core, np.zeros(512)), GOLD["sparseq:sparseq sub-tick interpolation with loop higher res 1"])
+
+
+def test_capture_events(core_factory):
+    """Capture.h:21-95: the recording is relayed once the gate has fallen, with everything the ring held by then; a recording
+    longer than the 128-frame scratch arrives whole; `name` becomes `source`."""
+    core = core_factory(num_input_channels=2, num_output_channels=1, block_size=64)
+    calls = []
+    core.on("capture", calls.append)
+    core.render(el.capture({"name": "take"}, el.in_({"channel": 0}), el.in_({"channel": 1})))
+    core.process([f32(64 * 20), f32(64 * 20)], [f32(64 * 20)])              # past the root fade-in, gate closed
+    assert calls == []
+    n = 64 * 12
+    gate = np.zeros(n, np.float32)
+    gate[70:75] = 1.0                     # a short take inside one block
+    gate[200:500] = 0.5                   # a long one over several blocks and scratch flushes
+    gate[600:n] = 1.0                     # still open at the end: nothing relayed for it
+    x = (np.arange(n, dtype=np.float32) * 0.001 + 0.25).astype(np.float32)
+    out = [f32(n)]
+    core.process([gate, x], out)
+    assert np.array_equal(out[0], x)                                          # pass-through of input 1
+    assert [c["source"] for c in calls] == ["take", "take"]
+    assert np.allclose(calls[0]["data"], x[70:75], rtol=0, atol=0)
+    assert np.allclose(calls[1]["data"], x[200:500], rtol=0, atol=0)
+    calls.clear()
+    gate2 = np.zeros(128, np.float32)
+    gate2[:10] = 1.0
+    x2 = np.full(128, -0.5, np.float32)
+    core.process([gate2, x2], [f32(128)])
+    assert len(calls) == 1 and np.allclose(calls[0]["data"], np.concatenate([x[600:n], x2[:10]]), rtol=0, atol=0)
+
+
 def test_vfs_table_snapshot(core_factory):
     """vfs.test.js:5-35: el.table over a virtual-file-system buffer."""
     core = core_factory(num_input_channels=1, num_output_channels=1,
