@@ -948,6 +948,13 @@ int Engine::commit(std::unique_lock<std::mutex>& renderLock) {   // Runtime.h:20
         // the rebuild stays owed so that the next commit retries instead of rendering the old sequence forever.)
         if (!p) { rebuildOwed = true; return kUnsupportedGraph; }
         rebuildOwed = false;
+        for (auto& pr : p->tapPairs) {        // a tapIn's record names the private buffer of the tapOut it follows inside a launch set
+            auto tin = nodes.find(pr.first);
+            if (tin == nodes.end()) continue;
+            void* priv = nullptr;
+            if (pr.second) { auto tout = nodes.find(pr.second); if (tout != nodes.end()) priv = tout->second.ring.ptr; }
+            writeParamPtr(tin->second, rec::TAP_PRIVATE, priv);
+        }
         pending = p;
         shouldRebuild = false;
         st.plansBuilt++;
@@ -1639,7 +1646,7 @@ bool Engine::specReady(const Plan& p) const {
 }
 
 bool Engine::batchEligible(const Plan& p, size_t nOut) const {
-    if (!p.taps.empty() || !p.hosts.empty()) return false;
+    if ((!p.taps.empty() && !p.tapsInSets) || !p.hosts.empty()) return false;
     // convolvers: the multi-block kernels (conv.hip) assume every node's 512-frame input block is empty at the start of a
     // launch set, i.e. that every call so far rendered whole 512-frame blocks
     if (!p.convs.empty() && !(convAligned && blockSize == (int)conv::kBlock)) return false;

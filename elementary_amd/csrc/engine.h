@@ -319,6 +319,8 @@ struct Plan {
     uint32_t numTasks = 0, numMembers = 0, numOperands = 0;
     std::vector<RootEntry> roots;
     std::vector<TapEntry> taps;
+    bool tapsInSets = true;                                  // every tapIn / tapOut pair sits in one island: launch sets may render this plan (plan.cpp)
+    std::vector<std::pair<int32_t, int32_t>> tapPairs;       // (tapIn node id, id of the in-island tapOut whose private buffer it reads inside a launch set, or 0)
     std::vector<std::pair<int32_t, int32_t>> eventNodes;   // (node id, owning root id) of meter / snapshot nodes, render order
     std::vector<ConvDesc> convs;           // convolve nodes (conv.hip)
     std::vector<uint32_t> convWork;        // conv workgroups, level-major

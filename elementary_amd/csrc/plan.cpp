@@ -504,6 +504,39 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     }
 
     phase("islands");
+    // ---- taps inside launch sets (Feedback.h:90-126, GraphRenderSequence.h:297-308) --------------------
+    // A tapIn of block b+1 reads what the tapOut of its name received in block b (the end-of-block promotion). A launch
+    // set renders its blocks level by level, so that hand-over can only happen inside ONE island: the island keeps a single
+    // block in flight (copies = 1: block b+1 starts when block b has left it), the tapOut sits at least one stage behind its
+    // tapIns, and a tapIn reads the tapOut's private buffer for every block but the set's first (run_tapin); the batch
+    // epilogue promotes once, after the set. Anything else — a name written by two tapOuts, or read in another island
+    // than the one that writes it — keeps the plan on the block-at-a-time path (Engine::batchEligible).
+    std::vector<int> tapWriter(ni.size(), -1);      // tapIn NI index -> NI index of the tapOut it is paired with
+    std::vector<char> islandPairsTaps(ib.size(), 0);
+    p.tapsInSets = true;
+    p.tapPairs.clear();
+    {
+        std::map<const void*, std::vector<int>> outs, ins;
+        for (size_t k = 0; k < ni.size(); ++k) {
+            if (ni[k].island < 0 || !ni[k].n->res) continue;
+            if (ni[k].n->op == OP_TAPOUT) outs[ni[k].n->res.get()].push_back((int)k);
+            if (ni[k].n->op == OP_TAPIN) ins[ni[k].n->res.get()].push_back((int)k);
+        }
+        for (auto& kv : outs) {
+            std::vector<int> uniq;                   // (a tapOut shared by two roots appears once per NI entry of its id)
+            for (int k : kv.second) { bool seen = false; for (int u : uniq) seen = seen || ni[u].n == ni[k].n; if (!seen) uniq.push_back(k); }
+            if (uniq.size() > 1) { p.tapsInSets = false; continue; }
+            auto it = ins.find(kv.first);
+            if (it == ins.end()) continue;
+            for (int k : it->second) {
+                if (ni[k].island != ni[uniq[0]].island) { p.tapsInSets = false; continue; }
+                tapWriter[(size_t)k] = uniq[0];
+                islandPairsTaps[(size_t)ni[k].island] = 1;
+            }
+        }
+        for (size_t k = 0; k < ni.size(); ++k)
+            if (ni[k].island >= 0 && ni[k].n->op == OP_TAPIN) p.tapPairs.push_back({ni[k].n->id, p.tapsInSets && tapWriter[k] >= 0 ? ni[(size_t)tapWriter[k]].n->id : 0});
+    }
     // ---- 3/4. per-island schedule, LDS allocation, task emission -------------------------------------
     p.islands.resize(ib.size());
     std::vector<int> convLevel;              // launch level of p.convs[i]
@@ -599,6 +632,11 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 if (fuse && s.level == lv) sub = std::max(sub, s.sub + 1);
             }
             x.sub = sub;
+            if (x.n->op == OP_TAPOUT && islandPairsTaps[ii]) {   // behind every tapIn (a leaf: stage `base`) that reads its buffer
+                bool paired = false;
+                for (int k2 : B.nodes) paired = paired || (tapWriter[(size_t)k2] >= 0 && ni[(size_t)tapWriter[(size_t)k2]].n == x.n);
+                if (paired && lv < base + 1) { lv = base + 1; x.sub = 0; }
+            }
             // svf / shelf take two stages: sample-parallel coefficient pre-pass, then the scan
             if (x.n->op == OP_SVF || x.n->op == OP_SVFSHELF) lv += 1;
             if (blepSplit(x.n->op)) lv += 1;   // recurrence at lv - 1, waveform (the node's output) at lv
@@ -679,6 +717,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         // blocks kept in flight by a multi-block launch: as many buffer sets as fit in ~140 KB of LDS (one such workgroup per CU)
         uint32_t copies = 1;
         if (!statelessIsland && slotArea > 0) copies = std::max<uint32_t>(1, std::min<uint32_t>(maxCopies, (35u * 1024u) / slotArea));
+        if (islandPairsTaps[ii]) copies = 1;          // a feedback loop through a tap: one block in flight
         const uint32_t slotWords = kSlot0 + copies * slotArea;                    // first word after every copy's buffers
 
         // island-local program tables
@@ -1481,7 +1520,7 @@ std::string Engine::describePlan() {
     kv("num_members", p.numMembers); kv("num_operands", p.numOperands); kv("num_nodes", p.nodeIds.size());
     kv("num_hbm_buffers", p.numHbmBuffers); kv("num_stream_buffers", p.numStreamBuffers); kv("pack_k", p.packK);
     kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());
-    kv("num_taps", p.taps.size()); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());
+    kv("num_taps", p.taps.size()); kv("taps_in_sets", p.tapsInSets ? 1 : 0); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());
     s += "\"level_sizes\":[";
     for (size_t l = 0; l + 1 < p.levelOffsets.size(); ++l) { if (l) s += ","; s += std::to_string(p.levelOffsets[l + 1] - p.levelOffsets[l]); }
     s += "],\"root_ids\":[";

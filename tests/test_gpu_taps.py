@@ -1,0 +1,113 @@
+"""Feedback taps inside launch sets (plan.cpp "taps inside launch sets", run_tapin, promote_taps): a tapIn / tapOut pair that
+sits in one island renders through elemhip_process_blocks' multi-block launches — one block in flight in that island, the
+tapIn of block b+1 reading the tapOut's private buffer of block b, one promotion per set — and must give the samples of the
+reference's per-block promotion (Feedback.h:90-126, GraphRenderSequence.h:297-308). Tolerance 1e-6 absolute (x max|ref|)."""
+import numpy as np
+import pytest
+
+from elementary_amd import el
+from helpers import lcg_noise
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+X = lambda ch=0: el.in_({"channel": ch})  # noqa: E731
+
+
+def _checker(sr, bs):
+    import oracle
+    return oracle.RefRuntime(sr, bs) if oracle.have_ref() else oracle.PortRuntime(sr, bs)
+
+
+def _hip(sr, bs, **opts):
+    from elementary_amd.runtime import Runtime
+    rt = Runtime(sr, bs, device=0)
+    for k, v in opts.items():
+        rt.set_option(k, v)
+    return rt
+
+
+def _loop():
+    return [el.tapOut({"name": "fb"}, el.add(el.mul(0.5, el.tapIn({"name": "fb"})), X()))]
+
+
+def _cross():
+    a = el.tapOut({"name": "a"}, el.add(el.mul(0.45, el.tapIn({"name": "b"})), X(0)))
+    b = el.tapOut({"name": "b"}, el.add(el.mul(-0.4, el.tapIn({"name": "a"})), el.mul(0.5, X(1))))
+    return [el.add(a, b)]
+
+
+def _filtered_loop():
+    fb = el.tapIn({"name": "rv"})
+    body = el.lowpass(1800.0, 0.9, el.add(X(0), el.mul(0.7, el.sdelay({"size": 300}, fb))))
+    return [el.tanh(el.tapOut({"name": "rv"}, body)), el.mul(0.5, el.tapIn({"name": "rv"}))]
+
+
+def _not_a_loop():
+    # the tapOut's input does not depend on the tapIn: a plain one-block delay line
+    return [el.add(el.tapOut({"name": "d"}, el.mul(0.9, X(0))), el.mul(2.0, el.tapIn({"name": "d"})))]
+
+
+def _two_writers():
+    a = el.tapOut({"name": "w"}, el.mul(0.5, X(0)))
+    b = el.tapOut({"name": "w"}, el.mul(0.25, X(1)))
+    return [el.add(a, b, el.tapIn({"name": "w"}))]
+
+
+def _split_roots():
+    # the tap is written under one root and read (by a tapIn node of its own) under another: two islands, block-at-a-time
+    return [el.tapOut({"name": "s"}, el.add(X(0), el.mul(0.3, el.tapIn({"name": "s"})))), el.mul(0.5, el.tapIn({"name": "s", "key": "reader"}))]
+
+
+CASES = {"loop": (_loop, 1, True), "cross": (_cross, 2, True), "filtered_loop": (_filtered_loop, 1, True), "not_a_loop": (_not_a_loop, 1, True),
+         "two_writers": (_two_writers, 2, False), "split_roots": (_split_roots, 1, False)}
+
+
+def _blocks(rt, x, k0, nb, n_out):
+    import torch
+    xin = torch.from_numpy(np.ascontiguousarray(x[:, k0 * 512:(k0 + nb) * 512].reshape(x.shape[0], nb, 512).transpose(1, 0, 2))).cuda()
+    out = torch.empty((nb, n_out, 512), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    rt.process_blocks(nb, n_out, out_ptr=out.data_ptr(), in_ptr=xin.data_ptr(), num_inputs=x.shape[0])
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("batch", [5, 64])
+def test_taps_through_launch_sets(gpu_required, name, batch):
+    roots_fn, n_in, in_sets = CASES[name]
+    a, c = _hip(44100.0, 512, batch_blocks=batch), _checker(44100.0, 512)
+    roots = roots_fn()
+    assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
+    plan = a.describe_plan()
+    assert plan["num_taps"] >= 1 and plan["taps_in_sets"] == (1 if in_sets else 0), plan
+    nb = 150
+    x = np.stack([lcg_noise(nb * 512, 3 + ch, 0.5) for ch in range(n_in)])
+    # several calls: sets of `batch`, a ragged tail, a single block in between (the realtime path), more sets
+    got = np.concatenate([_blocks(a, x, 0, 70, len(roots)), _blocks(a, x, 70, 1, len(roots)), _blocks(a, x, 71, 79, len(roots))])
+    ref = np.stack([c.process(x[:, k * 512:(k + 1) * 512], len(roots), 512) for k in range(nb)])
+    st = a.stats()
+    assert (st["batch_launches"] > 0) == in_sets, st
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(got - ref).max(axis=(1, 2))
+    assert np.isfinite(got).all() and float(err.max()) <= TOL * scale, f"block {int(err.argmax())}: {err.max():.3e}"
+    # block-by-block process() continues the same stream (the set's single promotion left the shared buffer as block 149 did)
+    more = np.stack([a.process(x[:, :512], len(roots), 512) for _ in range(3)])
+    ref2 = np.stack([c.process(x[:, :512], len(roots), 512) for _ in range(3)])
+    assert float(np.abs(more - ref2).max()) <= TOL * scale
+
+
+def test_tap_graph_swap_between_sets(gpu_required):
+    """A re-render that moves the tapOut away (the tapIn keeps reading the shared buffer, frozen) and back: the pairing written
+    into the tapIn's record follows the plan."""
+    a, c = _hip(44100.0, 512, batch_blocks=16), _checker(44100.0, 512)
+    x = np.stack([lcg_noise(120 * 512, 9, 0.5)])
+    out_a, out_c = [], []
+    k0 = 0
+    for roots in (_loop(), [el.mul(0.5, el.tapIn({"name": "fb"}))], _loop()):
+        assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
+        out_a.append(_blocks(a, x, k0, 40, 1))
+        out_c.append(np.stack([c.process(x[:, k * 512:(k + 1) * 512], 1, 512) for k in range(k0, k0 + 40)]))
+        k0 += 40
+    got, ref = np.concatenate(out_a), np.concatenate(out_c)
+    assert float(np.abs(got - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
+    assert a.stats()["batch_launches"] > 0
