@@ -1424,7 +1424,10 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     const size_t oConvWork = place(p.convWork.size() * 4);
     // ---- specialised kernels: group each level's islands by generated text, queue the shapes for compilation ----
     double jitWaitMs = -1.0;
-    if (!p.taps.empty() || !p.hosts.empty()) p.specText.clear();   // such plans never render through launch sets (Engine::batchEligible)
+    // call-out nodes never render through launch sets (Engine::batchEligible); a plan with tapOuts does when its pairs sit in one
+    // island, but through the interpreter kernel: the specialised kernel of such an island (one block in flight) faulted on the
+    // GPU when tried (r03) and has not been debugged
+    if (!p.taps.empty() || !p.hosts.empty()) p.specText.clear();
     {
         const size_t L = p.levelOffsets.size() - 1;
         p.restOffsets.assign(L + 1, 0);

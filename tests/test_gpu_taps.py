@@ -72,10 +72,11 @@ def _blocks(rt, x, k0, nb, n_out):
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-@pytest.mark.parametrize("batch", [5, 64])
-def test_taps_through_launch_sets(gpu_required, name, batch):
+@pytest.mark.parametrize("batch,spec", [(5, 0), (64, 0), (64, 2)])
+def test_taps_through_launch_sets(gpu_required, name, batch, spec):
+    """spec = 2 asks for run-time specialised kernels: a plan with tapOuts gets none (plan.cpp), the interpreter kernel renders it."""
     roots_fn, n_in, in_sets = CASES[name]
-    a, c = _hip(44100.0, 512, batch_blocks=batch), _checker(44100.0, 512)
+    a, c = _hip(44100.0, 512, batch_blocks=batch, specialize=spec), _checker(44100.0, 512)
     roots = roots_fn()
     assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
     plan = a.describe_plan()
@@ -87,6 +88,7 @@ def test_taps_through_launch_sets(gpu_required, name, batch):
     ref = np.stack([c.process(x[:, k * 512:(k + 1) * 512], len(roots), 512) for k in range(nb)])
     st = a.stats()
     assert (st["batch_launches"] > 0) == in_sets, st
+    assert st["spec_launches"] == 0, st
     scale = max(1.0, float(np.abs(ref).max()))
     err = np.abs(got - ref).max(axis=(1, 2))
     assert np.isfinite(got).all() and float(err.max()) <= TOL * scale, f"block {int(err.argmax())}: {err.max():.3e}"

@@ -1,6 +1,6 @@
 """A feedback loop through a tap (lowpass + 300-frame delay inside the loop, 8 such loops under two roots) rendered by
 elemhip_process_blocks: block-at-a-time (batch_blocks = 1: what every plan with a tapOut got before taps could be rendered
-inside launch sets) vs 64- and 256-block launch sets. Usage: python tools/tap_loop_bench.py [blocks]"""
+inside launch sets) vs 64- and 256-block launch sets (interpreter kernel: plans with tapOuts get no specialised kernels). Usage: python tools/tap_loop_bench.py [blocks]"""
 import os as _os, sys as _sys; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))); _sys.path[:0] = [_R, _os.path.join(_R, 'tests')]
 import json
 import sys
@@ -27,9 +27,10 @@ def graph():
 
 
 rows = []
-for batch in (1, 64, 256):
+for batch, spec in ((1, 0), (64, 0), (256, 0)):
     rt = Runtime(48000.0, 512, device=0)
     rt.set_option("batch_blocks", batch)
+    rt.set_option("specialize", spec)
     assert rt.render(*graph())["result"] == 0
     x = torch.rand((256, 1, 512), device="cuda") - 0.5
     out = torch.empty((256, 2, 512), dtype=torch.float32, device="cuda")
@@ -41,8 +42,7 @@ for batch in (1, 64, 256):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (blocks // 256 * 256)
     plan = rt.describe_plan()
-    rows.append({"batch_blocks": batch, "us_per_block": 1e6 * dt, "samples_per_s": 512 / dt, "batch_launches": rt.stats()["batch_launches"],
+    rows.append({"batch_blocks": batch, "specialize": spec, "spec_launches": rt.stats()["spec_launches"], "us_per_block": 1e6 * dt, "samples_per_s": 512 / dt, "batch_launches": rt.stats()["batch_launches"],
                  "taps_in_sets": plan["taps_in_sets"], "islands": plan["num_islands"], "levels": plan["num_levels"]})
     print(json.dumps(rows[-1]), flush=True)
-print(json.dumps({"speedup_64_vs_block_at_a_time": rows[0]["us_per_block"] / rows[1]["us_per_block"],
-                  "speedup_256_vs_block_at_a_time": rows[0]["us_per_block"] / rows[2]["us_per_block"]}))
+print(json.dumps({"speedup_vs_block_at_a_time": [rows[0]["us_per_block"] / r["us_per_block"] for r in rows]}))
