@@ -1,6 +1,7 @@
 // engine.cpp — instruction interpreter, node table, device-resident node records and the
 // per-block launch sequence. See engine.h for the mapping onto runtime/elem/Runtime.h.
 #include "engine.h"
+#include <thread>
 
 #include <hip/hip_runtime.h>
 
@@ -1730,7 +1731,14 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
     if (fork) {
         while (auxStreams.size() < launches - 1) {
             hipStream_t s2 = nullptr; hipEvent_t ev = nullptr;
-            HIP_WARN(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            // a side stream must not share a hardware queue with the engine's stream (the runtime hands queues out round-robin
+            // per priority class; in a process with many streams two shapes of C4 landed on one queue and ran back to back,
+            // 12.9 -> 25 us per block): side streams alternate between the two other priority classes
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            const int prio = (auxStreams.size() % 2 == 0) ? greatest : least;
+            if (least == greatest || hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio) != hipSuccess)
+                HIP_WARN(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
             HIP_WARN(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             auxStreams.push_back(s2); auxDone.push_back(ev);
         }
@@ -1964,11 +1972,23 @@ int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* 
     auto scatter = [&](size_t k) {     // pinned half -> the caller's planar arrays
         const size_t b0 = k * setBlocks, nb = std::min(setBlocks, numBlocks - b0);
         const float* src = hStageOut[k & 1];
-        for (size_t b = 0; b < nb; ++b) {
-            const size_t f0 = (b0 + b) * bs;
-            const size_t n = std::min(bs, numFrames - f0);
-            for (size_t c = 0; c < nOut; ++c) std::memcpy(out[c] + f0, src + (b * nOut + c) * bs, n * sizeof(float));
-        }
+        auto part = [&](size_t bBegin, size_t bEnd) {
+            for (size_t b = bBegin; b < bEnd; ++b) {
+                const size_t f0 = (b0 + b) * bs;
+                const size_t n = std::min(bs, numFrames - f0);
+                for (size_t c = 0; c < nOut; ++c) std::memcpy(out[c] + f0, src + (b * nOut + c) * bs, n * sizeof(float));
+            }
+        };
+        // One thread copies ~10 GB/s; a set of many channels (C4: 128 outputs x 1024 blocks = 268 MB per 12.6 ms of rendering)
+        // needs more than that to stay hidden behind the next set, so big sets are cut over a few threads by block range.
+        const size_t bytes = nb * nOut * bs * sizeof(float);
+        size_t threads = bytes >= (16u << 20) ? std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency() / 4)) : 1;
+        threads = std::min(threads, nb);
+        if (threads <= 1) return part(0, nb);
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < threads; ++t) pool.emplace_back(part, nb * t / threads, nb * (t + 1) / threads);
+        part(0, nb / threads);
+        for (auto& th : pool) th.join();
     };
     int result = kOk;
     size_t issued = 0;

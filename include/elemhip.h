@@ -164,9 +164,12 @@ size_t elemhip_describe_plan(elemhip_t*, char* buf, size_t cap);
 int  elemhip_spec_info(elemhip_t*, size_t k, char* src, size_t srcCap, char* log, size_t logCap, int* state, uint32_t* islands);
 /* Run the launches on a caller-owned hipStream_t (e.g. torch's current stream). */
 int  elemhip_set_stream(elemhip_t*, void* hipStream);
-/* Tunables: "use_graph" (0/1), "graph_blocks" (blocks per captured hipGraph), "batch_blocks" (blocks per multi-block
- * launch), "specialize" (0 interpreter kernels only, 1 per-island-shape kernels compiled in the background and used once
- * ready, 2 commit waits for them), "profile_launches", "pipeline_copies", "time_batch". */
+/* Tunables (the full table with defaults: INTEGRATION.md section 5): "batch_blocks" (blocks per multi-block launch, 1 ... 1024),
+ * "specialize" (0 interpreter kernels only, 1 per-island-shape kernels compiled in the background and used once ready, 2 commit
+ * waits for them), "spec_blocks" / "host_out_direct" (elemhip_process through the specialised kernels / output written straight
+ * into pinned host memory), "use_graph" / "graph_blocks" (per-block launch path replayed from a hipGraph), "stateless_rows",
+ * "mixer_split", "pipeline_copies", "merge_phases", "stream_ring", "pack_islands" / "pack_max" / "cu_count" (lane-packing of
+ * isomorphic islands), "profile_launches", "time_batch", "chain_lds_out" (measurement). Unknown keys return code 6. */
 int  elemhip_set_option(elemhip_t*, const char* key, double value);
 
 #ifdef __cplusplus
