@@ -241,6 +241,7 @@ private:
     int  pipelineCopies = 6;               // blocks a stateful island keeps in flight inside a multi-block launch
     bool convAligned = true;               // every process call so far rendered whole 512-frame blocks (conv.hip batch path)
     float* dConvScratch = nullptr; size_t convScratchFloats = 0;
+    uint32_t soloWaves = 0;                // plan.cpp: heaviest recurrence waves that get no SIMD mate
     uint32_t mixerSplit = 2;               // workgroups a mixer island is cut into (plan.cpp; each renders blockSize / split frames on 8 / split waves)
     bool streamRing = true;                // stream buffers of the specialised kernels live in a ring of `copies` slices (0: one slice per block; measurement)
     int  packIslands = 0;                  // option "pack_islands": same-shape islands merged into one workgroup (0 auto: when a launch level has more

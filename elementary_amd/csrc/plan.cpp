@@ -1018,6 +1018,21 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                     for (size_t k = 0; k < ser.size(); ++k) { taken[k] = true; if (k < par.size()) taken[k + 4] = true; }
                     for (int w = 0; w < (int)kWaves; ++w) if (!taken[w]) freeIdx[nf++] = w;
                     for (int f = 0; pi < par.size() && f < nf; ++f) renum[par[pi++]] = freeIdx[f];
+                    // `solo_waves` = n: the n heaviest recurrence waves keep their SIMD to themselves — the mate's tasks move
+                    // to the lightest sample-parallel wave that is not such a mate (it then owns two slots per block)
+                    const size_t solo = std::min<size_t>({(size_t)e.soloWaves, ser.size(), par.size() > 1 ? par.size() - 1 : 0});
+                    if (solo > 0) {
+                        uint32_t ld[kWaves] = {};
+                        for (int w = 0; w < (int)kWaves; ++w) ld[renum[w]] = load[w];
+                        for (size_t k = 0; k < solo; ++k) {
+                            const int mate = renum[par[k]];
+                            int best = -1;
+                            for (size_t j = solo; j < par.size(); ++j) { const int w = renum[par[j]]; if (best < 0 || ld[w] < ld[best]) best = w; }
+                            if (best < 0) break;
+                            for (int w = 0; w < (int)kWaves; ++w) if (renum[w] == mate) renum[w] = best;
+                            ld[best] += ld[mate]; ld[mate] = 0;
+                        }
+                    }
                     for (size_t q = 0; q < tasks.size(); ++q) taskWave[q] = renum[taskWave[q]];
                 }
             }
