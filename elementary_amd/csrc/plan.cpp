@@ -1441,8 +1441,12 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     double jitWaitMs = -1.0;
     // call-out nodes never render through launch sets (Engine::batchEligible); a plan with tapOuts does when its pairs sit in one
     // island, but through the interpreter kernel: the specialised kernel of such an island (one block in flight) faulted on the
-    // GPU when tried (r03) and has not been debugged
-    if (!p.taps.empty() || !p.hosts.empty()) p.specText.clear();
+    // GPU when tried (r03) and has not been debugged (hook: ELEMHIP_EXP_SPEC_TAPS=1 compiles them anyway)
+    static const bool specTaps = std::getenv("ELEMHIP_EXP_SPEC_TAPS") != nullptr;      // debugging hook for the above
+    // (r03 bisect, tools/tap_spec_fault.py: tapIn -> sdelay -> svf in an island with one block in flight faults in the specialised
+    //  kernel with or without a tapOut, so ANY tap node keeps a plan on the interpreter kernels)
+    const bool anyTap = !p.taps.empty() || !p.tapPairs.empty();
+    if ((anyTap && !(specTaps && p.tapsInSets)) || !p.hosts.empty()) p.specText.clear();
     {
         const size_t L = p.levelOffsets.size() - 1;
         p.restOffsets.assign(L + 1, 0);
@@ -1538,7 +1542,7 @@ std::string Engine::describePlan() {
     kv("num_members", p.numMembers); kv("num_operands", p.numOperands); kv("num_nodes", p.nodeIds.size());
     kv("num_hbm_buffers", p.numHbmBuffers); kv("num_stream_buffers", p.numStreamBuffers); kv("pack_k", p.packK);
     kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());
-    kv("num_taps", p.taps.size()); kv("taps_in_sets", p.tapsInSets ? 1 : 0); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());
+    kv("num_taps", p.taps.size()); kv("taps_in_sets", p.tapsInSets ? 1 : 0); kv("num_tap_nodes", p.taps.size() + p.tapPairs.size()); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());
     s += "\"level_sizes\":[";
     for (size_t l = 0; l + 1 < p.levelOffsets.size(); ++l) { if (l) s += ","; s += std::to_string(p.levelOffsets[l + 1] - p.levelOffsets[l]); }
     s += "],\"root_ids\":[";
