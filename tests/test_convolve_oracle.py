@@ -30,3 +30,30 @@ def test_convolve_property_codes():
     rt = oracle.PortRuntime(48000.0, 512)
     assert rt.apply_instructions([[0, 1, "convolve"], [3, 1, "path", 4]]) == 5          # Convolve.h:37-38
     assert rt.apply_instructions([[3, 1, "path", "/nope"]]) == 6                         # :40-41
+
+
+def _c3x2_golden():
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    man = json.load(open(os.path.join(here, "golden", "convolve_wasm_c3x2.json")))
+    blob = np.fromfile(os.path.join(here, "golden", "convolve_wasm_c3x2.f32"), dtype="<f4")
+    return man, blob.reshape(man["channels"], man["blocks"] * man["block"])
+
+
+@pytest.mark.skipif(not oracle.have_port(), reason="oracle port not built")
+def test_restatement_matches_two_channels_of_c3_recorded_from_the_wasm_engine():
+    """BASELINE configs[2] itself — the graph, IRs and inputs of elementary_amd/graphs.py, two of its eight channels, 200 blocks
+    (past the IR's 188 partitions) — recorded from the reference's wasm engine (tests/golden/make_convolve_c3x2_golden.js).
+    The first 960 frames are inside the root fade of the recording's Runtime<double> and rounded to float32 there."""
+    from elementary_amd import graphs
+    man, gold = _c3x2_golden()
+    ch, nb = man["channels"], man["blocks"]
+    rt = oracle.PortRuntime(graphs.C3_SAMPLE_RATE, 512)
+    for c in range(ch):
+        assert rt.add_shared_resource(f"ir{c}", graphs.c3_impulse_response(c))
+    assert rt.render(*graphs.c3_graph(ch))["result"] == 0
+    x = graphs.c3_input(ch, nb * 512)
+    y = np.concatenate([rt.process(x[:, k * 512:(k + 1) * 512], ch, 512) for k in range(nb)], axis=1)
+    assert float(np.abs(gold).max()) > 0.5
+    assert float(np.abs(y.astype(np.float64) - gold).max()) <= TOL

@@ -173,3 +173,25 @@ def test_partial_blocks_switch_the_multi_block_path_off(gpu_required):
     assert a.stats()["batch_launches"] == before
     ref.append(np.concatenate([c.process(xs[:, i * 512:(i + 1) * 512], 1, 512) for i in range(30)], axis=1))
     assert float(np.abs(np.concatenate(got, axis=1).astype(np.float64) - np.concatenate(ref, axis=1)).max()) <= TOL
+
+
+@pytest.mark.parametrize("batch", [1, 64, 256])
+def test_c3_two_channels_vs_the_wasm_recording(gpu_required, batch):
+    """Two channels of BASELINE configs[2] against outputs RECORDED FROM THE REFERENCE'S WASM ENGINE
+    (tests/golden/convolve_wasm_c3x2.f32, 200 blocks: past the 188 partitions of the IR), block at a time (batch = 1) and
+    through 64- / 256-block launch sets — not against the restatement."""
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    man = json.load(open(os.path.join(here, "golden", "convolve_wasm_c3x2.json")))
+    gold = np.fromfile(os.path.join(here, "golden", "convolve_wasm_c3x2.f32"), dtype="<f4").reshape(man["channels"], -1)
+    ch, nb = man["channels"], man["blocks"]
+    rt, x = _c3(hip, ch, nb)
+    rt.set_option("batch_blocks", batch)
+    if batch == 1:
+        got = np.concatenate([rt.process(x[:, k * 512:(k + 1) * 512], ch, 512) for k in range(nb)], axis=1)
+    else:
+        got = _blocks(rt, x, 0, nb, ch).transpose(1, 0, 2).reshape(ch, nb * 512)
+        assert rt.stats()["batch_launches"] >= 1
+    err = np.abs(got.astype(np.float64) - gold)
+    assert float(err.max()) <= TOL, f"frame {int(err.argmax())}: {err.max():.3e}"
