@@ -1264,6 +1264,7 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "spec_blocks") { specBlocks = value != 0; return kOk; }      // elemhip_process through the specialised kernels when it can
     if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(1024, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
     if (key == "debug_build_delay_ms") { debugBuildDelayMs = std::max(0, (int)value); return kOk; }   // tests: stretches the unlocked part of a plan build
+    if (key == "fuse_svf_coef") { fuseSvfCoef = (uint32_t)std::max(0, std::min(2, (int)value)); planStale = true; return kOk; }
     if (key == "solo_waves") { soloWaves = (uint32_t)std::max(0, std::min(3, (int)value)); planStale = true; return kOk; }
     if (key == "mixer_split") { const int v = (int)value; mixerSplit = (v == 2 || v == 4 || v == 8) ? (uint32_t)v : 1u; planStale = true; return kOk; }
     if (key == "stateless_rows") { statelessRows = (uint32_t)std::max(1, std::min(64, (int)value)); return kOk; }   // gridDim.y of a multi-block launch: blocks that stateless islands render side by side

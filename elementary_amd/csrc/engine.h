@@ -241,6 +241,7 @@ private:
     int  pipelineCopies = 6;               // blocks a stateful island keeps in flight inside a multi-block launch
     bool convAligned = true;               // every process call so far rendered whole 512-frame blocks (conv.hip batch path)
     float* dConvScratch = nullptr; size_t convScratchFloats = 0;
+    uint32_t fuseSvfCoef = 2;              // plan.cpp: svf coefficient pre-pass inside the scan: 0 never, 1 always, 2 in lane-packed islands
     uint32_t soloWaves = 0;                // plan.cpp: heaviest recurrence waves that get no SIMD mate
     uint32_t mixerSplit = 2;               // workgroups a mixer island is cut into (plan.cpp; each renders blockSize / split frames on 8 / split waves)
     bool streamRing = true;                // stream buffers of the specialised kernels live in a ring of `copies` slices (0: one slice per block; measurement)

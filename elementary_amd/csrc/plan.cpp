@@ -610,6 +610,9 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             }
         }
         const int base = anyImport ? 1 : 0;
+        // svf with its coefficient pre-pass inside the scan (scan_svf, island_ops.inc): no pre-pass task, no 6-slot scratch
+        const bool fuseCoef = e.fuseSvfCoef == 1 || (e.fuseSvfCoef == 2 && packCount[ii] > 1u);
+        auto coefFused = [&](uint16_t op) { return fuseCoef && op == OP_SVF; };
         int maxStage = 0;
         for (int k : B.nodes) {
             NI& x = ni[k];
@@ -622,7 +625,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 // Sample-parallel ops are lane-local (lane l reads and writes only samples l + 64j of
                 // its slice), so a sample-parallel consumer of a sample-parallel producer can run in
                 // the SAME stage on the same wave, right after it, with no barrier in between.
-                const bool xsvf = x.n->op == OP_SVF || x.n->op == OP_SVFSHELF;   // its coefficient pre-pass is such an op too
+                const bool xsvf = (x.n->op == OP_SVF || x.n->op == OP_SVFSHELF) && !coefFused(x.n->op);   // its coefficient pre-pass is such an op too
                 // (xsvf && splitCoefStage: the pre-pass gets a stage of its own, so its light producers run unsplit on one
                 // wave instead of four times with four times the per-task overhead)
                 // (a split oscillator's waveform task is sample-parallel as well: its consumers may follow it in its stage)
@@ -638,7 +641,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 if (paired && lv < base + 1) { lv = base + 1; x.sub = 0; }
             }
             // svf / shelf take two stages: sample-parallel coefficient pre-pass, then the scan
-            if (x.n->op == OP_SVF || x.n->op == OP_SVFSHELF) lv += 1;
+            if ((x.n->op == OP_SVF || x.n->op == OP_SVFSHELF) && !coefFused(x.n->op)) lv += 1;
             if (blepSplit(x.n->op)) lv += 1;   // recurrence at lv - 1, waveform (the node's output) at lv
             x.level = lv;
             x.lastUse = lv;
@@ -690,7 +693,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         for (int stage = base; stage <= maxStage; ++stage) {
             for (int k : B.nodes) {   // coefficient scratch of the svf's that scan in the NEXT stage
                 NI& x = ni[k];
-                if (x.level != stage + 1 || (x.n->op != OP_SVF && x.n->op != OP_SVFSHELF)) continue;
+                if (x.level != stage + 1 || (x.n->op != OP_SVF && x.n->op != OP_SVFSHELF) || coefFused(x.n->op)) continue;
                 x.scratch = takeSlots(stage, scratchSlots(x.n->op), stage + 1);
             }
             for (int k : B.nodes) {   // out slot of a split oscillator: carries the phase from the recurrence stage on
@@ -858,7 +861,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 else if (x.kind == K_SINGLE) groups.insert({x.level, 0x20000u | (uint32_t)k});
                 else if (x.kind == K_PAR) parTotal[x.level] += taskCost(op, 8, 1);
                 if (blepSplit(op)) parTotal[x.level] += taskCost(op == OP_BLEPSAW ? OP_SAW_SHAPE : OP_SQUARE_SHAPE, 8, 1);
-                if (op == OP_SVF) parTotal[x.level - 1] += taskCost(OP_SVF_COEF, 8, 1);
+                if (op == OP_SVF && !coefFused(op)) parTotal[x.level - 1] += taskCost(OP_SVF_COEF, 8, 1);
                 if (op == OP_SVFSHELF) parTotal[x.level - 1] += taskCost(OP_SHELF_COEF, 8, 1);
             }
             spareWaves -= (int)groups.size();
@@ -872,7 +875,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             std::vector<int> phasePhasors, phaseOscs;          // members of this stage's OP_PHASE task
             for (int k : B.nodes) {
                 NI& x = ni[k];
-                if (x.level == stage + 1 && x.n->op == OP_SVF) par[{1 << 20, OP_SVF_COEF}].push_back(k);
+                if (x.level == stage + 1 && x.n->op == OP_SVF && !coefFused(OP_SVF)) par[{1 << 20, OP_SVF_COEF}].push_back(k);
                 if (x.level == stage + 1 && x.n->op == OP_SVFSHELF) par[{1 << 20, OP_SHELF_COEF}].push_back(k);
                 if (x.level == stage + 1 && blepSplit(x.n->op)) {
                     if (phaseMergeable(x)) phaseOscs.push_back(k);

@@ -30,8 +30,9 @@ def _planar(rt, n_out, blocks):
 @pytest.mark.parametrize("spec", [0, 2])
 @pytest.mark.parametrize("k", [2, 3, 4])
 def test_packed_voices_equal_unpacked(gpu_required, spec, k):
-    """48 C2 voices, K voices per island when forced (K = 4 leaves room for one buffer set only: the planner settles for 3),
-    both kernel families, 150 blocks through launch sets of 32."""
+    """48 C2 voices, K voices per island when forced, both kernel families, 150 blocks through launch sets of 32. Packed islands
+    evaluate the svf coefficients inside the scan (`fuse_svf_coef` = 2: no 6-slot scratch per voice), which is what leaves
+    K = 4 two buffer sets; the unpacked engine keeps the separate pre-pass — the two forms are bit-identical too."""
     a = _hip(graphs.C2_SAMPLE_RATE, specialize=spec, batch_blocks=32, pack_islands=k)
     b = _hip(graphs.C2_SAMPLE_RATE, specialize=spec, batch_blocks=32, pack_islands=1)
     c = _checker(graphs.C2_SAMPLE_RATE, 512)
@@ -40,7 +41,7 @@ def test_packed_voices_equal_unpacked(gpu_required, spec, k):
         assert rt.render(*roots)["result"] == 0
     pa, pb = a.describe_plan(), b.describe_plan()
     assert pb["pack_k"] == 1 and pb["level_sizes"][0] == 48
-    assert pa["pack_k"] == min(k, 3) and pa["level_sizes"][0] == -(-48 // min(k, 3))
+    assert pa["pack_k"] == k and pa["level_sizes"][0] == -(-48 // k)
     assert pa["islands"][0]["copies"] >= 2
     got, ref_hip = _planar(a, 2, 150), _planar(b, 2, 150)
     assert np.array_equal(got, ref_hip)
@@ -49,6 +50,27 @@ def test_packed_voices_equal_unpacked(gpu_required, spec, k):
     if spec:
         st = a.stats()
         assert st["spec_launches"] > 0 and all(a.spec_info(q)["state"] == 1 for q in range(st["spec_shapes"])), st
+
+
+@pytest.mark.parametrize("spec", [0, 2])
+def test_fused_svf_coefficients_equal_the_pre_pass(gpu_required, spec):
+    """`fuse_svf_coef` = 1 on unpacked voices vs 0: the same double operations in another place — bit-identical; modulated cutoff
+    (C2 voices), constant cutoff and resonance, and a shelf next to it (never fused)."""
+    from elementary_amd import el
+    x = el.in_({"channel": 0})
+    roots = graphs.c2_graph(voices=6) + [el.lowpass(900.0, 1.1, x), el.highpass(el.add(1000.0, el.mul(500.0, x)), 0.8, x),
+                                         el.bandpass(700.0, el.add(2.0, x), x), el.lowshelf(300.0, 0.9, 3.0, x)]
+    a = _hip(graphs.C2_SAMPLE_RATE, specialize=spec, batch_blocks=16, fuse_svf_coef=1)
+    b = _hip(graphs.C2_SAMPLE_RATE, specialize=spec, batch_blocks=16, fuse_svf_coef=0)
+    c = _checker(graphs.C2_SAMPLE_RATE, 512)
+    for rt in (a, b, c):
+        assert rt.render(*roots)["result"] == 0
+    from helpers import lcg_noise
+    xin = np.stack([lcg_noise(60 * 512, 21, 0.5)])
+    ya, yb = a.process_blocks_host(xin, len(roots), 60 * 512), b.process_blocks_host(xin, len(roots), 60 * 512)
+    assert np.array_equal(ya, yb)
+    ref = np.concatenate([c.process(xin[:, k * 512:(k + 1) * 512], len(roots), 512) for k in range(60)], axis=1)
+    assert float(np.abs(ya - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
 
 
 def test_auto_packing_follows_the_cu_count(gpu_required):
