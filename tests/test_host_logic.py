@@ -97,12 +97,13 @@ def test_plan_shape_for_the_benchmark_graph():
 
 
 def test_lane_packing_plan_shapes():
-    """Auto lane-packing: 256 voices = one island per CU, untouched; 512 voices = 2 per island (3 buffer sets); 1024 voices: still 2
-    per island (auto never goes beyond 2: with 3 only two buffer sets fit and the block pipeline starves); 4 per island asked for
-    explicitly: only one buffer set would fit in LDS, so the planner settles for 3 (342 islands); pack_islands = 1 switches it
-    off. The two mixers stay as they are."""
-    for voices, opts, want_k, want_islands in ((256, {}, 1, 256), (512, {}, 2, 256), (1024, {}, 2, 512), (1024, {"pack_islands": 4}, 3, 342),
-                                               (512, {"pack_islands": 1}, 1, 512)):
+    """Auto lane-packing: 256 voices = one island per CU, untouched; 512 voices = 2 per island (4 buffer sets: packed islands
+    evaluate the svf coefficients inside the scan, no scratch); 1024 voices: still 2 per island (auto never goes beyond 2: deeper
+    packs leave too few buffer sets and the block pipeline starves); 4 per island asked for explicitly: two buffer sets (without
+    the fused coefficients only one would fit and the planner settles for 3: 342 islands); pack_islands = 1 switches it off.
+    The two mixers stay as they are."""
+    for voices, opts, want_k, want_islands in ((256, {}, 1, 256), (512, {}, 2, 256), (1024, {}, 2, 512), (1024, {"pack_islands": 4}, 4, 256),
+                                               (1024, {"pack_islands": 4, "fuse_svf_coef": 0}, 3, 342), (512, {"pack_islands": 1}, 1, 512)):
         rt = dry(graphs.C2_SAMPLE_RATE)
         for k, v in opts.items():
             rt.set_option(k, v)
