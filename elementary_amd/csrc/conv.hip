@@ -406,6 +406,18 @@ __device__ __forceinline__ void batch_mac_tile(const BatchCtx& c, uint32_t tile,
     c2 w0 = xs((int)j0 - (int)pBegin), w1 = xs((int)j0 + 1 - (int)pBegin), w2 = xs((int)j0 + 2 - (int)pBegin), w3 = xs((int)j0 + 3 - (int)pBegin);
     c2 a0 = mk(0.0f, 0.0f), a1 = a0, a2 = a0, a3 = a0;
     auto mac = [&](c2& acc, c2 h, c2 x) {
+        if constexpr (!HasPacked) {
+            // two v_pk_fma_f32 per complex multiply-add instead of four v_fma_f32 — the same four fused operations in the same
+            // order per component: (re, im) += (h.re, h.re) * (x.re, x.im); (re, im) += (-h.im, h.im) * (x.im, x.re)
+            typedef float pk2 __attribute__((ext_vector_type(2)));
+            pk2 a = __builtin_bit_cast(pk2, acc);
+            const pk2 hv = __builtin_bit_cast(pk2, h), xv = __builtin_bit_cast(pk2, x);
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+                : "+v"(a) : "v"(hv), "v"(xv));
+            acc = __builtin_bit_cast(c2, a);
+            return;
+        }
         if (HasPacked && packed) { acc.x = __builtin_fmaf(h.x, x.x, acc.x); acc.y = __builtin_fmaf(h.y, x.y, acc.y); }
         else {
             acc.x = __builtin_fmaf(h.x, x.x, acc.x); acc.x = __builtin_fmaf(-h.y, x.y, acc.x);
