@@ -351,17 +351,18 @@ void elemhip_convolve_batch_fft(PlanView pv, uint32_t* recs, float* hbm, const G
 // r02's kernel ran one workgroup per (node, block) over all partitions: every block re-read all of H and its whole input
 // window (12.3 MB per block against 1.28 MB algorithmic); here a 64-block set reads H and the ring once and the 64
 // new spectra once per bin tile.
+constexpr uint32_t kMacU = 8, kMacR = 128, kMacDP = 3;     // partitions per chunk, ring rows, chunks the global loads run ahead
 template <bool HasPacked>
 __device__ __forceinline__ void batch_mac_tile(const BatchCtx& c, uint32_t tile, uint32_t jBase, uint32_t batch, uint32_t tid,
-                                               uint32_t part, uint32_t maxBatch) {
+                                               uint32_t part, uint32_t maxBatch, c2 (&Xs)[kMacR][20], c2 (&Hs)[kMacDP + 1u][kMacU][16]) {
     // LDS: a ring of input-spectrum rows (16 bins each) indexed by block time, and two chunks of H rows. A chunk is 8
     // partitions; per chunk the workgroup brings in 8 new ring rows and 8 H rows — ONE 8-byte value per thread — while the
     // 64 x 16 outputs it accumulates read everything else from LDS.
-    constexpr uint32_t U = 8, R = 128, DP = 3;             // partitions per chunk, ring rows, chunks the global loads run ahead
+    constexpr uint32_t U = kMacU, R = kMacR, DP = kMacDP;
     // (row pitch 20 values = 40 dwords: the four block groups of a wave read rows 4 apart — 160 dwords = 32 banks on — so each
     //  half-wave's 8-byte reads cover all 64 banks once; a 16-value pitch put all four on the same 32 banks)
-    __shared__ c2 Xs[R][20];
-    __shared__ c2 Hs[DP + 1u][U][16];
+    // (Xs / Hs belong to the kernel: as statics of this template they existed once per instantiation, 48 KB per workgroup
+    //  instead of 24 — three workgroups per CU instead of six)
     const uint32_t bin = tid & 15u, row = tid >> 4, kb = tile * 16u + bin, jg = row;      // bin, load row / block group
     const uint32_t j0 = jBase + jg * 4u;
     const uint32_t P = c.st.P, b0 = c.st.hdr[conv::H_BLK];
@@ -468,8 +469,10 @@ void elemhip_convolve_batch_mac(PlanView pv, uint32_t* recs, float* hbm, const G
     if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
     BatchCtx c;
     if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) return;     // (the ifft kernel writes the zeros)
-    if (tile == 0u) batch_mac_tile<true>(c, tile, jBase, batch, tid, part, maxBatch);
-    else batch_mac_tile<false>(c, tile, jBase, batch, tid, part, maxBatch);
+    __shared__ c2 Xs[kMacR][20];
+    __shared__ c2 Hs[kMacDP + 1u][kMacU][16];
+    if (tile == 0u) batch_mac_tile<true>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs);
+    else batch_mac_tile<false>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs);
 }
 
 // K2b (node, j): inverse FFT of the block's partition sum; head half -> the node's output buffer of block j, tail half -> tails[j + 1]
