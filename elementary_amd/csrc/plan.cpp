@@ -1442,12 +1442,13 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     const size_t oConvWork = place(p.convWork.size() * 4);
     // ---- specialised kernels: group each level's islands by generated text, queue the shapes for compilation ----
     double jitWaitMs = -1.0;
-    // call-out nodes never render through launch sets (Engine::batchEligible); a plan with tapOuts does when its pairs sit in one
-    // island, but through the interpreter kernel: the specialised kernel of such an island (one block in flight) faulted on the
-    // GPU when tried (r03) and has not been debugged (hook: ELEMHIP_EXP_SPEC_TAPS=1 compiles them anyway)
-    static const bool specTaps = std::getenv("ELEMHIP_EXP_SPEC_TAPS") != nullptr;      // debugging hook for the above
-    // (r03 bisect, tools/tap_spec_fault.py: tapIn -> sdelay -> svf in an island with one block in flight faults in the specialised
-    //  kernel with or without a tapOut, so ANY tap node keeps a plan on the interpreter kernels)
+    // Call-out nodes never render through launch sets (Engine::batchEligible); a plan with tapOuts does when its pairs sit in one
+    // island, but through the INTERPRETER kernel. The specialised kernel of such an island renders a tap loop 4.7x faster (r03:
+    // 83.6 -> 17.6 us per block, tools/tap_loop_bench.py with ELEMHIP_EXP_SPEC_TAPS=1) and is not shipped: after two fixes found by
+    // bisecting (tools/tap_spec_fault.py: wave-uniform reads of the tap pointers, vmcnt(0) before a tapOut slot publishes) the
+    // `cross` and `not_a_loop` graphs of tests/test_gpu_taps.py still get one block in ~150 wrong and some runs fault. Any tap node
+    // keeps a plan on the interpreter kernels until that is understood.
+    static const bool specTaps = std::getenv("ELEMHIP_EXP_SPEC_TAPS") != nullptr;
     const bool anyTap = !p.taps.empty() || !p.tapPairs.empty();
     if ((anyTap && !(specTaps && p.tapsInSets)) || !p.hosts.empty()) p.specText.clear();
     {

@@ -74,7 +74,7 @@ def _blocks(rt, x, k0, nb, n_out):
 @pytest.mark.parametrize("name", sorted(CASES))
 @pytest.mark.parametrize("batch,spec", [(5, 0), (64, 0), (64, 2)])
 def test_taps_through_launch_sets(gpu_required, name, batch, spec):
-    """spec = 2 asks for run-time specialised kernels: a plan with tapOuts gets none (plan.cpp), the interpreter kernel renders it."""
+    """spec = 2 asks for run-time specialised kernels: a plan with tap nodes gets none (plan.cpp), the interpreter kernel renders it."""
     roots_fn, n_in, in_sets = CASES[name]
     a, c = _hip(44100.0, 512, batch_blocks=batch, specialize=spec), _checker(44100.0, 512)
     roots = roots_fn()
