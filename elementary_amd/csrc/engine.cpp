@@ -1784,7 +1784,7 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
     }
 }
 
-// the convolve nodes of level l over a whole launch set: three launches (conv.hip, "multi-block launches")
+// the convolve nodes of level l over a whole launch set: four launches (fft, mac, ifft, finish: conv.hip, "multi-block launches")
 void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32_t arenaFloats) {
     const uint32_t cb = p.convLevelOffsets[l], ce = p.convLevelOffsets[l + 1];
     uint32_t mains = 0;
