@@ -86,6 +86,7 @@ Plan::~Plan() {
 Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), device(dev) {
     auto fail = [&](int code) { initErr = code; };
     if (const char* e = std::getenv("ELEMHIP_SPECIALIZE")) specialize = std::max(0, std::min(2, std::atoi(e)));
+    if (const char* e = std::getenv("ELEMHIP_PLAN_CACHE")) planCache = std::max(0, std::min(2, std::atoi(e)));   // 2: verify mode (tests)
     if (bs <= 0 || bs > (int)kMaxBlock) { fail(kBlockTooLarge); return; }
     if (dev == -1) {
         // "dry" engine: host logic only (instruction decode, graph mutation, plan build, gc) with
@@ -1264,6 +1265,7 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "spec_blocks") { specBlocks = value != 0; return kOk; }      // elemhip_process through the specialised kernels when it can
     if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(1024, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
     if (key == "debug_build_delay_ms") { debugBuildDelayMs = std::max(0, (int)value); return kOk; }   // tests: stretches the unlocked part of a plan build
+    if (key == "plan_cache") { planCache = std::max(0, std::min(2, (int)value)); islandCache.clear(); return kOk; }
     if (key == "fuse_svf_coef") { fuseSvfCoef = (uint32_t)std::max(0, std::min(2, (int)value)); planStale = true; return kOk; }
     if (key == "solo_waves") { soloWaves = (uint32_t)std::max(0, std::min(3, (int)value)); planStale = true; return kOk; }
     if (key == "mixer_split") { const int v = (int)value; mixerSplit = (v == 2 || v == 4 || v == 8) ? (uint32_t)v : 1u; planStale = true; return kOk; }

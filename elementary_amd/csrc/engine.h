@@ -99,12 +99,22 @@ struct SpecText {
     uint32_t keyLdsWords = 0; // the LDS footprint the key was computed for
 };
 
+// One island's scheduled program as the planner left it (plan.cpp "island program cache"): an island whose nodes, edges,
+// arena positions and options are unchanged at the next build takes these instead of being scheduled again.
+struct IslandProgram {
+    Island I;                            // progBegin / rootRec are re-made per plan
+    std::vector<uint32_t> blob;          // its slice of Plan::prog (16-byte padded)
+    std::shared_ptr<SpecText> spec;      // specialised-kernel text of its shape (null: none)
+    uint32_t numMembers = 0, numOperands = 0, streamDelta = 0;
+};
+
 struct Stats {
     uint64_t blocksRendered = 0;
     uint64_t plansBuilt = 0;
     double   lastPlanBuildMs = 0.0;
     uint32_t numIslands = 0, numLevels = 0, numTasks = 0, numNodesInPlan = 0, maxLdsBytes = 0, numHbmBuffers = 0;
     uint64_t graphReplays = 0, graphCaptures = 0, batchLaunches = 0;
+    uint64_t planIslandsReused = 0, planIslandsScheduled = 0, planCacheMismatches = 0;   // island program cache (plan.cpp)
     uint64_t specLaunches = 0;             // launches of run-time specialised island kernels
     uint32_t specShapes = 0, specIslands = 0;
     double   lastJitWaitMs = 0.0;
@@ -187,6 +197,9 @@ private:
     // generated text per island-program signature: 256 voices (and every re-plan of a live graph) format their text once
     // (the kernel cache key of a text lives NEXT TO the text, in the same shared object: nothing is keyed by an address)
     std::unordered_map<uint64_t, std::shared_ptr<SpecText>> specTextCache;
+    // per-island programs of earlier builds (plan.cpp "island program cache"); same locking as specTextCache
+    std::unordered_map<uint64_t, std::shared_ptr<IslandProgram>> islandCache;
+    int planCache = 1;                     // 0 off, 1 reuse unchanged islands' programs, 2 schedule anyway and compare (tests)
     uint32_t planEpoch = 0;                // PlanBuilder::traverse marks
     int64_t curBlockTime = 0;              // sample time of the block being enqueued (call-out nodes get it as userData)
     bool shouldRebuild = false;

@@ -588,6 +588,52 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             continue;
         }
 
+        // ---- island program cache (commit -> first block): a re-plan after "one voice replaced" meets the other
+        // islands unchanged. Everything below is a function of the island's nodes (ids, opcodes, records, edges), of where its
+        // exports / imports sit in the arena, of the stream buffers handed out so far and of the planner options: keyed by a hash
+        // of exactly that, an unchanged island takes its Island header, program blob and kernel text from the previous build.
+        // `plan_cache` = 2 schedules anyway and compares (tests).
+        const uint32_t streamStart = p.numStreamBuffers;
+        uint64_t ikey = 0;
+        std::shared_ptr<IslandProgram> cached;
+        if (e.planCache != 0) {
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ull; h ^= h >> 29; };
+            mix(bs); mix(maxCopies); mix(splitCoefStage); mix(wantSpec); mix(e.fuseSvfCoef); mix(e.mergePhases); mix(e.soloWaves);
+            mix(e.mixerSplit); mix(e.chainLdsOut); mix(packCount[ii]); mix((uint32_t)islandPairsTaps[ii]); mix(streamStart);
+            mix(B.nodes.size());       // (the owning root's record is not an input of the schedule: Island::rootRec is re-made per plan)
+            for (int k : B.nodes) {
+                const NI& x = ni[k];
+                mix((uint32_t)x.n->id); mix(x.n->op); mix(x.rec); mix(x.ch); mix((uint32_t)x.kind); mix(x.exported); mix(x.hbm); mix(x.elided);
+                mix((uint32_t)(x.fusedRoot >= 0 ? ni[(size_t)x.fusedRoot].n->rec : kNone)); mix(x.needLds);
+                mix((uint32_t)(tapWriter[(size_t)k] >= 0 ? ni[(size_t)tapWriter[(size_t)k]].n->id : 0));
+                mix(x.n->inlets.size());
+                for (auto& in : x.n->inlets) {
+                    mix((uint32_t)in.source); mix(in.channel);
+                    auto it = idx.find(K(in.source, in.channel));
+                    if (it == idx.end()) { mix(0xDEADu); continue; }
+                    const NI& sn = ni[it->second];
+                    mix((uint32_t)sn.kind); mix(sn.island == x.island); mix(sn.hbm); mix(sn.rec); mix(sn.elided); mix(sn.n->op);
+                }
+            }
+            ikey = h;
+            auto it = e.islandCache.find(ikey);
+            if (it != e.islandCache.end()) cached = it->second;
+            if (cached && e.planCache == 1) {
+                I = cached->I;
+                I.progBegin = (uint32_t)p.prog.size();
+                I.rootRec = seqRoots[B.seq]->rec;
+                p.prog.insert(p.prog.end(), cached->blob.begin(), cached->blob.end());
+                p.numStreamBuffers += cached->streamDelta;
+                if (packCount[ii] > 1u) minPackedCopies = minPackedCopies ? std::min(minPackedCopies, I.copies) : I.copies;
+                p.maxCopies = std::max(p.maxCopies, I.copies);
+                p.maxLdsBytes = std::max(p.maxLdsBytes, I.ldsWords * 4u);
+                if (cached->spec) { if (p.specText.size() < ib.size()) p.specText.resize(ib.size()); p.specText[ii] = cached->spec; }
+                p.numTasks += I.numTasks; p.numMembers += cached->numMembers; p.numOperands += cached->numOperands;
+                e.st.planIslandsReused++;
+                continue;
+            }
+        }
         // imports needed in LDS: external producers (or host inputs) feeding chain members
         struct Import { uint32_t hbm; int lastUse; uint32_t lds; };
         std::vector<Import> imports;
@@ -1352,6 +1398,23 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             p.specText[ii] = it->second;
         }
         p.numTasks += I.numTasks; p.numMembers += (uint32_t)members.size(); p.numOperands += (uint32_t)operands.size();
+        if (e.planCache != 0) {
+            auto ent = std::make_shared<IslandProgram>();
+            ent->I = I;
+            ent->blob.assign(p.prog.begin() + I.progBegin, p.prog.end());
+            if (ii < p.specText.size()) ent->spec = p.specText[ii];
+            ent->numMembers = (uint32_t)members.size(); ent->numOperands = (uint32_t)operands.size();
+            ent->streamDelta = p.numStreamBuffers - streamStart;
+            if (cached) {          // plan_cache = 2: the cached program must be what was just scheduled
+                Island a = cached->I, b2 = I;
+                a.progBegin = b2.progBegin = 0u; a.rootRec = b2.rootRec = 0u;
+                const bool same = std::memcmp(&a, &b2, sizeof(Island)) == 0 && cached->blob == ent->blob && cached->spec == ent->spec &&
+                                  cached->streamDelta == ent->streamDelta && cached->numMembers == ent->numMembers;
+                if (!same) { e.st.planCacheMismatches++; std::fprintf(stderr, "[elemhip] plan cache: island %zu differs from its cached program\n", ii); }
+            }
+            e.islandCache[ikey] = std::move(ent);
+            e.st.planIslandsScheduled++;
+        }
     }
 
     phase("island programs");
@@ -1405,6 +1468,7 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     const uint32_t ldsLimit = 160u * 1024u - 1024u;
     // the text cache is only ever trimmed BETWEEN builds (texts in use stay alive through the shared objects the plan holds)
     if (specTextCache.size() > 4096) specTextCache.clear();
+    if (islandCache.size() > 8192) islandCache.clear();
     // Lane-packing (option "pack_islands": 0 auto, 1 off, K): the first attempt packs as the option says; a packed island
     // that does not fit in LDS, or fits with a single buffer set (no blocks in flight: the stages of a block would run back
     // to back), sends the build back with one island fewer per pack.
@@ -1544,6 +1608,7 @@ std::string Engine::describePlan() {
     auto kv = [&](const char* k, uint64_t v, bool comma = true) { s += "\"" + std::string(k) + "\":" + std::to_string(v) + (comma ? "," : ""); };
     kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.numTasks);
     kv("num_members", p.numMembers); kv("num_operands", p.numOperands); kv("num_nodes", p.nodeIds.size());
+    kv("plan_islands_reused", st.planIslandsReused); kv("plan_islands_scheduled", st.planIslandsScheduled); kv("plan_cache_mismatches", st.planCacheMismatches);
     kv("num_hbm_buffers", p.numHbmBuffers); kv("num_stream_buffers", p.numStreamBuffers); kv("pack_k", p.packK);
     kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());
     kv("num_taps", p.taps.size()); kv("taps_in_sets", p.tapsInSets ? 1 : 0); kv("num_tap_nodes", p.taps.size() + p.tapPairs.size()); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());

@@ -250,3 +250,39 @@ def test_process_does_not_wait_for_a_plan_build():
     assert done["rc"] == 0 and done["s"] >= 0.5
     assert calls >= 20 and worst < 0.1, (calls, worst)
     assert rt.describe_plan()["num_roots"] == 2
+
+
+def test_island_program_cache_reuses_unchanged_islands():
+    """plan.cpp "island program cache": on the C5 mutation stream (one voice of 128 replaced per batch) a re-plan takes the
+    unchanged voices' Island headers, program blobs and kernel texts from the previous build. `plan_cache` = 2 schedules every
+    island anyway and compares it with the cached program byte for byte; = 1 must end with the same plan as = 0."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "benchmarks"))
+    import bench_configs as B
+    texts, _, _ = B._c5_batches(128, 24)
+    plans = {}
+    for mode in (0, 1, 2):
+        rt = dry(graphs.C2_SAMPLE_RATE)
+        rt.set_option("plan_cache", mode)
+        rt.set_option("specialize", 2)
+        for i, t in enumerate(texts):
+            assert rt.apply_instructions_json(t) == 0
+            if i % 16 == 15:
+                rt.gc()
+        plans[mode] = rt.describe_plan()
+    assert plans[2]["plan_cache_mismatches"] == 0 and plans[2]["plan_islands_scheduled"] > 24 * 128
+    assert plans[1]["plan_islands_reused"] > 20 * 120                 # ~126 of 130 islands per re-plan
+    strip = lambda p: {k: v for k, v in p.items() if not k.startswith("plan_")}      # noqa: E731
+    assert strip(plans[1]) == strip(plans[0]) == strip(plans[2])
+    # other graph families through the comparing mode: every node case, re-rendered twice (second build: all hits)
+    from cases import NODE_CASES, node_case_resources
+    rt = dry(44100.0)
+    rt.set_option("plan_cache", 2)
+    for name, data in node_case_resources().items():
+        assert rt.add_shared_resource(name, data)
+    for name in sorted(NODE_CASES):
+        roots = NODE_CASES[name][0]()
+        assert rt.render(*roots)["result"] == 0
+        assert rt.render(*roots[:1])["result"] == 0
+        assert rt.render(*roots)["result"] == 0
+    assert rt.describe_plan()["plan_cache_mismatches"] == 0
