@@ -1468,7 +1468,7 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     const uint32_t ldsLimit = 160u * 1024u - 1024u;
     // the text cache is only ever trimmed BETWEEN builds (texts in use stay alive through the shared objects the plan holds)
     if (specTextCache.size() > 4096) specTextCache.clear();
-    if (islandCache.size() > 8192) islandCache.clear();
+    if (islandCache.size() > 2048) islandCache.clear();      // (entries of replaced islands are never looked up again: ~8 KB each)
     // Lane-packing (option "pack_islands": 0 auto, 1 off, K): the first attempt packs as the option says; a packed island
     // that does not fit in LDS, or fits with a single buffer set (no blocks in flight: the stages of a block would run back
     // to back), sends the build back with one island fewer per pack.
