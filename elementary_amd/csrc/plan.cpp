@@ -220,6 +220,10 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     }
     if (++e.planEpoch == 0u) { for (auto& kv : e.nodes) kv.second.planVisited = kv.second.planOnStack = 0u; e.planEpoch = 1u; }
     const uint32_t epoch = e.planEpoch;
+    idx.reserve(e.nodes.size() + e.nodes.size() / 4 + 16);
+    ni.reserve(e.nodes.size() + 16);
+    std::vector<int32_t> planNodeIds;
+    planNodeIds.reserve(e.nodes.size());
     for (size_t s = 0; s < sortedRoots.size(); ++s) {
         std::vector<Node*> order;
         traverse(epoch, order, sortedRoots[s]);
@@ -243,9 +247,12 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 seqNodes.back().push_back((int)ni.size());
                 ni.push_back(x);
             }
-            p.nodeIds.insert(id);
+            planNodeIds.push_back(id);
         }
     }
+    std::sort(planNodeIds.begin(), planNodeIds.end());
+    planNodeIds.erase(std::unique(planNodeIds.begin(), planNodeIds.end()), planNodeIds.end());
+    p.nodeIds = std::set<int32_t>(planNodeIds.begin(), planNodeIds.end());   // (built from the sorted range: linear)
 
     // ---- 1b. nodes folded into the convolve launch ------------------------------------------------------
     // `root(convolve(in))` is the whole graph of a convolution reverb channel: three launch levels for one
