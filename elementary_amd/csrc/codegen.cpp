@@ -118,10 +118,6 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
                         for (uint32_t j = 0; j < mm.nin; ++j) if ((operands[mm.opnd + j] & kOpKindMask) == kOpLds) plainFamily = false;
                     }
                     for (uint32_t k = 0; k < tasks[q].count; ++k) if (members[tasks[q].first + k].outHbm != kNone) writes = true;
-                    // a tapOut's private block is global memory the tapIn of the NEXT block reads from another wave (taps inside
-                    // launch sets, plan.cpp): the slot's publish has to wait for those stores like for arena stores (without it
-                    // one block in a few hundred read the previous contents: test_gpu_taps `cross`, `not_a_loop`)
-                    if (tasks[q].opcode == OP_TAPOUT) writes = true;
                 }
             o << "    static constexpr uint32_t stage = " << st << "u, prev = " << u(prev) << ", prevT = " << (prev == kNone ? 0u : stageTab[prev])
               << "u, ntasks = " << ntasks << "u;\n    static constexpr bool writesStreams = " << (writes ? "true" : "false")

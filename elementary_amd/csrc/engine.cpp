@@ -950,13 +950,6 @@ int Engine::commit(std::unique_lock<std::mutex>& renderLock) {   // Runtime.h:20
         // the rebuild stays owed so that the next commit retries instead of rendering the old sequence forever.)
         if (!p) { rebuildOwed = true; return kUnsupportedGraph; }
         rebuildOwed = false;
-        for (auto& pr : p->tapPairs) {        // a tapIn's record names the private buffer of the tapOut it follows inside a launch set
-            auto tin = nodes.find(pr.first);
-            if (tin == nodes.end()) continue;
-            void* priv = nullptr;
-            if (pr.second) { auto tout = nodes.find(pr.second); if (tout != nodes.end()) priv = tout->second.ring.ptr; }
-            writeParamPtr(tin->second, rec::TAP_PRIVATE, priv);
-        }
         pending = p;
         shouldRebuild = false;
         st.plansBuilt++;
@@ -1479,7 +1472,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     if (rc != kOk) return rc;
     // A whole block of a settled sequence whose island shapes are all compiled goes through the specialised kernels as a
     // launch set of one (stages pipelined inside the workgroup, no interpreter image); everything else block by block.
-    const bool specBlock = specBlocks && n == (size_t)blockSize && p.convs.empty() && specReady(p) && batchEligible(p, nOut);
+    const bool specBlock = specBlocks && n == (size_t)blockSize && p.convs.empty() && specReady(p) && batchEligible(p, nOut, true);
     if (specBlock) {
         rc = ensureHbm(arenaBuffers(p, 1));
         if (rc != kOk) return rc;
@@ -1650,8 +1643,10 @@ bool Engine::specReady(const Plan& p) const {
     return true;
 }
 
-bool Engine::batchEligible(const Plan& p, size_t nOut) const {
-    if ((!p.taps.empty() && !p.tapsInSets) || !p.hosts.empty()) return false;
+// (oneBlock: a launch set of ONE — the batch epilogue promotes the taps after it like the per-block epilogue does, so tap
+// pairs that do not sit in one island are no obstacle)
+bool Engine::batchEligible(const Plan& p, size_t nOut, bool oneBlock) const {
+    if ((!oneBlock && !p.taps.empty() && !p.tapsInSets) || !p.hosts.empty()) return false;
     // convolvers: the multi-block kernels (conv.hip) assume every node's 512-frame input block is empty at the start of a
     // launch set, i.e. that every call so far rendered whole 512-frame blocks
     if (!p.convs.empty() && !(convAligned && blockSize == (int)conv::kBlock)) return false;

@@ -306,7 +306,7 @@ private:
     void enqueueBatch(const Plan& p, uint32_t batch, float* outRing = nullptr);
     void launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32_t arenaFloats);
     void launchLevelBatch(const Plan& p, size_t level, uint32_t batch, uint32_t arenaFloats);   // specialised kernels when ready, else the interpreter
-    bool batchEligible(const Plan& p, size_t nOut) const;
+    bool batchEligible(const Plan& p, size_t nOut, bool oneBlock = false) const;
     bool specReady(const Plan& p) const;
     void mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn);
     int  setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime);

@@ -539,6 +539,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 if (ni[k].island != ni[uniq[0]].island) { p.tapsInSets = false; continue; }
                 tapWriter[(size_t)k] = uniq[0];
                 islandPairsTaps[(size_t)ni[k].island] = 1;
+                ni[(size_t)uniq[0]].needLds = true;   // the hand-over goes through the tapOut's LDS slot (below)
             }
         }
         for (size_t k = 0; k < ni.size(); ++k)
@@ -743,6 +744,13 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             return tag | (uint32_t)s0;
         };
         for (auto& im : imports) im.lds = takeSlots(0, 1, im.lastUse);
+        // A paired tapOut's output slot belongs to it for the whole block, every block: with one block in flight the slot still
+        // holds block b when the tapIns of block b + 1 run (stage `base`, before the tapOut's own stage), so the hand-over never
+        // leaves LDS — the same completion counters that order every other buffer of the island order it (run_tapin).
+        std::vector<int> pairedOut;
+        if (islandPairsTaps[ii])
+            for (int k : B.nodes) if (tapWriter[(size_t)k] >= 0 && std::find(pairedOut.begin(), pairedOut.end(), tapWriter[(size_t)k]) == pairedOut.end()) pairedOut.push_back(tapWriter[(size_t)k]);
+        for (int k : pairedOut) ni[(size_t)k].lds = takeSlots(0, 1, maxStage);
         for (int stage = base; stage <= maxStage; ++stage) {
             for (int k : B.nodes) {   // coefficient scratch of the svf's that scan in the NEXT stage
                 NI& x = ni[k];
@@ -756,7 +764,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             for (int k : B.nodes) {
                 NI& x = ni[k];
                 if (x.level != stage) continue;
-                if (x.needLds && !blepSplit(x.n->op)) x.lds = takeSlots(stage, 1, x.lastUse);
+                if (x.needLds && !blepSplit(x.n->op) && std::find(pairedOut.begin(), pairedOut.end(), k) == pairedOut.end()) x.lds = takeSlots(stage, 1, x.lastUse);
                 const uint32_t sc = scratchSlots(x.n->op);
                 if (sc && x.n->op != OP_SVF && x.n->op != OP_SVFSHELF) x.scratch = takeSlots(stage, sc, stage);
             }
@@ -766,6 +774,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             auto resolve = [&](uint32_t v) { return v == kNone ? v : kSlot0 + ((v & kLongBit) ? nShort + (v & ~kLongBit) : v) * kSlotWords; };
             for (auto& im : imports) im.lds = resolve(im.lds);
             for (int k : B.nodes) { ni[k].lds = resolve(ni[k].lds); ni[k].scratch = resolve(ni[k].scratch); }
+            // a paired tapIn names its writer's slot (Member::scratch; run_tapin reads it from the set's second block on)
+            for (int k : B.nodes) if (tapWriter[(size_t)k] >= 0) ni[k].scratch = ni[(size_t)tapWriter[(size_t)k]].lds;
         }
         const uint32_t slotArea = (uint32_t)(slotFreeAt[0].size() + slotFreeAt[1].size()) * kSlotWords;      // block-buffer words of one copy
         bool statelessIsland = true;
@@ -1513,15 +1523,10 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     const size_t oConvWork = place(p.convWork.size() * 4);
     // ---- specialised kernels: group each level's islands by generated text, queue the shapes for compilation ----
     double jitWaitMs = -1.0;
-    // Call-out nodes never render through launch sets (Engine::batchEligible); a plan with tapOuts does when its pairs sit in one
-    // island, but through the INTERPRETER kernel. The specialised kernel of such an island renders a tap loop 4.7x faster (r03:
-    // 83.6 -> 17.6 us per block, tools/tap_loop_bench.py with ELEMHIP_EXP_SPEC_TAPS=1) and is not shipped: after two fixes found by
-    // bisecting (tools/tap_spec_fault.py: wave-uniform reads of the tap pointers, vmcnt(0) before a tapOut slot publishes) the
-    // `cross` and `not_a_loop` graphs of tests/test_gpu_taps.py still get one block in ~150 wrong and some runs fault. Any tap node
-    // keeps a plan on the interpreter kernels until that is understood.
-    static const bool specTaps = std::getenv("ELEMHIP_EXP_SPEC_TAPS") != nullptr;
-    const bool anyTap = !p.taps.empty() || !p.tapPairs.empty();
-    if ((anyTap && !(specTaps && p.tapsInSets)) || !p.hosts.empty()) p.specText.clear();
+    // Call-out nodes synchronise with the host inside a block: their plans render block at a time through the interpreter kernels.
+    // (Plans with tap nodes keep their specialised kernels: a paired tapIn takes its block from the tapOut's LDS slot, an unpaired
+    // one from the shared buffer the per-block promotion fills — neither needs anything the specialised kernels lack.)
+    if (!p.hosts.empty()) p.specText.clear();
     {
         const size_t L = p.levelOffsets.size() - 1;
         p.restOffsets.assign(L + 1, 0);

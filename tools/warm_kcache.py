@@ -2,7 +2,7 @@
 suite and the benchmarks render, by building their plans on a dry engine (no GPU needed: hiprtc cross-compiles for
 gfx950). The cache travels with the tree; a miss only costs the compile at first use.
 Usage: python tools/warm_kcache.py [bench|tests|all]"""
-import os as _os, sys as _sys; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))); _sys.path[:0] = [_R, _os.path.join(_R, 'tests')]
+import os as _os, sys as _sys; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))); _sys.path[:0] = [_R, _os.path.join(_R, 'tests'), _os.path.join(_R, 'tools')]
 import sys
 import time
 
@@ -54,6 +54,12 @@ def main():
         for bs in (64, 192, 256):                      # tests/test_gpu_spec.py::test_spec_other_block_sizes
             jobs.append((f"c2x16_bs{bs}", 48000.0, bs, graphs.c2_graph(voices=16), None, None))
             jobs.append((f"stateful_bs{bs}", 48000.0, bs, every_stateful_roots(), None, None))
+        import test_gpu_taps, tap_soak                  # tap islands (one block in flight) and the 8-loop soak graph
+        for name, (fn, _n_in) in sorted(tap_soak.GRAPHS.items()):
+            jobs.append((f"taps_{name}", 44100.0, 512, fn(), None, None))
+        for name, case in sorted(test_gpu_taps.CASES.items()):
+            if not case[2]: jobs.append((f"taps_{name}", 44100.0, 512, case[0](), None, None))
+        jobs.append(("tap_loop_bench", 48000.0, 512, tap_soak._bench_graph(), None, None))
         for copies in (1, 3, 6):
             jobs.append((f"stateful_d{copies}", 48000.0, 512, every_stateful_roots(), None, copies))
     for name, sr, bs, roots, res, copies in jobs:
