@@ -131,6 +131,87 @@ def cpu_baseline_multicore(single_ms_per_block: float, target_seconds: float = 8
     return out
 
 
+def _c4_worker(args):
+    """One host process of the C4 CPU leg: ONE reference Runtime PER INSTANCE (each offline render job owns its
+    engine, offline-renderer/index.ts:87-133), rendered job after job, `blocks` blocks each from time zero; the last `tail`
+    blocks of every job come back."""
+    ks, blocks, tail, core = args
+    import numpy as np
+    import oracle
+    from elementary_amd import graphs
+    try:
+        os.sched_setaffinity(0, {core})
+    except Exception:
+        pass
+    rts = []
+    for k in ks:
+        rt = oracle.RefRuntime(graphs.C4_SAMPLE_RATE, BLOCK, bench_build=os.path.exists(oracle.REF_BENCH_SO))
+        assert rt.render(graphs.c4_instance(k))["result"] == 0
+        rts.append(rt)
+    tails = {}
+    t0 = time.perf_counter()
+    for k, rt in zip(ks, rts):
+        last = []
+        for b in range(blocks):
+            y = rt.process(None, 1, BLOCK)
+            if b >= blocks - tail:
+                last.append(y[0].copy())
+        if tail:
+            tails[k] = np.concatenate(last)
+    return time.perf_counter() - t0, tails
+
+
+def c4_cpu_baseline(inst: int, first: int = 0, target_seconds: float = 12.0):
+    """The reference engine on the host cores of this box, the way the offline renderer would run the same jobs: P pinned
+    processes, the `inst` jobs dealt round-robin, one Runtime per job. A bounded sample: M blocks per job."""
+    import multiprocessing as mp
+    import oracle
+    if not oracle.have_ref():
+        return None
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    P = max(1, min(32, len(avail), inst))
+    ctx = mp.get_context("spawn")       # the parent holds a HIP context: never fork it
+    with ctx.Pool(P) as pool:
+        cal = pool.map(_c4_worker, [([first], 400, 0, avail[0])])[0][0] / 400.0          # seconds per job-block on one core
+        per_proc = (inst + P - 1) // P
+        M = int(max(200, min(20000, target_seconds / (cal * per_proc))))
+        res = pool.map(_c4_worker, [([first + k for k in range(p_, inst, P)], M, 0, avail[p_ % len(avail)]) for p_ in range(P)])
+    dt = max(r[0] for r in res)
+    return {"value": inst * BLOCK * M / dt, "unit": "samples/s", "cores": P, "kind": "reference",
+            "sample": f"{M} blocks of {BLOCK} frames of each of the same {inst} render jobs from time zero, one reference Runtime per job, "
+                      f"{P} pinned host processes ({per_proc} jobs each, job after job)",
+            "us_per_job_block_one_core": 1e6 * cal, "ms_per_block_step": 1e3 * dt / M}
+
+
+def c4_parity(timed_host, inst: int, first: int, total_blocks: int, tail: int = 64, jobs: int = 8, budget_seconds: float = 90.0,
+              us_per_job_block: float = 15.0):
+    """The LAST `tail` blocks of the timed region for `jobs` of the render jobs, against reference engines advanced from
+    time zero through all `total_blocks` blocks (one process per job)."""
+    import multiprocessing as mp
+    import numpy as np
+    import oracle
+    if not oracle.have_ref() or timed_host is None:
+        return None
+    picks = sorted({k for k in (0, 1, 2, 3, inst // 2 - 1, inst // 2, inst - 2, inst - 1, 17, 42) if 0 <= k < inst})[:max(1, jobs)]
+    if total_blocks * us_per_job_block * 1e-6 > budget_seconds:
+        return {"ok": None, "note": f"not checked: advancing a reference engine through {total_blocks} blocks exceeds the {budget_seconds:.0f} s budget"}
+    tail = min(tail, total_blocks)
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(min(len(picks), max(1, len(avail)))) as pool:
+        res = pool.map(_c4_worker, [([first + k], total_blocks, tail, avail[i % len(avail)]) for i, k in enumerate(picks)])
+    worst, peak = 0.0, 0.0
+    for (dt_, tails), k in zip(res, picks):
+        ref = tails[first + k]
+        got = timed_host[k, -tail * BLOCK:]
+        worst = max(worst, float(np.abs(got - ref).max()))
+        peak = max(peak, float(np.abs(ref).max()))
+    tol = 1e-6 * max(1.0, peak)
+    return {"ok": bool(worst <= tol), "max_abs_err": worst, "tolerance": tol, "jobs_checked": [first + k for k in picks], "blocks_checked_per_job": tail,
+            "reference_advanced_blocks": total_blocks, "max_abs_ref": peak,
+            "what": f"last {tail} blocks of the timed region of {len(picks)} render jobs vs reference engines advanced from time zero through all {total_blocks} blocks"}
+
+
 def main_c4(args) -> None:
     """BASELINE configs[3] (C4): `--instances` independent offline render jobs per GPU (1024 over 8 GPUs = 128 per GPU),
     "RCCL output gather". SURVEY.md 8(e): the unit of sharding is the whole render job, so ranks share nothing while they
@@ -207,6 +288,18 @@ def main_c4(args) -> None:
         dt = float(t.item())
     if rank == 0:
         blocks = args.steps * B
+        parity = c4_parity(timed_host, inst, inst * rank, (args.warmup + args.steps) * B) if host_mode else None
+        base = None if args.no_cpu_baseline else c4_cpu_baseline(inst, inst * rank)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_c4.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if int(tj.get("instances", 0)) == inst and int(tj.get("blocks_per_launch", 0)) == B:
+                    traffic = tj.get("hbm_bytes_per_launch_set")
+                    traffic_src = "profiles/traffic_c4.json (rocprofv3 PMC passes of this command, committed; not re-measured in this run): " + str(tj.get("round", ""))
+            except Exception:
+                traffic = None
         alg = graphs.c4_algorithmic_bytes(inst)                  # per block-step of one rank
         us = 1e6 * dt / blocks
         sets = max(1, prof["launch_sets"])
@@ -228,10 +321,13 @@ def main_c4(args) -> None:
                                        f"({gathered_elems * 4 / max(1, args.steps) / 1e6:.1f} MB per step); nothing is exchanged while rendering")},
             "us_per_block_step": us, "plan_build_ms": build_ms,
             "roofline": {"bound": "hbm", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                         "algorithmic_bytes_per_block_step": alg,
+                         "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_block_step": alg, "algorithmic_bytes_per_launch_set": alg * B,
                          "launch_us_per_step": [1e3 * x / sets for x in prof["level_ms"]],
-                         "note": "bound by the float recurrences (biquad, delay feedback) of the instances, not by bytes"},
+                         "note": "bound by the float recurrences (biquad, delay feedback) of the instances, not by bytes; `traffic` = PMC HBM "
+                                 "bytes of one launch set (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md)"},
+            "cpu_baseline": base, "speedup_vs_cpu_baseline": (world * inst * BLOCK * blocks / dt) / base["value"] if base else None,
+            "parity": parity,
         }))
     if world > 1:
         dist.destroy_process_group()

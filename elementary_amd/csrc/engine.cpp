@@ -17,6 +17,16 @@
 
 namespace elemhip {
 
+// ELEMHIP_DEBUG_SYNC=1 (fault hunting on the GPU box): every launch is followed by a device synchronise and a line on stderr, so
+// the last line printed before a "Memory access fault" abort names the kernel that faulted.
+static bool debugSyncOn() { static const bool on = std::getenv("ELEMHIP_DEBUG_SYNC") != nullptr; return on; }
+static void debugSync(const char* what, unsigned a = 0, unsigned b = 0) {
+    if (!debugSyncOn()) return;
+    std::fprintf(stderr, "[elemhip sync] %s %u %u ...", what, a, b); std::fflush(stderr);
+    const hipError_t e = hipDeviceSynchronize();
+    std::fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); std::fflush(stderr);
+}
+
 #define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     std::fprintf(stderr, "[elemhip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return kHipError; } } while (0)
 #define HIP_WARN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
@@ -1320,6 +1330,7 @@ int Engine::flushPending() {
         const size_t cnt = std::min<size_t>(patchCap - patchCursor, patches.size() - off);
         std::memcpy(hPatches + patchCursor, patches.data() + off, cnt * sizeof(Patch));
         launch_patches(stream, hPatches + patchCursor, (uint32_t)cnt, dRecs, reinterpret_cast<uint32_t*>(dGlobals));
+        debugSync("patches", (unsigned)cnt);
         patchCursor += cnt;
         off += cnt;
     }
@@ -1386,11 +1397,13 @@ void Engine::enqueueBlock(const Plan& p, float* outRing) {
     for (size_t l = 0; l < L; ++l) {
         const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
         if (e > b) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l]);
+        debugSync("block: interpreter level", (unsigned)l, e - b);
         const uint32_t cb = p.convLevelOffsets[l], ce = p.convLevelOffsets[l + 1];
         if (ce > cb) launch_convolve(stream, p.view, dRecs, dHbm, dGlobals, cb, ce - cb);
         if (!p.hosts.empty()) (void)renderHostNodes(p, l);
     }
     launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, outRing);
+    debugSync("block: epilogue");
 }
 
 // Call-out nodes of launch level `l` (GraphNode::process on the CPU, GraphNode.h:72): drain the stream, bring each node's
@@ -1720,7 +1733,7 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         }
         if (!any) spec = false;
     }
-    if (!spec) { launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats, statelessRows); return; }
+    if (!spec) { launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats, statelessRows); debugSync("set: interpreter level", (unsigned)l, batch); return; }
     // The launches of one level are independent of each other (different islands): with more than one they go to side
     // streams forked from / joined to the engine's stream, so two shapes of 64 islands each fill 128 CUs at once
     // instead of 64 CUs twice.
@@ -1767,11 +1780,13 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         void* args[] = {&pv, &recs, &hbm, &g, &lcg, &list, &bt, &af, &sb, &ss};
         HIP_WARN(hipModuleLaunchKernel(f.first, f.second->count, 1, 1, kThreads, 1, 1, 0, st_, args, nullptr));
         st.specLaunches++;
+        debugSync("set: specialised shape", f.second->count, batch);
     }
     if (re > rb) {
         PlanView pv = p.view;
         pv.levelIslands = p.dRestIslands;
         launch_level(streamFor(k++), pv, dRecs, dHbm, dGlobals, dLcg, rb, re - rb, p.levelLdsBytes[l], batch, arenaFloats, statelessRows);
+        debugSync("set: interpreter rest", re - rb, batch);
     }
     if (fork) {
         for (size_t i = 1; i < launches; ++i) {
@@ -1804,6 +1819,7 @@ void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
     }
     if (prof) (void)hipEventRecord(profEvent(), stream);
     launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, outRing, batch, arenaFloats);
+    debugSync("set: epilogue", batch);
     if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)L); profSets++; profBlocks += batch; }
 }
 
@@ -1828,7 +1844,7 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
     if (!current || numBlocks == 0) return kOk;
     Plan& p = *current;
     const size_t bs = (size_t)blockSize;
-    const bool graphOk = useGraph && p.hosts.empty();   // call-out nodes synchronise inside a block: nothing to capture
+    const bool graphOk = useGraph && p.hosts.empty() && !debugSyncOn();   // call-out nodes synchronise inside a block: nothing to capture
     const bool haveIn = nIn > 0 && inDev != nullptr;
     const size_t G = graphOk ? (size_t)graphBlocks : 1;
     rc = ensureOutRing(std::max<size_t>(nOut, 1) * bs * G);

@@ -65,6 +65,29 @@ def test_bench_geometry_full_c2(gpu_required, batch):
     assert float(err[batch - 8:batch + 8].max()) <= TOL * scale and float(err[-8:].max()) <= TOL * scale
 
 
+def test_bench_geometry_full_c4(gpu_required):
+    """What `bench.py --workload c4` times, checked for every instance and every block (BASELINE configs[3], one GPU's share;
+    offline-renderer/index.ts:87-133 is the caller): 128 independent render instances = 128 output channels, specialize = 2,
+    1024-block launch sets through elemhip_process_blocks_host — a full set (268 MB: the host scatter runs on several
+    threads, engine.cpp processBlocksHost) and a ragged one that is still above the 16 MB threshold."""
+    inst, batch = 128, 1024
+    nb = batch + 90
+    a, c = _hip(graphs.C4_SAMPLE_RATE, 512, specialize=2, batch_blocks=batch), _checker(graphs.C4_SAMPLE_RATE, 512)
+    roots = [graphs.c4_instance(k) for k in range(inst)]
+    assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
+    got = a.process_blocks_host(None, inst, nb * 512)
+    st = a.stats()
+    assert st["spec_launches"] >= 2 and st["batch_launches"] >= 2, st
+    assert got.shape == (inst, nb * 512)
+    ref = _ref_planar(c, inst, nb)
+    assert float(np.abs(ref).max()) > 0.05
+    err = np.abs(got - ref).reshape(inst, nb, 512).max(axis=2)                   # [instance, block]
+    wi, wb = np.unravel_index(int(err.argmax()), err.shape)
+    assert float(err.max()) <= TOL * max(1.0, float(np.abs(ref).max())), f"instance {wi} block {wb}: {err.max():.3e}"
+    # every instance produced its own stream (a scatter that mixed channels up would pass a max-error test on silence only)
+    assert len({got[k, 5000:5064].tobytes() for k in range(inst)}) == inst
+
+
 def test_host_path_equals_device_path(gpu_required):
     """elemhip_process_blocks_host vs elemhip_process_blocks on two engines with the same options: bit-identical, for a
     frame count that is not a multiple of the block size (the tail block is rendered whole, delivered cut)."""

@@ -45,12 +45,11 @@ def _render_blocks(rt, nb, n_out, x=None, block=512):
 
 def _assert_ran_specialised(rt):
     """Unconditional wherever the plan has a stateful island program (the planner writes a specialised kernel for every
-    such island when the block is a multiple of 64 frames and the plan has no tapIn / tapOut node): the shape must exist, be compiled and
+    such island when the block is a multiple of 64 frames, tap islands included): the shape must exist, be compiled and
     have been launched. Plans of stateless islands only (pure math / mixers) must have no shape at all."""
     st = rt.stats()
     plan = rt.describe_plan()
-    expect = (plan["num_tap_nodes"] == 0 and rt.block_size % 64 == 0
-              and any(i["stateless"] == 0 and i["tasks"] > 0 for i in plan["islands"]))
+    expect = (rt.block_size % 64 == 0 and any(i["stateless"] == 0 and i["tasks"] > 0 for i in plan["islands"]))
     if not expect:
         assert st["spec_shapes"] == 0, st
         return

@@ -32,7 +32,7 @@ GRAPHS = {k: (v[0], v[1]) for k, v in T.CASES.items() if v[2]}
 GRAPHS["eight_loops"] = (_bench_graph, 1)
 
 
-def soak(name, nb, batch=64, spec=2):
+def soak(name, nb, batch=64, spec=2, pattern="mixed"):
     roots_fn, n_in = GRAPHS[name]
     a = Runtime(44100.0, 512, device=0)
     a.set_option("batch_blocks", batch); a.set_option("specialize", spec)
@@ -46,7 +46,7 @@ def soak(name, nb, batch=64, spec=2):
     torch.cuda.synchronize()
     # odd call sizes: sets of `batch`, ragged tails, single blocks in between
     cuts, k = [], 0
-    sizes = [batch * 3 + 7, 1, batch, 2, batch * 5 + 1, 1, 1]
+    sizes = [batch * 3 + 7, 1, batch, 2, batch * 5 + 1, 1, 1] if pattern == "mixed" else [batch * 4]
     i = 0
     while k < nb:
         n = min(sizes[i % len(sizes)] if i < 14 else batch * 16, nb - k)
@@ -84,11 +84,18 @@ def soak(name, nb, batch=64, spec=2):
 
 
 if __name__ == "__main__":
-    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-    names = sys.argv[2:] or sorted(GRAPHS)
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("blocks", nargs="?", type=int, default=5000)
+    ap.add_argument("graphs", nargs="*")
+    ap.add_argument("--spec", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--pattern", choices=["mixed", "sets"], default="mixed", help="sets: calls of 4 x batch blocks only (no single-block calls)")
+    a_ = ap.parse_args()
+    nb, names = a_.blocks, a_.graphs or sorted(GRAPHS)
     rc = 0
     for name in names:
-        row = soak(name, nb)
+        row = soak(name, nb, a_.batch, a_.spec, a_.pattern)
         print(json.dumps(row), flush=True)
-        rc |= row["bad_blocks"] != 0 or row["spec_launches"] == 0
+        rc |= row["bad_blocks"] != 0 or (a_.spec != 0 and row["spec_launches"] == 0)
     sys.exit(rc)

@@ -1,7 +1,7 @@
 """Fill the on-disk kernel cache (elementary_amd/kcache/) with the specialised island kernels of the graphs the test
 suite and the benchmarks render, by building their plans on a dry engine (no GPU needed: hiprtc cross-compiles for
 gfx950). The cache travels with the tree; a miss only costs the compile at first use.
-Usage: python tools/warm_kcache.py [bench|tests|all]"""
+Usage: python tools/warm_kcache.py [bench|tests|all] [i/n]"""
 import os as _os, sys as _sys; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))); _sys.path[:0] = [_R, _os.path.join(_R, 'tests'), _os.path.join(_R, 'tools')]
 import sys
 import time
@@ -62,6 +62,9 @@ def main():
         jobs.append(("tap_loop_bench", 48000.0, 512, tap_soak._bench_graph(), None, None))
         for copies in (1, 3, 6):
             jobs.append((f"stateful_d{copies}", 48000.0, 512, every_stateful_roots(), None, copies))
+    if len(sys.argv) > 2:      # "i/n": this process takes every n-th job (several processes warm the cache in parallel)
+        i, n = (int(v) for v in sys.argv[2].split("/"))
+        jobs = jobs[i::n]
     for name, sr, bs, roots, res, copies in jobs:
         s, b, ms = warm(sr, bs, roots, res, copies=copies)
         shapes += s; bad += b
