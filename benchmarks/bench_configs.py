@@ -96,6 +96,9 @@ def c3(args):
     assert rt.render(*graphs.c3_graph(ch))["result"] == 0
     set_blocks = args.batch_blocks or 1024
     rt.set_option("batch_blocks", set_blocks)
+    for kv in args.opt:
+        k_, v_ = kv.split("=", 1)
+        rt.set_option(k_, float(v_))
     x = graphs.c3_input(ch, 64 * BLOCK)
     xin = torch.from_numpy(np.ascontiguousarray(x.reshape(ch, 64, BLOCK).transpose(1, 0, 2))).cuda().repeat(max(4, set_blocks // 64), 1, 1).contiguous()
     g = _time_gpu(rt, ch, ch, args.blocks, xin, chunk=max(256, set_blocks))
@@ -107,13 +110,26 @@ def c3(args):
     c, m = _time_cpu(cpu, ch, ch, x[:, :BLOCK].copy())
     alg = graphs.c3_algorithmic_bytes(ch)
     conv_us = 1e3 * (lv[1] if len(lv) > 2 else lv[0])    # the convolve launch (level 0 once `in` / root are folded into it)
-    wasm = None     # the reference's own engine (wasm build) timed in the authoring container: benchmarks/c3_wasm_baseline.js
-    try:
-        import json as _json, os as _os
-        w = _json.load(open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "profiles", "r02", "c3_wasm_reference_cpu.json")))
-        wasm = {k: w[k] for k in ("us_per_block_mean", "us_per_block_p50", "us_per_block_p99", "host_cpu", "measured_on")}
-    except Exception:
-        pass
+    # the reference's own engine (its prebuilt wasm build under Node): timed HERE, beside the GPU, when node and /root/reference
+    # exist on this machine (benchmarks/c3_wasm_baseline.js); otherwise the figure recorded in the authoring container, labelled
+    wasm = None
+    import json as _json, os as _os, shutil as _sh, subprocess as _sp
+    here = _os.path.dirname(_os.path.abspath(__file__))
+    if _sh.which("node") and _os.path.isdir("/root/reference/js/packages"):
+        try:
+            r = _sp.run(["node", _os.path.join(here, "c3_wasm_baseline.js")], capture_output=True, text=True, timeout=300)
+            w = _json.loads(r.stdout.strip().splitlines()[-1])
+            wasm = {k: w[k] for k in ("us_per_block_mean", "us_per_block_p50", "us_per_block_p99", "host_cpu") if k in w}
+            wasm["measured"] = "on this machine, in this run"
+        except Exception as e_:
+            wasm = {"error": str(e_)[:200]}
+    if wasm is None or "error" in wasm:
+        try:
+            w = _json.load(open(_os.path.join(here, "..", "profiles", "r02", "c3_wasm_reference_cpu.json")))
+            wasm = {k: w[k] for k in ("us_per_block_mean", "us_per_block_p50", "us_per_block_p99", "host_cpu", "measured_on")}
+            wasm["measured"] = "NOT in this run: recorded in the authoring container (no node / no /root/reference on this machine)"
+        except Exception:
+            pass
     return {"config": "C3 8-channel convolution reverb, 96 000-tap IRs, sr 48000", "gpu_us_per_block": 1e6 * g,
             "gpu_path": f"elemhip_process_blocks: multi-block convolve kernels (fft / mac / ifft / finish per {set_blocks}-block launch set)",
             "gpu_launch_set_profile": getattr(_time_gpu, "last_profile", None), "batch_launches": rt.stats()["batch_launches"],
@@ -123,7 +139,8 @@ def c3(args):
             "cpu_blocks_timed": m, "speedup": c / g, "launch_us": [1e3 * v for v in lv],
             "algorithmic_bytes_per_block": alg, "conv_kernel_us": conv_us,
             "conv_kernel_GBps_algorithmic": (alg / (conv_us * 1e-6) / 1e9) if conv_us else None,
-            "spectra_bytes_read_per_block": ch * 2 * 188 * 512 * 8}
+            "conv_mfma": int(dict(kv.split("=", 1) for kv in args.opt).get("conv_mfma", 1)),
+            "mac_flops_per_launch_set": 8.0 * ch * 188 * 512 * set_blocks}
 
 
 def c4(args):
@@ -298,6 +315,7 @@ def main():
     ap.add_argument("--batches", type=int, default=400)
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--specialize", type=int, default=2, help="1 for c5 (background compilation, the product default) is set by c5 itself")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra engine option (c3), repeatable")
     args = ap.parse_args()
     for name in args.configs:
         out = {"c1": c1, "c3": c3, "c4": c4, "c5": c5}[name](args)

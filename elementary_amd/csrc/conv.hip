@@ -460,9 +460,141 @@ __device__ __forceinline__ void batch_mac_tile(const BatchCtx& c, uint32_t tile,
     if (j0 + 3u < batch) Y[(size_t)(j0 + 3u) * 512u] = a3;
 }
 
+
+// K2a on the matrix cores (north_star: "MFMA used only for the partitioned-convolution dense FFT x IR multiply"; the reference's
+// call site is wasm/Convolve.h:49,73-84). For one bin the set's partition sums are a Toeplitz product along the block index:
+// y[t] = sum_p h[p] x[t - p]. Take four consecutive taps and four consecutive input times: the outer product
+//     D[m][n] += x[t0 - 4J - m] * h[4J + n]            (m, n = 0..3; J = tap group)
+// accumulated over J holds, on its seven anti-diagonals, partial sums of y[t0 + n - m] — every one of the 16 products is a term
+// the convolution needs, and every (t, p) pair is formed exactly once over the tiles t0 = 0, 4, 8, ...: y[t0 + n] = P_n(t0) +
+// Q_n(t0 + 4) with P_n = sum of the diagonal n - m = n (n + m' < 4) and Q_n = the diagonal n - 4 of the NEXT tile. That is
+// v_mfma_f32_4x4x1_16B_f32: sixteen independent 4x4x1 blocks per instruction = the sixteen bins of the workgroup's tile, A = one
+// x value per lane (lane 4 b + m: bin b, time offset m), B = one h value per lane (lane 4 b + n), D = 4 registers (row m) — 256
+// multiply-adds per instruction from two operand registers, and because A of (tile i, group J) is A of (tile i + 1, group J + 1)
+// a wave keeps a window of x segments in registers and loads ONE new x segment and ONE h segment per 20 instructions. Complex =
+// four real products (xr hr, xi (-hi) -> re; xi hr, xr hi -> im). f32 MFMA is an exact fmaf chain (MI355X_MICROARCH.md), so the
+// result differs from the vector kernel's only in the order of the sum (taps by residue mod 4, then the diagonals).
+// Same workgroup geometry, LDS ring and H staging as batch_mac_tile; a wave owns 16 consecutive blocks = 4 output tiles + the
+// fifth tile whose lower diagonals complete the fourth.
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int CTRL>
+__device__ __forceinline__ float quad_rot(float v) {      // value of lane (n + k) % 4 of the same quad, k encoded in CTRL
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <bool HasPacked, bool Swap>
+__device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t tile, uint32_t jBase, uint32_t batch, uint32_t tid,
+                                                    uint32_t part, uint32_t maxBatch, c2 (&Xs)[kMacR][20], c2 (&Hs)[kMacDP + 1u][kMacU][16]) {
+    constexpr uint32_t U = kMacU, R = kMacR, DP = kMacDP;
+    constexpr int NT = 4;                                                   // output tiles per wave (+ 1 for the last tile's lower diagonals)
+    const uint32_t bin = tid & 15u, row = tid >> 4, kb = tile * 16u + bin;  // staging roles: as in batch_mac_tile
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t mb = lane >> 2, mq = lane & 3u;                          // compute roles: MFMA block (= bin of the tile) and row / column inside it
+    const uint32_t P = c.st.P, b0 = c.st.hdr[conv::H_BLK];
+    gcf2p H = (gcf2p)c.st.H + kb, X = (gcf2p)c.st.X + kb, N = (gcf2p)c.xnew + kb;
+    const uint32_t bm = b0 % P;
+    auto xat = [&](int t) -> c2 {
+        if (t >= (int)batch) return mk(0.0f, 0.0f);
+        if (t >= 0) return N[(size_t)t * 512u];
+        uint32_t back = (uint32_t)(-t);
+        if (back > P) back = P;
+        const uint32_t slot = bm >= back ? bm - back : bm + P - back;
+        return X[(size_t)slot * 512u];
+    };
+    const uint32_t perPart = (P + kMacParts - 1u) / kMacParts, pBegin = part * perPart, pEnd = pBegin + perPart < P ? pBegin + perPart : P;
+    const uint32_t Tw = jBase + wave * 16u;                                 // this wave's first output block
+    gf2p Y = c.ysum + (size_t)part * maxBatch * 512u + tile * 16u + mb;
+    if (pBegin >= pEnd) {
+        for (uint32_t i = 0; i < (uint32_t)NT; ++i) { const uint32_t t = Tw + 4u * i + mq; if (t < batch) Y[(size_t)t * 512u] = mk(0.0f, 0.0f); }
+        return;
+    }
+    auto hrow = [&](uint32_t p) -> c2 { return p < pEnd ? H[(size_t)p * 512u] : mk(0.0f, 0.0f); };
+    {   // initial fill (identical to batch_mac_tile)
+        const int tLo = (int)jBase - (int)(U * DP) - (int)pBegin;
+        constexpr uint32_t NX = (64u + U * DP + 15u) / 16u, NH = (U * DP + 15u) / 16u;
+        c2 fx[NX], fh[NH];
+#pragma unroll
+        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; fx[i] = r < 64u + U * DP ? xat(tLo + (int)r) : mk(0.0f, 0.0f); }
+#pragma unroll
+        for (uint32_t i = 0; i < NH; ++i) { const uint32_t r = row + 16u * i; fh[i] = r < U * DP ? hrow(pBegin + r) : mk(0.0f, 0.0f); }
+#pragma unroll
+        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; if (r < 64u + U * DP) Xs[(uint32_t)(tLo + (int)r) & (R - 1u)][bin] = fx[i]; }
+#pragma unroll
+        for (uint32_t i = 0; i < NH; ++i) { const uint32_t r = row + 16u * i; if (r < U * DP) Hs[r / U][r % U][bin] = fh[i]; }
+    }
+    __syncthreads();
+    // x segment sigma of this wave: lane (b, m) holds x[Tw + 4 sigma - m - pBegin] of bin b
+    auto xseg = [&](int sigma) -> c2 { return Xs[(uint32_t)((int)Tw + 4 * sigma - (int)mq - (int)pBegin) & (R - 1u)][mb]; };
+    c2 W[NT + 1];
+#pragma unroll
+    for (int i = 0; i <= NT; ++i) W[i] = xseg(i);
+    f4v Dr[NT + 1], Di[NT + 1];
+#pragma unroll
+    for (int i = 0; i <= NT; ++i) { Dr[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f}; Di[i] = Dr[i]; }
+    const bool packedLane = HasPacked && tile == 0u && mb == 0u;            // bin 0 carries two REAL bins (DC, Nyquist): (hr xr, hi xi)
+    auto mma = [&](float a, float b, f4v acc) -> f4v {
+        if constexpr (Swap) return __builtin_amdgcn_mfma_f32_4x4x1f32(b, a, acc, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, 0, 0, 0);
+    };
+    auto piece = [&](uint32_t ck) -> c2 {
+        const uint32_t pk = pBegin + ck * U;
+        if (pk >= pEnd) return mk(0.0f, 0.0f);
+        return row < U ? xat((int)jBase - (int)U - (int)pk + (int)row) : hrow(pk + row - U);
+    };
+    auto stash = [&](uint32_t ck, c2 v) {
+        const uint32_t pk = pBegin + ck * U;
+        if (pk >= pEnd) return;
+        if (row < U) Xs[(uint32_t)((int)jBase - (int)U - (int)pk + (int)row) & (R - 1u)][bin] = v; else Hs[ck % (DP + 1u)][row - U][bin] = v;
+    };
+    c2 q1 = piece(DP), q2 = mk(0.0f, 0.0f);
+    uint32_t ck = 0u;
+    int J = 0;                                                               // tap group: taps pBegin + 4 J .. + 3
+    for (uint32_t p0 = pBegin; p0 < pEnd; p0 += U, ++ck) {
+        q2 = piece(ck + DP + 1u);
+        const uint32_t hb = ck % (DP + 1u);
+#pragma unroll
+        for (uint32_t g = 0; g < U / 4u; ++g, ++J) {
+            const c2 h = Hs[hb][4u * g + mq][mb];                            // lane (b, n): h[pBegin + 4 J + n] of bin b (zero past the last tap)
+            const c2 xn = xseg(-(J + 1));                                    // enters the window after this group
+            // the four real products of a complex multiply-add; the packed bin's lanes get (hr xr, hi xi) from the same four instructions
+            const float hB1 = h.x, hB2 = packedLane ? 0.0f : -h.y, hB3 = packedLane ? h.y : h.x, hB4 = packedLane ? 0.0f : h.y;
+#pragma unroll
+            for (int i = 0; i <= NT; ++i) Dr[i] = mma(W[i].x, hB1, Dr[i]);
+#pragma unroll
+            for (int i = 0; i <= NT; ++i) Di[i] = mma(W[i].y, hB3, Di[i]);
+#pragma unroll
+            for (int i = 0; i <= NT; ++i) Dr[i] = mma(W[i].y, hB2, Dr[i]);
+#pragma unroll
+            for (int i = 0; i <= NT; ++i) Di[i] = mma(W[i].x, hB4, Di[i]);
+#pragma unroll
+            for (int i = NT; i > 0; --i) W[i] = W[i - 1];
+            W[0] = xn;
+        }
+        stash(ck + DP, q1);
+        q1 = q2;
+        __syncthreads();
+    }
+    // anti-diagonals: lane n of a quad collects D[m][(n + m) % 4] from register m; n + m < 4 belongs to y[t0 + n] of this tile (P),
+    // n + m >= 4 to y[t0 - 4 + n], i.e. to the previous tile's outputs (Q)
+    auto diag = [&](const f4v& D, float& Pn, float& Qn) {
+        const float v1 = quad_rot<0x39>(D.y), v2 = quad_rot<0x4E>(D.z), v3 = quad_rot<0x93>(D.w);   // quad_perm [1,2,3,0], [2,3,0,1], [3,0,1,2]
+        Pn = D.x; Qn = 0.0f;
+        if (mq + 1u < 4u) Pn += v1; else Qn += v1;
+        if (mq + 2u < 4u) Pn += v2; else Qn += v2;
+        if (mq + 3u < 4u) Pn += v3; else Qn += v3;
+    };
+    float Pr[NT + 1], Qr[NT + 1], Pi[NT + 1], Qi[NT + 1];
+#pragma unroll
+    for (int i = 0; i <= NT; ++i) { diag(Dr[i], Pr[i], Qr[i]); diag(Di[i], Pi[i], Qi[i]); }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const uint32_t t = Tw + 4u * (uint32_t)i + mq;
+        if (t < batch) Y[(size_t)t * 512u] = mk(Pr[i] + Qr[i + 1], Pi[i] + Qi[i + 1]);
+    }
+}
+
 __global__ __launch_bounds__(256)
 void elemhip_convolve_batch_mac(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t batch) {
+                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t batch, uint32_t mode) {
     const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, tile = blockIdx.y, tid = threadIdx.x;
     const uint32_t part = blockIdx.z % kMacParts, jBase = (blockIdx.z / kMacParts) * 64u;
     const ConvDesc d = pv.convs[convIdx];
@@ -471,7 +603,11 @@ void elemhip_convolve_batch_mac(PlanView pv, uint32_t* recs, float* hbm, const G
     if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) return;     // (the ifft kernel writes the zeros)
     __shared__ c2 Xs[kMacR][20];
     __shared__ c2 Hs[kMacDP + 1u][kMacU][16];
-    if (tile == 0u) batch_mac_tile<true>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs);
+    // mode (engine option "conv_mfma"): 1 = the partition sums on the matrix cores (default), 0 = packed vector FMAs (r03),
+    // 2 = MFMA with the operand roles exchanged (a layout probe for bring-up, tests/test_gpu_convolve.py)
+    if (mode == 1u) { if (tile == 0u) batch_mac_tile_mfma<true, false>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs); else batch_mac_tile_mfma<false, false>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs); }
+    else if (mode == 2u) { if (tile == 0u) batch_mac_tile_mfma<true, true>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs); else batch_mac_tile_mfma<false, true>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs); }
+    else if (tile == 0u) batch_mac_tile<true>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs);
     else batch_mac_tile<false>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs);
 }
 
@@ -544,11 +680,11 @@ void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* h
 size_t convolve_batch_scratch_floats(uint32_t maxBatch) { return 16u + (size_t)maxBatch * 1024u + (size_t)(maxBatch + 1u) * 512u + (size_t)kMacParts * maxBatch * 1024u; }
 
 void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                           uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch) {
+                           uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch, uint32_t macMode) {
     const dim3 grid(numNodes, batch), block(256);
     hipLaunchKernelGGL(elemhip_convolve_batch_fft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
     // (node, 16-bin tile, 64-block chunk x partition run): 1024 workgroups for 8 channels
-    hipLaunchKernelGGL(elemhip_convolve_batch_mac, dim3(numNodes, conv::kBlock / 16u, kMacParts * ((batch + 63u) / 64u)), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch);
+    hipLaunchKernelGGL(elemhip_convolve_batch_mac, dim3(numNodes, conv::kBlock / 16u, kMacParts * ((batch + 63u) / 64u)), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, macMode);
     hipLaunchKernelGGL(elemhip_convolve_batch_ifft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
     hipLaunchKernelGGL(elemhip_convolve_batch_finish, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
 }

@@ -1265,6 +1265,7 @@ int Engine::setOption(const std::string& key, double value) {
     std::lock_guard<std::mutex> lock(mu);
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
     if (key == "host_out_direct") { hostOutDirect = value != 0; return kOk; }   // elemhip_process: epilogue writes the pinned host block itself
+    if (key == "conv_mfma") { convMfma = std::max(0, std::min(2, (int)value)); return kOk; }   // partition MAC of launch sets: 1 matrix cores (default), 0 packed vector FMAs
     if (key == "spec_blocks") { specBlocks = value != 0; return kOk; }      // elemhip_process through the specialised kernels when it can
     if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(1024, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
     if (key == "debug_build_delay_ms") { debugBuildDelayMs = std::max(0, (int)value); return kOk; }   // tests: stretches the unlocked part of a plan build
@@ -1801,7 +1802,7 @@ void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32
     const uint32_t cb = p.convLevelOffsets[l], ce = p.convLevelOffsets[l + 1];
     uint32_t mains = 0;
     while (cb + mains < ce && (p.convWork[cb + mains] >> 16) == 0u) ++mains;   // main entries lead a level's work list
-    if (mains) launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks);
+    if (mains) launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks, (uint32_t)convMfma);
 }
 
 void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {

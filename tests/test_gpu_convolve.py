@@ -120,6 +120,25 @@ def test_c3_large_launch_sets_vs_restatement(gpu_required, ch, batch, blocks):
     assert float(err.max()) <= TOL, f"block {int(err.argmax())}: {err.max():.3e}"
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_partition_mac_on_matrix_cores_and_on_vector_fmas(gpu_required, mode):
+    """The launch sets' partition sums (conv.hip elemhip_convolve_batch_mac) in both forms — `conv_mfma` = 1 (default):
+    v_mfma_f32_4x4x1_16B_f32 Toeplitz tiles; 0: packed vector FMAs — each against the restatement (itself pinned to the wasm
+    recordings), 4 channels x 96 000-tap IRs, a 256-block set, a ragged 93-block one and a 7-block one (fewer blocks than
+    a wave's 16-block tile run; partitions split over two workgroups)."""
+    ch, blocks = 4, 256 + 93 + 7
+    rt, x = _c3(hip, ch, blocks)
+    rt.set_option("batch_blocks", 256)
+    rt.set_option("conv_mfma", mode)
+    got = np.concatenate([_blocks(rt, x, 0, 256, ch), _blocks(rt, x, 256, 93, ch), _blocks(rt, x, 349, 7, ch)])
+    assert rt.stats()["batch_launches"] >= 3
+    ref_rt, _ = _c3(lambda sr, bs: oracle.PortRuntime(sr, bs), ch, blocks)
+    ref = np.stack([ref_rt.process(x[:, k * 512:(k + 1) * 512], ch, 512) for k in range(blocks)])
+    assert float(np.abs(ref).max()) > 0.2
+    err = np.abs(got.astype(np.float64) - ref).max(axis=(1, 2))
+    assert float(err.max()) <= TOL, f"block {int(err.argmax())}: {err.max():.3e}"
+
+
 @pytest.mark.parametrize("taps", [300, 700, 3000, 40000])
 def test_multi_block_and_single_block_calls_interleave(gpu_required, taps):
     """One stream rendered by alternating elemhip_process_blocks (multi-block kernels) and elemhip_process (main +
