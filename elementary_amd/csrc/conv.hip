@@ -481,22 +481,30 @@ template <int CTRL>
 __device__ __forceinline__ float quad_rot(float v) {      // value of lane (n + k) % 4 of the same quad, k encoded in CTRL
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// LDS of the matrix-core variant: EVERY input-spectrum row and H row the workgroup needs, loaded once, up front (one memory round
+// trip, one barrier, then nothing but MFMAs and two 8-byte LDS reads per 20 of them). The first version kept batch_mac_tile's
+// chunked ring (8 partitions per barrier): measured no faster than the vector kernel — both sat out a global-load round trip per
+// chunk (`s_waitcnt vmcnt(0)` behind a predicated load), not arithmetic.
+constexpr uint32_t kMfmaSteps = 24;                                  // tap groups of 4 per workgroup: ceil(ceil(188 / kMacParts) / 4)
+constexpr uint32_t kMfmaXRows = 64u + 4u * kMfmaSteps + 8u;          // 168 rows x 16 bins x 8 bytes
+constexpr uint32_t kMfmaHRows = 4u * kMfmaSteps;                     // 96
+constexpr uint32_t kMfmaLdsBytes = (kMfmaXRows + kMfmaHRows) * 16u * 8u;
 template <bool HasPacked, bool Swap>
 __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t tile, uint32_t jBase, uint32_t batch, uint32_t tid,
-                                                    uint32_t part, uint32_t maxBatch, c2 (&Xs)[kMacR][20], c2 (&Hs)[kMacDP + 1u][kMacU][16]) {
-    constexpr uint32_t U = kMacU, R = kMacR, DP = kMacDP;
+                                                    uint32_t part, uint32_t maxBatch, c2 (*Xs)[16], c2 (*Hs)[16]) {
     constexpr int NT = 4;                                                   // output tiles per wave (+ 1 for the last tile's lower diagonals)
-    const uint32_t bin = tid & 15u, row = tid >> 4, kb = tile * 16u + bin;  // staging roles: as in batch_mac_tile
+    const uint32_t bin = tid & 15u, row = tid >> 4, kb = tile * 16u + bin;  // load roles: 16 bins x 16 rows per pass, 128 contiguous bytes per row
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t mb = lane >> 2, mq = lane & 3u;                          // compute roles: MFMA block (= bin of the tile) and row / column inside it
     const uint32_t P = c.st.P, b0 = c.st.hdr[conv::H_BLK];
     gcf2p H = (gcf2p)c.st.H + kb, X = (gcf2p)c.st.X + kb, N = (gcf2p)c.xnew + kb;
     const uint32_t bm = b0 % P;
+    // x(t): input spectrum of block b0 + t — 0 <= t < batch: a block of this set; t < 0: the ring (slot of block b is b mod P)
     auto xat = [&](int t) -> c2 {
         if (t >= (int)batch) return mk(0.0f, 0.0f);
         if (t >= 0) return N[(size_t)t * 512u];
         uint32_t back = (uint32_t)(-t);
-        if (back > P) back = P;
+        if (back > P) return mk(0.0f, 0.0f);                               // (older than the IR is long: only padded taps look there)
         const uint32_t slot = bm >= back ? bm - back : bm + P - back;
         return X[(size_t)slot * 512u];
     };
@@ -507,23 +515,25 @@ __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t 
         for (uint32_t i = 0; i < (uint32_t)NT; ++i) { const uint32_t t = Tw + 4u * i + mq; if (t < batch) Y[(size_t)t * 512u] = mk(0.0f, 0.0f); }
         return;
     }
-    auto hrow = [&](uint32_t p) -> c2 { return p < pEnd ? H[(size_t)p * 512u] : mk(0.0f, 0.0f); };
-    {   // initial fill (identical to batch_mac_tile)
-        const int tLo = (int)jBase - (int)(U * DP) - (int)pBegin;
-        constexpr uint32_t NX = (64u + U * DP + 15u) / 16u, NH = (U * DP + 15u) / 16u;
+    const uint32_t steps = (pEnd - pBegin + 3u) / 4u;                       // <= kMfmaSteps (checked by the caller)
+    // rows of x' = x shifted by pBegin: x'[s] = x[s - pBegin]; LDS row r holds time tLo + r
+    const int tLo = (int)jBase - (int)pBegin - 4 * (int)steps - 4;
+    {
+        constexpr uint32_t NX = (kMfmaXRows + 15u) / 16u, NH = kMfmaHRows / 16u;
         c2 fx[NX], fh[NH];
 #pragma unroll
-        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; fx[i] = r < 64u + U * DP ? xat(tLo + (int)r) : mk(0.0f, 0.0f); }
+        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; fx[i] = r < kMfmaXRows ? xat(tLo + (int)r) : mk(0.0f, 0.0f); }
 #pragma unroll
-        for (uint32_t i = 0; i < NH; ++i) { const uint32_t r = row + 16u * i; fh[i] = r < U * DP ? hrow(pBegin + r) : mk(0.0f, 0.0f); }
+        for (uint32_t i = 0; i < NH; ++i) { const uint32_t p = pBegin + row + 16u * i; fh[i] = p < pEnd ? H[(size_t)p * 512u] : mk(0.0f, 0.0f); }   // taps past the end multiply by zero
 #pragma unroll
-        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; if (r < 64u + U * DP) Xs[(uint32_t)(tLo + (int)r) & (R - 1u)][bin] = fx[i]; }
+        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; if (r < kMfmaXRows) Xs[r][bin] = fx[i]; }
 #pragma unroll
-        for (uint32_t i = 0; i < NH; ++i) { const uint32_t r = row + 16u * i; if (r < U * DP) Hs[r / U][r % U][bin] = fh[i]; }
+        for (uint32_t i = 0; i < NH; ++i) Hs[row + 16u * i][bin] = fh[i];
     }
     __syncthreads();
-    // x segment sigma of this wave: lane (b, m) holds x[Tw + 4 sigma - m - pBegin] of bin b
-    auto xseg = [&](int sigma) -> c2 { return Xs[(uint32_t)((int)Tw + 4 * sigma - (int)mq - (int)pBegin) & (R - 1u)][mb]; };
+    // x segment sigma of this wave: lane (b, m) holds x'[Tw + 4 sigma - m] of bin b
+    const int segBase = (int)Tw - (int)mq - (int)pBegin - tLo;              // LDS row of sigma = 0
+    auto xseg = [&](int sigma) -> c2 { return Xs[segBase + 4 * sigma][mb]; };
     c2 W[NT + 1];
 #pragma unroll
     for (int i = 0; i <= NT; ++i) W[i] = xseg(i);
@@ -535,43 +545,22 @@ __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t 
         if constexpr (Swap) return __builtin_amdgcn_mfma_f32_4x4x1f32(b, a, acc, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, 0, 0, 0);
     };
-    auto piece = [&](uint32_t ck) -> c2 {
-        const uint32_t pk = pBegin + ck * U;
-        if (pk >= pEnd) return mk(0.0f, 0.0f);
-        return row < U ? xat((int)jBase - (int)U - (int)pk + (int)row) : hrow(pk + row - U);
-    };
-    auto stash = [&](uint32_t ck, c2 v) {
-        const uint32_t pk = pBegin + ck * U;
-        if (pk >= pEnd) return;
-        if (row < U) Xs[(uint32_t)((int)jBase - (int)U - (int)pk + (int)row) & (R - 1u)][bin] = v; else Hs[ck % (DP + 1u)][row - U][bin] = v;
-    };
-    c2 q1 = piece(DP), q2 = mk(0.0f, 0.0f);
-    uint32_t ck = 0u;
-    int J = 0;                                                               // tap group: taps pBegin + 4 J .. + 3
-    for (uint32_t p0 = pBegin; p0 < pEnd; p0 += U, ++ck) {
-        q2 = piece(ck + DP + 1u);
-        const uint32_t hb = ck % (DP + 1u);
+    for (int J = 0; J < (int)steps; ++J) {                                  // tap group: taps pBegin + 4 J .. + 3
+        const c2 h = Hs[4 * J + (int)mq][mb];                               // lane (b, n): h[pBegin + 4 J + n] of bin b
+        const c2 xn = xseg(-(J + 1));                                       // enters the window after this group (row >= 0: tLo leaves room)
+        // the four real products of a complex multiply-add; the packed bin's lanes get (hr xr, hi xi) from the same four instructions
+        const float hB1 = h.x, hB2 = packedLane ? 0.0f : -h.y, hB3 = packedLane ? h.y : h.x, hB4 = packedLane ? 0.0f : h.y;
 #pragma unroll
-        for (uint32_t g = 0; g < U / 4u; ++g, ++J) {
-            const c2 h = Hs[hb][4u * g + mq][mb];                            // lane (b, n): h[pBegin + 4 J + n] of bin b (zero past the last tap)
-            const c2 xn = xseg(-(J + 1));                                    // enters the window after this group
-            // the four real products of a complex multiply-add; the packed bin's lanes get (hr xr, hi xi) from the same four instructions
-            const float hB1 = h.x, hB2 = packedLane ? 0.0f : -h.y, hB3 = packedLane ? h.y : h.x, hB4 = packedLane ? 0.0f : h.y;
+        for (int i = 0; i <= NT; ++i) Dr[i] = mma(W[i].x, hB1, Dr[i]);
 #pragma unroll
-            for (int i = 0; i <= NT; ++i) Dr[i] = mma(W[i].x, hB1, Dr[i]);
+        for (int i = 0; i <= NT; ++i) Di[i] = mma(W[i].y, hB3, Di[i]);
 #pragma unroll
-            for (int i = 0; i <= NT; ++i) Di[i] = mma(W[i].y, hB3, Di[i]);
+        for (int i = 0; i <= NT; ++i) Dr[i] = mma(W[i].y, hB2, Dr[i]);
 #pragma unroll
-            for (int i = 0; i <= NT; ++i) Dr[i] = mma(W[i].y, hB2, Dr[i]);
+        for (int i = 0; i <= NT; ++i) Di[i] = mma(W[i].x, hB4, Di[i]);
 #pragma unroll
-            for (int i = 0; i <= NT; ++i) Di[i] = mma(W[i].x, hB4, Di[i]);
-#pragma unroll
-            for (int i = NT; i > 0; --i) W[i] = W[i - 1];
-            W[0] = xn;
-        }
-        stash(ck + DP, q1);
-        q1 = q2;
-        __syncthreads();
+        for (int i = NT; i > 0; --i) W[i] = W[i - 1];
+        W[0] = xn;
     }
     // anti-diagonals: lane n of a quad collects D[m][(n + m) % 4] from register m; n + m < 4 belongs to y[t0 + n] of this tile (P),
     // n + m >= 4 to y[t0 - 4 + n], i.e. to the previous tile's outputs (Q)
@@ -601,13 +590,23 @@ void elemhip_convolve_batch_mac(PlanView pv, uint32_t* recs, float* hbm, const G
     if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
     BatchCtx c;
     if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) return;     // (the ifft kernel writes the zeros)
-    __shared__ c2 Xs[kMacR][20];
-    __shared__ c2 Hs[kMacDP + 1u][kMacU][16];
     // mode (engine option "conv_mfma"): 1 = the partition sums on the matrix cores (default), 0 = packed vector FMAs (r03),
-    // 2 = MFMA with the operand roles exchanged (a layout probe for bring-up, tests/test_gpu_convolve.py)
-    if (mode == 1u) { if (tile == 0u) batch_mac_tile_mfma<true, false>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs); else batch_mac_tile_mfma<false, false>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs); }
-    else if (mode == 2u) { if (tile == 0u) batch_mac_tile_mfma<true, true>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs); else batch_mac_tile_mfma<false, true>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs); }
-    else if (tile == 0u) batch_mac_tile<true>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs);
+    // 2 = MFMA with the operand roles exchanged (the layout probe of the bring-up: wrong sums by construction)
+    // one LDS block, laid out per variant (the vector kernel's ring + H chunks: 24 KB; the matrix-core kernel's rows: 33 KB)
+    constexpr uint32_t kVecBytes = (kMacR * 20u + (kMacDP + 1u) * kMacU * 16u) * 8u;
+    __shared__ __attribute__((aligned(16))) char ldsRaw[kMfmaLdsBytes > kVecBytes ? kMfmaLdsBytes : kVecBytes];
+    const bool mfma = mode != 0u && (c.st.P + kMacParts - 1u) / kMacParts <= 4u * kMfmaSteps;      // (an IR longer than the LDS rows hold: vector kernel)
+    if (mfma) {
+        c2 (*Xm)[16] = reinterpret_cast<c2 (*)[16]>(ldsRaw);
+        c2 (*Hm)[16] = reinterpret_cast<c2 (*)[16]>(ldsRaw + (size_t)kMfmaXRows * 16u * 8u);
+        if (mode == 2u) { if (tile == 0u) batch_mac_tile_mfma<true, true>(c, tile, jBase, batch, tid, part, maxBatch, Xm, Hm); else batch_mac_tile_mfma<false, true>(c, tile, jBase, batch, tid, part, maxBatch, Xm, Hm); }
+        else if (tile == 0u) batch_mac_tile_mfma<true, false>(c, tile, jBase, batch, tid, part, maxBatch, Xm, Hm);
+        else batch_mac_tile_mfma<false, false>(c, tile, jBase, batch, tid, part, maxBatch, Xm, Hm);
+        return;
+    }
+    c2 (&Xs)[kMacR][20] = *reinterpret_cast<c2 (*)[kMacR][20]>(ldsRaw);
+    c2 (&Hs)[kMacDP + 1u][kMacU][16] = *reinterpret_cast<c2 (*)[kMacDP + 1u][kMacU][16]>(ldsRaw + (size_t)kMacR * 20u * 8u);
+    if (tile == 0u) batch_mac_tile<true>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs);
     else batch_mac_tile<false>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs);
 }
 
