@@ -279,10 +279,18 @@ namespace {
 
 constexpr uint32_t kBatchHdr = 16;
 constexpr uint32_t kMacParts = 2;       // workgroups the partitions of one (node, bin tile, 64-block chunk) are cut into
-__device__ __forceinline__ size_t batch_scratch_floats(uint32_t maxBatch) { return kBatchHdr + (size_t)maxBatch * 1024u + (size_t)(maxBatch + 1u) * 512u + (size_t)kMacParts * maxBatch * 1024u; }
+// the matrix-core MAC reads TILED copies: per 16-bin tile a contiguous slab of rows [kTileHist + maxBatch][16] (time - the launch
+// set's first block + kTileHist) and of IR rows [kTileHist][16] — a workgroup's whole window is one contiguous stream, where the
+// natural [row][512] layout hands out 128-byte pieces 4 KB apart
+constexpr uint32_t kTileHist = 192;     // history rows (= the longest IR, in partitions, the matrix-core kernel takes)
+__host__ __device__ __forceinline__ size_t batch_scratch_floats(uint32_t maxBatch) {
+    return kBatchHdr + (size_t)maxBatch * 1024u + (size_t)(maxBatch + 1u) * 512u + (size_t)kMacParts * maxBatch * 1024u
+         + (size_t)(kTileHist + maxBatch) * 1024u + (size_t)kTileHist * 1024u;
+}
 
 struct BatchCtx {
     State st; bool live; uint32_t inKind, inBuf; float cval; gfp scratch; gf2p xnew; gfp tails; gf2p ysum; float gain;
+    gf2p xt, ht; uint32_t xtRows;      // tiled spectra [32 tiles][xtRows][16], tiled IR spectra [32][kTileHist][16]
 };
 
 // decode shared by the three kernels; live == false: the node writes zeros (Convolve.h:70-71) or does nothing
@@ -302,6 +310,9 @@ __device__ __forceinline__ bool batch_ctx(const ConvDesc& d, gup recs, const Glo
     c.xnew = (gf2p)(c.scratch + kBatchHdr);
     c.tails = c.scratch + kBatchHdr + (size_t)maxBatch * 1024u;
     c.ysum = (gf2p)(c.tails + (size_t)(maxBatch + 1u) * 512u);
+    c.xtRows = kTileHist + maxBatch;
+    c.xt = c.ysum + (size_t)kMacParts * maxBatch * 512u;
+    c.ht = c.xt + (size_t)c.xtRows * 512u;
     c.live = false;
     if (sp == 0ull || c.inKind == 0u) return false;
     c.st = state_of((gup)reinterpret_cast<uint32_t*>(sp));
@@ -314,7 +325,7 @@ __device__ __forceinline__ bool batch_ctx(const ConvDesc& d, gup recs, const Glo
 
 __global__ __launch_bounds__(256)
 void elemhip_convolve_batch_fft(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch) {
+                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t macMode) {
     __shared__ c2 A[conv::kFft], B[conv::kFft], W[conv::kFft];
     const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, j = blockIdx.y, tid = threadIdx.x;
     const ConvDesc d = pv.convs[convIdx];
@@ -332,10 +343,25 @@ void elemhip_convolve_batch_fft(PlanView pv, uint32_t* recs, float* hbm, const G
     }
     __syncthreads();
     fft1024(A, B, W, tid);
+    const bool tiled = macMode != 0u && c.st.P <= kTileHist;     // the matrix-core MAC takes this node (elemhip_convolve_batch_mac)
 #pragma unroll
     for (uint32_t q = 0; q < 2; ++q) {
         const uint32_t k = tid + 256u * q;
-        c.xnew[(size_t)j * 512u + k] = k == 0u ? mk(B[0].x, B[512].x) : B[k];
+        const c2 v = k == 0u ? mk(B[0].x, B[512].x) : B[k];
+        c.xnew[(size_t)j * 512u + k] = v;
+        if (tiled) c.xt[((size_t)(k >> 4) * c.xtRows + kTileHist + j) * 16u + (k & 15u)] = v;
+    }
+    if (tiled) {   // the rows older than the set (the node's spectra ring) and the IR spectra, tile by tile: row `back` blocks back sits at kTileHist - back
+        const uint32_t P = c.st.P, bm = c.st.hdr[conv::H_BLK] % P, nb = gridDim.y;
+        for (uint32_t back = j + 1u; back <= P; back += nb) {
+            const uint32_t slot = bm >= back ? bm - back : bm + P - back;
+#pragma unroll
+            for (uint32_t q = 0; q < 2; ++q) { const uint32_t k = tid + 256u * q; c.xt[((size_t)(k >> 4) * c.xtRows + kTileHist - back) * 16u + (k & 15u)] = ((gcf2p)c.st.X)[(size_t)slot * 512u + k]; }
+        }
+        for (uint32_t p = j; p < P; p += nb) {
+#pragma unroll
+            for (uint32_t q = 0; q < 2; ++q) { const uint32_t k = tid + 256u * q; c.ht[((size_t)(k >> 4) * kTileHist + p) * 16u + (k & 15u)] = ((gcf2p)c.st.H)[(size_t)p * 512u + k]; }
+        }
     }
     if (j == 0u) {   // what the later kernels must not read from state another workgroup of theirs rewrites
         for (uint32_t i = tid; i < 512u; i += 256u) c.tails[i] = c.st.overlap[i];
@@ -481,58 +507,50 @@ template <int CTRL>
 __device__ __forceinline__ float quad_rot(float v) {      // value of lane (n + k) % 4 of the same quad, k encoded in CTRL
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-// LDS of the matrix-core variant: EVERY input-spectrum row and H row the workgroup needs, loaded once, up front (one memory round
-// trip, one barrier, then nothing but MFMAs and two 8-byte LDS reads per 20 of them). The first version kept batch_mac_tile's
-// chunked ring (8 partitions per barrier): measured no faster than the vector kernel — both sat out a global-load round trip per
-// chunk (`s_waitcnt vmcnt(0)` behind a predicated load), not arithmetic.
-constexpr uint32_t kMfmaSteps = 24;                                  // tap groups of 4 per workgroup: ceil(ceil(188 / kMacParts) / 4)
-constexpr uint32_t kMfmaXRows = 64u + 4u * kMfmaSteps + 8u;          // 168 rows x 16 bins x 8 bytes
-constexpr uint32_t kMfmaHRows = 4u * kMfmaSteps;                     // 96
-constexpr uint32_t kMfmaLdsBytes = (kMfmaXRows + kMfmaHRows) * 16u * 8u;
+// LDS of the matrix-core variant: EVERY input-spectrum row and IR row the workgroup needs, loaded once, up front, from the TILED
+// copies the fft kernel leaves (one contiguous stream per workgroup, one barrier, then nothing but MFMAs and two 8-byte LDS reads
+// per 36 of them). Two earlier versions, measured (profiles/r04/c3_mac_variants.txt): the vector kernel's chunked LDS ring with MFMA
+// arithmetic — no faster (131 us per 1024-block set either way); everything up front from the natural [row][512] layout, 64 blocks
+// and half the partitions per workgroup — 183 us: both are bound by what the workgroups READ (8192 workgroups x 33 KB = 270 MB per
+// set in 128-byte pieces 4 KB apart, ~2 TB/s), not by arithmetic. Hence: tiled copies, ALL partitions and 128 blocks per workgroup
+// (2048 workgroups x 65 KB), a wave = 32 consecutive blocks = 8 output tiles + the ninth whose lower diagonals complete the eighth.
+constexpr uint32_t kMfmaSteps = kTileHist / 4u;                      // tap groups of 4
+constexpr uint32_t kMfmaOut = 128;                                   // blocks per workgroup
+constexpr uint32_t kMfmaXRows = kMfmaOut + 4u * kMfmaSteps + 8u;     // 328 rows x 16 bins x 8 bytes = 41 KB
+constexpr uint32_t kMfmaLdsBytes = (kMfmaXRows + kTileHist) * 16u * 8u;   // + 192 IR rows: 65 KB, two workgroups per CU
 template <bool HasPacked, bool Swap>
 __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t tile, uint32_t jBase, uint32_t batch, uint32_t tid,
-                                                    uint32_t part, uint32_t maxBatch, c2 (*Xs)[16], c2 (*Hs)[16]) {
-    constexpr int NT = 4;                                                   // output tiles per wave (+ 1 for the last tile's lower diagonals)
-    const uint32_t bin = tid & 15u, row = tid >> 4, kb = tile * 16u + bin;  // load roles: 16 bins x 16 rows per pass, 128 contiguous bytes per row
+                                                    c2 (*Xs)[16], c2 (*Hs)[16]) {
+    constexpr int NT = 8;                                                   // output tiles per wave (+ 1 for the last tile's lower diagonals)
+    const uint32_t bin = tid & 15u, row = tid >> 4;                         // load roles: 16 rows x 16 bins per pass = 2 KB contiguous
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t mb = lane >> 2, mq = lane & 3u;                          // compute roles: MFMA block (= bin of the tile) and row / column inside it
-    const uint32_t P = c.st.P, b0 = c.st.hdr[conv::H_BLK];
-    gcf2p H = (gcf2p)c.st.H + kb, X = (gcf2p)c.st.X + kb, N = (gcf2p)c.xnew + kb;
-    const uint32_t bm = b0 % P;
-    // x(t): input spectrum of block b0 + t — 0 <= t < batch: a block of this set; t < 0: the ring (slot of block b is b mod P)
+    const uint32_t P = c.st.P;
+    gcf2p Xt = (gcf2p)c.xt + (size_t)tile * c.xtRows * 16u + bin, Ht = (gcf2p)c.ht + (size_t)tile * kTileHist * 16u + bin;
+    // x(t): input spectrum of block (set start + t); t < 0: the rows the fft kernel copied out of the node's ring
     auto xat = [&](int t) -> c2 {
-        if (t >= (int)batch) return mk(0.0f, 0.0f);
-        if (t >= 0) return N[(size_t)t * 512u];
-        uint32_t back = (uint32_t)(-t);
-        if (back > P) return mk(0.0f, 0.0f);                               // (older than the IR is long: only padded taps look there)
-        const uint32_t slot = bm >= back ? bm - back : bm + P - back;
-        return X[(size_t)slot * 512u];
+        if (t >= (int)batch || t < -(int)P) return mk(0.0f, 0.0f);         // (rows older than the IR is long meet zero taps only: keep NaNs out)
+        return Xt[(size_t)((int)kTileHist + t) * 16u];
     };
-    const uint32_t perPart = (P + kMacParts - 1u) / kMacParts, pBegin = part * perPart, pEnd = pBegin + perPart < P ? pBegin + perPart : P;
-    const uint32_t Tw = jBase + wave * 16u;                                 // this wave's first output block
-    gf2p Y = c.ysum + (size_t)part * maxBatch * 512u + tile * 16u + mb;
-    if (pBegin >= pEnd) {
-        for (uint32_t i = 0; i < (uint32_t)NT; ++i) { const uint32_t t = Tw + 4u * i + mq; if (t < batch) Y[(size_t)t * 512u] = mk(0.0f, 0.0f); }
-        return;
-    }
-    const uint32_t steps = (pEnd - pBegin + 3u) / 4u;                       // <= kMfmaSteps (checked by the caller)
-    // rows of x' = x shifted by pBegin: x'[s] = x[s - pBegin]; LDS row r holds time tLo + r
-    const int tLo = (int)jBase - (int)pBegin - 4 * (int)steps - 4;
+    const uint32_t Tw = jBase + wave * 32u;                                 // this wave's first output block
+    gf2p Y = c.ysum + tile * 16u + mb;                                      // one partition run: partial sum 0 is the sum
+    const uint32_t steps = (P + 3u) / 4u;                                   // <= kMfmaSteps (P <= kTileHist: checked by the caller)
+    const int tLo = (int)jBase - 4 * (int)steps - 4;                        // LDS row r holds time tLo + r
     {
-        constexpr uint32_t NX = (kMfmaXRows + 15u) / 16u, NH = kMfmaHRows / 16u;
+        constexpr uint32_t NX = (kMfmaXRows + 15u) / 16u, NH = kTileHist / 16u;
         c2 fx[NX], fh[NH];
 #pragma unroll
         for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; fx[i] = r < kMfmaXRows ? xat(tLo + (int)r) : mk(0.0f, 0.0f); }
 #pragma unroll
-        for (uint32_t i = 0; i < NH; ++i) { const uint32_t p = pBegin + row + 16u * i; fh[i] = p < pEnd ? H[(size_t)p * 512u] : mk(0.0f, 0.0f); }   // taps past the end multiply by zero
+        for (uint32_t i = 0; i < NH; ++i) { const uint32_t p = row + 16u * i; fh[i] = p < P ? Ht[(size_t)p * 16u] : mk(0.0f, 0.0f); }   // taps past the end multiply by zero
 #pragma unroll
         for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; if (r < kMfmaXRows) Xs[r][bin] = fx[i]; }
 #pragma unroll
         for (uint32_t i = 0; i < NH; ++i) Hs[row + 16u * i][bin] = fh[i];
     }
     __syncthreads();
-    // x segment sigma of this wave: lane (b, m) holds x'[Tw + 4 sigma - m] of bin b
-    const int segBase = (int)Tw - (int)mq - (int)pBegin - tLo;              // LDS row of sigma = 0
+    // x segment sigma of this wave: lane (b, m) holds x[Tw + 4 sigma - m] of bin b
+    const int segBase = (int)Tw - (int)mq - tLo;                            // LDS row of sigma = 0
     auto xseg = [&](int sigma) -> c2 { return Xs[segBase + 4 * sigma][mb]; };
     c2 W[NT + 1];
 #pragma unroll
@@ -545,8 +563,8 @@ __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t 
         if constexpr (Swap) return __builtin_amdgcn_mfma_f32_4x4x1f32(b, a, acc, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, 0, 0, 0);
     };
-    for (int J = 0; J < (int)steps; ++J) {                                  // tap group: taps pBegin + 4 J .. + 3
-        const c2 h = Hs[4 * J + (int)mq][mb];                               // lane (b, n): h[pBegin + 4 J + n] of bin b
+    for (int J = 0; J < (int)steps; ++J) {                                  // tap group: taps 4 J .. 4 J + 3
+        const c2 h = Hs[4 * J + (int)mq][mb];                               // lane (b, n): h[4 J + n] of bin b
         const c2 xn = xseg(-(J + 1));                                       // enters the window after this group (row >= 0: tLo leaves room)
         // the four real products of a complex multiply-add; the packed bin's lanes get (hr xr, hi xi) from the same four instructions
         const float hB1 = h.x, hB2 = packedLane ? 0.0f : -h.y, hB3 = packedLane ? h.y : h.x, hB4 = packedLane ? 0.0f : h.y;
@@ -590,30 +608,38 @@ void elemhip_convolve_batch_mac(PlanView pv, uint32_t* recs, float* hbm, const G
     if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
     BatchCtx c;
     if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) return;     // (the ifft kernel writes the zeros)
-    // mode (engine option "conv_mfma"): 1 = the partition sums on the matrix cores (default), 0 = packed vector FMAs (r03),
-    // 2 = MFMA with the operand roles exchanged (the layout probe of the bring-up: wrong sums by construction)
-    // one LDS block, laid out per variant (the vector kernel's ring + H chunks: 24 KB; the matrix-core kernel's rows: 33 KB)
-    constexpr uint32_t kVecBytes = (kMacR * 20u + (kMacDP + 1u) * kMacU * 16u) * 8u;
-    __shared__ __attribute__((aligned(16))) char ldsRaw[kMfmaLdsBytes > kVecBytes ? kMfmaLdsBytes : kVecBytes];
-    const bool mfma = mode != 0u && (c.st.P + kMacParts - 1u) / kMacParts <= 4u * kMfmaSteps;      // (an IR longer than the LDS rows hold: vector kernel)
-    if (mfma) {
-        c2 (*Xm)[16] = reinterpret_cast<c2 (*)[16]>(ldsRaw);
-        c2 (*Hm)[16] = reinterpret_cast<c2 (*)[16]>(ldsRaw + (size_t)kMfmaXRows * 16u * 8u);
-        if (mode == 2u) { if (tile == 0u) batch_mac_tile_mfma<true, true>(c, tile, jBase, batch, tid, part, maxBatch, Xm, Hm); else batch_mac_tile_mfma<false, true>(c, tile, jBase, batch, tid, part, maxBatch, Xm, Hm); }
-        else if (tile == 0u) batch_mac_tile_mfma<true, false>(c, tile, jBase, batch, tid, part, maxBatch, Xm, Hm);
-        else batch_mac_tile_mfma<false, false>(c, tile, jBase, batch, tid, part, maxBatch, Xm, Hm);
-        return;
-    }
+    // (mode != 0: the nodes whose IR fits the matrix-core kernel are rendered by elemhip_convolve_batch_mac_mfma)
+    if (mode != 0u && c.st.P <= kTileHist) return;
+    __shared__ __attribute__((aligned(16))) char ldsRaw[(kMacR * 20u + (kMacDP + 1u) * kMacU * 16u) * 8u];
     c2 (&Xs)[kMacR][20] = *reinterpret_cast<c2 (*)[kMacR][20]>(ldsRaw);
     c2 (&Hs)[kMacDP + 1u][kMacU][16] = *reinterpret_cast<c2 (*)[kMacDP + 1u][kMacU][16]>(ldsRaw + (size_t)kMacR * 20u * 8u);
     if (tile == 0u) batch_mac_tile<true>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs);
     else batch_mac_tile<false>(c, tile, jBase, batch, tid, part, maxBatch, Xs, Hs);
 }
 
+// K2a on the matrix cores: one workgroup per (node, 16-bin tile, kMfmaOut blocks). mode (engine option "conv_mfma"): 1 = default
+// (IRs of up to kTileHist partitions; longer ones stay with the vector kernel), 0 = packed vector FMAs only (r03), 2 = MFMA with the
+// operand roles exchanged (the layout probe of the bring-up: wrong sums by construction).
+__global__ __launch_bounds__(256)
+void elemhip_convolve_batch_mac_mfma(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
+                                     uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t batch, uint32_t mode) {
+    const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, tile = blockIdx.y, tid = threadIdx.x, jB = blockIdx.z * kMfmaOut;
+    const ConvDesc d = pv.convs[convIdx];
+    if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
+    BatchCtx c;
+    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c) || c.st.P > kTileHist) return;
+    __shared__ __attribute__((aligned(16))) char ldsRaw[kMfmaLdsBytes];
+    c2 (*Xm)[16] = reinterpret_cast<c2 (*)[16]>(ldsRaw);
+    c2 (*Hm)[16] = reinterpret_cast<c2 (*)[16]>(ldsRaw + (size_t)kMfmaXRows * 16u * 8u);
+    if (mode == 2u) { if (tile == 0u) batch_mac_tile_mfma<true, true>(c, tile, jB, batch, tid, Xm, Hm); else batch_mac_tile_mfma<false, true>(c, tile, jB, batch, tid, Xm, Hm); }
+    else if (tile == 0u) batch_mac_tile_mfma<true, false>(c, tile, jB, batch, tid, Xm, Hm);
+    else batch_mac_tile_mfma<false, false>(c, tile, jB, batch, tid, Xm, Hm);
+}
+
 // K2b (node, j): inverse FFT of the block's partition sum; head half -> the node's output buffer of block j, tail half -> tails[j + 1]
 __global__ __launch_bounds__(256)
 void elemhip_convolve_batch_ifft(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                 uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch) {
+                                 uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t macMode) {
     __shared__ c2 A[conv::kFft], B[conv::kFft], W[conv::kFft];
     const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, j = blockIdx.y, tid = threadIdx.x;
     const ConvDesc d = pv.convs[convIdx];
@@ -630,7 +656,8 @@ void elemhip_convolve_batch_ifft(PlanView pv, uint32_t* recs, float* hbm, const 
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(1))) const f4* gcf4p;
     f4 y = ((gcf4p)(c.ysum + (size_t)j * 512u))[tid];
-    for (uint32_t q = 1; q < kMacParts; ++q) y += ((gcf4p)(c.ysum + ((size_t)q * maxBatch + j) * 512u))[tid];       // the runs' partial sums
+    const uint32_t runs = (macMode != 0u && c.st.P <= kTileHist) ? 1u : kMacParts;      // the matrix-core MAC sums all partitions in one run
+    for (uint32_t q = 1; q < runs; ++q) y += ((gcf4p)(c.ysum + ((size_t)q * maxBatch + j) * 512u))[tid];       // the runs' partial sums
     const c2 acc0 = mk(y.x, y.y), acc1 = mk(y.z, y.w);
     const uint32_t k0 = 2u * tid, k1 = k0 + 1u;
     if (tid == 0u) { A[0] = mk(acc0.x, 0.0f); A[512] = mk(acc0.y, 0.0f); }
@@ -676,17 +703,24 @@ void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* h
     hipLaunchKernelGGL(elemhip_convolve_kernel, dim3(numWorkgroups), dim3(256), 0, s, pv, recs, hbm, g, workBegin);
 }
 
-size_t convolve_batch_scratch_floats(uint32_t maxBatch) { return 16u + (size_t)maxBatch * 1024u + (size_t)(maxBatch + 1u) * 512u + (size_t)kMacParts * maxBatch * 1024u; }
+size_t convolve_batch_scratch_floats(uint32_t maxBatch) { return batch_scratch_floats(maxBatch); }
 
 void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                           uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch, uint32_t macMode) {
+                           uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch, uint32_t macMode,
+                           bool anyShortIr, bool anyLongIr) {
     const dim3 grid(numNodes, batch), block(256);
-    hipLaunchKernelGGL(elemhip_convolve_batch_fft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
-    // (node, 16-bin tile, 64-block chunk x partition run): 1024 workgroups for 8 channels
+    hipLaunchKernelGGL(elemhip_convolve_batch_fft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, macMode);
+    // the partition sums: nodes whose IR has at most kTileHist partitions on the matrix cores (macMode != 0), the others through the
+    // vector kernel — (node, 16-bin tile, 64-block chunk x partition run)
+    if (macMode != 0u && anyShortIr)
+        hipLaunchKernelGGL(elemhip_convolve_batch_mac_mfma, dim3(numNodes, conv::kBlock / 16u, (batch + kMfmaOut - 1u) / kMfmaOut), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, macMode);
+    if (macMode == 0u || anyLongIr)
     hipLaunchKernelGGL(elemhip_convolve_batch_mac, dim3(numNodes, conv::kBlock / 16u, kMacParts * ((batch + 63u) / 64u)), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, macMode);
-    hipLaunchKernelGGL(elemhip_convolve_batch_ifft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
+    hipLaunchKernelGGL(elemhip_convolve_batch_ifft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, macMode);
     hipLaunchKernelGGL(elemhip_convolve_batch_finish, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
 }
+
+uint32_t convolve_mfma_max_partitions() { return kTileHist; }
 
 hipError_t upload_convolve_tables(const float* twiddleReIm /* 2 * 1024 floats */) {
     return hipMemcpyToSymbol(HIP_SYMBOL(kTwiddle), twiddleReIm, sizeof(float) * 2 * conv::kFft);

@@ -381,6 +381,7 @@ int Engine::setConvolverIr(Node& n, const ResourcePtr& res) {
     const size_t words = conv::kHeaderDwords + 2 * ((size_t)2 * P + 2 * S + 1) * 512 + 1024;
     std::vector<uint32_t> blob(conv::kHeaderDwords + (size_t)P * 1024, 0u);
     blob[conv::H_P] = P; blob[conv::H_S] = S;
+    convMinP = std::min(convMinP, P); convMaxP = std::max(convMaxP, P);   // (over the engine's lifetime: which MAC kernels a launch set needs)
     // IR partition spectra in double, scaled by 1/1024 (exact), rounded to float, Nyquist packed into bin 0
     std::vector<std::complex<double>> a(N), tw(N / 2);
     for (uint32_t k = 0; k < N / 2; ++k) { const double ang = -2.0 * 3.14159265358979323846 * k / N; tw[k] = {std::cos(ang), std::sin(ang)}; }
@@ -1802,7 +1803,8 @@ void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32
     const uint32_t cb = p.convLevelOffsets[l], ce = p.convLevelOffsets[l + 1];
     uint32_t mains = 0;
     while (cb + mains < ce && (p.convWork[cb + mains] >> 16) == 0u) ++mains;   // main entries lead a level's work list
-    if (mains) launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks, (uint32_t)convMfma);
+    if (mains) launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks, (uint32_t)convMfma,
+                                     convMinP <= convolve_mfma_max_partitions(), convMaxP > convolve_mfma_max_partitions());
 }
 
 void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {

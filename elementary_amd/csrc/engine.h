@@ -249,6 +249,7 @@ private:
     bool useGraph = true;
     int  graphBlocks = 8;
     bool hostOutDirect = true;             // process(): the epilogue kernel writes into the mapped pinned output block
+    uint32_t convMinP = 0xFFFFFFFFu, convMaxP = 0;   // fewest / most partitions of any impulse response set so far
     int convMfma = 1;                      // conv.hip elemhip_convolve_batch_mac: 1 v_mfma_f32_4x4x1_16B_f32 Toeplitz tiles, 0 v_pk_fma_f32 (r03)
     bool specBlocks = true;                // process(): whole blocks of a settled, fully compiled sequence use the specialised kernels
     int  batchBlocks = 64;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)

@@ -19,7 +19,9 @@ void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* h
                      uint32_t workBegin, uint32_t numWorkgroups);
 size_t convolve_batch_scratch_floats(uint32_t maxBatch);   // per convolve node
 void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                           uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch, uint32_t macMode);
+                           uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch, uint32_t macMode,
+                           bool anyShortIr, bool anyLongIr);
+uint32_t convolve_mfma_max_partitions();   // IRs of up to this many 512-tap partitions take the matrix-core MAC
 hipError_t upload_convolve_tables(const float* twiddleReIm);
 void launch_patches(hipStream_t s, const Patch* patches, uint32_t count, uint32_t* recs, uint32_t* globals);
 
