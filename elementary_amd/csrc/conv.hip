@@ -503,6 +503,8 @@ __device__ __forceinline__ void batch_mac_tile(const BatchCtx& c, uint32_t tile,
 // Same workgroup geometry, LDS ring and H staging as batch_mac_tile; a wave owns 16 consecutive blocks = 4 output tiles + the
 // fifth tile whose lower diagonals complete the fourth.
 typedef float f4v __attribute__((ext_vector_type(4)));
+template <int V> struct MfmaIntC { static constexpr int value = V; };
+template <int I, int N, class F> __device__ __forceinline__ void mfma_static_for(F&& f) { if constexpr (I < N) { f(MfmaIntC<I>{}); mfma_static_for<I + 1, N>(f); } }
 template <int CTRL>
 __device__ __forceinline__ float quad_rot(float v) {      // value of lane (n + k) % 4 of the same quad, k encoded in CTRL
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -552,33 +554,37 @@ __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t 
     // x segment sigma of this wave: lane (b, m) holds x[Tw + 4 sigma - m] of bin b
     const int segBase = (int)Tw - (int)mq - tLo;                            // LDS row of sigma = 0
     auto xseg = [&](int sigma) -> c2 { return Xs[segBase + 4 * sigma][mb]; };
-    c2 W[NT + 1];
+    // The window of x segments lives in NT + 1 registers used round-robin: segment sigma sits in slot sigma mod (NT + 1), the tap
+    // loop is unrolled NT + 1 times so that every slot index is a compile-time constant (a rotating array made the compiler copy
+    // the window AND the accumulators every step: 130 register moves per 36 MFMAs in the first build of this kernel).
+    constexpr int NS = NT + 1;
+    c2 W[NS];
 #pragma unroll
-    for (int i = 0; i <= NT; ++i) W[i] = xseg(i);
-    f4v Dr[NT + 1], Di[NT + 1];
+    for (int i = 0; i < NS; ++i) W[i] = xseg(i);
+    f4v Dr[NS], Di[NS];
 #pragma unroll
-    for (int i = 0; i <= NT; ++i) { Dr[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f}; Di[i] = Dr[i]; }
+    for (int i = 0; i < NS; ++i) { Dr[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f}; Di[i] = Dr[i]; }
     const bool packedLane = HasPacked && tile == 0u && mb == 0u;            // bin 0 carries two REAL bins (DC, Nyquist): (hr xr, hi xi)
     auto mma = [&](float a, float b, f4v acc) -> f4v {
         if constexpr (Swap) return __builtin_amdgcn_mfma_f32_4x4x1f32(b, a, acc, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, 0, 0, 0);
     };
-    for (int J = 0; J < (int)steps; ++J) {                                  // tap group: taps 4 J .. 4 J + 3
-        const c2 h = Hs[4 * J + (int)mq][mb];                               // lane (b, n): h[4 J + n] of bin b
-        const c2 xn = xseg(-(J + 1));                                       // enters the window after this group (row >= 0: tLo leaves room)
-        // the four real products of a complex multiply-add; the packed bin's lanes get (hr xr, hi xi) from the same four instructions
-        const float hB1 = h.x, hB2 = packedLane ? 0.0f : -h.y, hB3 = packedLane ? h.y : h.x, hB4 = packedLane ? 0.0f : h.y;
-#pragma unroll
-        for (int i = 0; i <= NT; ++i) Dr[i] = mma(W[i].x, hB1, Dr[i]);
-#pragma unroll
-        for (int i = 0; i <= NT; ++i) Di[i] = mma(W[i].y, hB3, Di[i]);
-#pragma unroll
-        for (int i = 0; i <= NT; ++i) Dr[i] = mma(W[i].y, hB2, Dr[i]);
-#pragma unroll
-        for (int i = 0; i <= NT; ++i) Di[i] = mma(W[i].x, hB4, Di[i]);
-#pragma unroll
-        for (int i = NT; i > 0; --i) W[i] = W[i - 1];
-        W[0] = xn;
+    for (int J0 = 0; J0 < (int)steps; J0 += NS) {                           // tap groups J0 .. J0 + NT (taps 4 J .. 4 J + 3 each)
+        mfma_static_for<0, NS>([&](auto Uc) {
+            constexpr int u = decltype(Uc)::value;
+            const int J = J0 + u;
+            if (J >= (int)steps) return;
+            const c2 h = Hs[4 * J + (int)mq][mb];                           // lane (b, n): h[4 J + n] of bin b
+            const c2 xn = xseg(-(J + 1));                                   // enters the window after this group (row >= 0: tLo leaves room)
+            // the four real products of a complex multiply-add; the packed bin's lanes get (hr xr, hi xi) from the same four instructions
+            const float hB1 = h.x, hB2 = packedLane ? 0.0f : -h.y, hB3 = packedLane ? h.y : h.x, hB4 = packedLane ? 0.0f : h.y;
+            // tile i multiplies segment sigma = i - J: slot (i - u) mod NS (J0 is a multiple of NS)
+            mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Dr[i] = mma(W[sl].x, hB1, Dr[i]); });
+            mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Di[i] = mma(W[sl].y, hB3, Di[i]); });
+            mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Dr[i] = mma(W[sl].y, hB2, Dr[i]); });
+            mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Di[i] = mma(W[sl].x, hB4, Di[i]); });
+            W[(NT - u + NS) % NS] = xn;                                     // the oldest segment (tile NT's) makes room for sigma = -(J + 1)
+        });
     }
     // anti-diagonals: lane n of a quad collects D[m][(n + m) % 4] from register m; n + m < 4 belongs to y[t0 + n] of this tile (P),
     // n + m >= 4 to y[t0 - 4 + n], i.e. to the previous tile's outputs (Q)
