@@ -509,19 +509,21 @@ template <int CTRL>
 __device__ __forceinline__ float quad_rot(float v) {      // value of lane (n + k) % 4 of the same quad, k encoded in CTRL
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-// LDS of the matrix-core variant: EVERY input-spectrum row and IR row the workgroup needs, loaded once, up front, from the TILED
-// copies the fft kernel leaves (one contiguous stream per workgroup, one barrier, then nothing but MFMAs and two 8-byte LDS reads
-// per 36 of them). Two earlier versions, measured (profiles/r04/c3_mac_variants.txt): the vector kernel's chunked LDS ring with MFMA
-// arithmetic — no faster (131 us per 1024-block set either way); everything up front from the natural [row][512] layout, 64 blocks
-// and half the partitions per workgroup — 183 us: both are bound by what the workgroups READ (8192 workgroups x 33 KB = 270 MB per
-// set in 128-byte pieces 4 KB apart, ~2 TB/s), not by arithmetic. Hence: tiled copies, ALL partitions and 128 blocks per workgroup
-// (2048 workgroups x 65 KB), a wave = 32 consecutive blocks = 8 output tiles + the ninth whose lower diagonals complete the eighth.
+// The matrix-core variant is PERSISTENT over the block axis: a workgroup owns (node, 16-bin tile) and walks `chunks` runs of
+// kMfmaOut = 128 blocks. LDS holds the tile's IR rows (loaded once) and a 512-row ring of input-spectrum rows, both read from the
+// TILED copies the fft kernel leaves — contiguous streams; while a run's MFMAs execute, the next run's 128 new rows are already on
+// their way (registers -> ring after the run). Every spectrum row and every IR row is read from memory ONCE per (node, tile).
+// Measured on the way here (profiles/r04/c3_mac_variants.txt, 8 channels x 188 partitions, 1024-block sets): the vector kernel's
+// chunked ring with MFMA arithmetic 131 us (= the vector kernel: both wait out a global round trip per 8-partition chunk);
+// everything up front from the natural [row][512] layout, 64 blocks x half the partitions per workgroup 183 us (8192 workgroups x
+// 33 KB in 128-byte pieces 4 KB apart); tiled copies, all partitions, 128 blocks per workgroup 162 us with a rotating register
+// window (the compiler copied window AND accumulators every step) and 92 us with compile-time window slots; persistent: below.
 constexpr uint32_t kMfmaSteps = kTileHist / 4u;                      // tap groups of 4
-constexpr uint32_t kMfmaOut = 128;                                   // blocks per workgroup
-constexpr uint32_t kMfmaXRows = kMfmaOut + 4u * kMfmaSteps + 8u;     // 328 rows x 16 bins x 8 bytes = 41 KB
-constexpr uint32_t kMfmaLdsBytes = (kMfmaXRows + kTileHist) * 16u * 8u;   // + 192 IR rows: 65 KB, two workgroups per CU
+constexpr uint32_t kMfmaOut = 128;                                   // blocks per run
+constexpr uint32_t kMfmaRing = 512;                                  // ring rows (>= kMfmaOut + 4 kMfmaSteps + 8 live rows + kMfmaOut incoming)
+constexpr uint32_t kMfmaLdsBytes = (kMfmaRing + kTileHist) * 16u * 8u;    // 64 KB + 24 KB: one workgroup per CU
 template <bool HasPacked, bool Swap>
-__device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t tile, uint32_t jBase, uint32_t batch, uint32_t tid,
+__device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t tile, uint32_t jFirst, uint32_t chunks, uint32_t batch, uint32_t tid,
                                                     c2 (*Xs)[16], c2 (*Hs)[16]) {
     constexpr int NT = 8;                                                   // output tiles per wave (+ 1 for the last tile's lower diagonals)
     const uint32_t bin = tid & 15u, row = tid >> 4;                         // load roles: 16 rows x 16 bins per pass = 2 KB contiguous
@@ -534,58 +536,29 @@ __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t 
         if (t >= (int)batch || t < -(int)P) return mk(0.0f, 0.0f);         // (rows older than the IR is long meet zero taps only: keep NaNs out)
         return Xt[(size_t)((int)kTileHist + t) * 16u];
     };
-    const uint32_t Tw = jBase + wave * 32u;                                 // this wave's first output block
-    gf2p Y = c.ysum + tile * 16u + mb;                                      // one partition run: partial sum 0 is the sum
     const uint32_t steps = (P + 3u) / 4u;                                   // <= kMfmaSteps (P <= kTileHist: checked by the caller)
-    const int tLo = (int)jBase - 4 * (int)steps - 4;                        // LDS row r holds time tLo + r
-    {
-        constexpr uint32_t NX = (kMfmaXRows + 15u) / 16u, NH = kTileHist / 16u;
+    const int tBase = (int)jFirst - (int)kMfmaRing;                         // ring row of time t: (t - tBase) & (kMfmaRing - 1)
+    auto ringRow = [&](int t) -> uint32_t { return (uint32_t)(t - tBase) & (kMfmaRing - 1u); };
+    {   // IR rows and the first run's window [jFirst - 4 steps - 4, jFirst + kMfmaOut]
+        constexpr uint32_t NX = (kMfmaOut + 4u * kMfmaSteps + 8u + 15u) / 16u, NH = kTileHist / 16u;
+        const int tLo = (int)jFirst - 4 * (int)steps - 4;
+        const uint32_t rows = kMfmaOut + 4u * steps + 5u;
         c2 fx[NX], fh[NH];
 #pragma unroll
-        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; fx[i] = r < kMfmaXRows ? xat(tLo + (int)r) : mk(0.0f, 0.0f); }
+        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; fx[i] = r < rows ? xat(tLo + (int)r) : mk(0.0f, 0.0f); }
 #pragma unroll
         for (uint32_t i = 0; i < NH; ++i) { const uint32_t p = row + 16u * i; fh[i] = p < P ? Ht[(size_t)p * 16u] : mk(0.0f, 0.0f); }   // taps past the end multiply by zero
 #pragma unroll
-        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; if (r < kMfmaXRows) Xs[r][bin] = fx[i]; }
+        for (uint32_t i = 0; i < NX; ++i) { const uint32_t r = row + 16u * i; if (r < rows) Xs[ringRow(tLo + (int)r)][bin] = fx[i]; }
 #pragma unroll
         for (uint32_t i = 0; i < NH; ++i) Hs[row + 16u * i][bin] = fh[i];
     }
     __syncthreads();
-    // x segment sigma of this wave: lane (b, m) holds x[Tw + 4 sigma - m] of bin b
-    const int segBase = (int)Tw - (int)mq - tLo;                            // LDS row of sigma = 0
-    auto xseg = [&](int sigma) -> c2 { return Xs[segBase + 4 * sigma][mb]; };
-    // The window of x segments lives in NT + 1 registers used round-robin: segment sigma sits in slot sigma mod (NT + 1), the tap
-    // loop is unrolled NT + 1 times so that every slot index is a compile-time constant (a rotating array made the compiler copy
-    // the window AND the accumulators every step: 130 register moves per 36 MFMAs in the first build of this kernel).
-    constexpr int NS = NT + 1;
-    c2 W[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) W[i] = xseg(i);
-    f4v Dr[NS], Di[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) { Dr[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f}; Di[i] = Dr[i]; }
     const bool packedLane = HasPacked && tile == 0u && mb == 0u;            // bin 0 carries two REAL bins (DC, Nyquist): (hr xr, hi xi)
     auto mma = [&](float a, float b, f4v acc) -> f4v {
         if constexpr (Swap) return __builtin_amdgcn_mfma_f32_4x4x1f32(b, a, acc, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, 0, 0, 0);
     };
-    for (int J0 = 0; J0 < (int)steps; J0 += NS) {                           // tap groups J0 .. J0 + NT (taps 4 J .. 4 J + 3 each)
-        mfma_static_for<0, NS>([&](auto Uc) {
-            constexpr int u = decltype(Uc)::value;
-            const int J = J0 + u;
-            if (J >= (int)steps) return;
-            const c2 h = Hs[4 * J + (int)mq][mb];                           // lane (b, n): h[4 J + n] of bin b
-            const c2 xn = xseg(-(J + 1));                                   // enters the window after this group (row >= 0: tLo leaves room)
-            // the four real products of a complex multiply-add; the packed bin's lanes get (hr xr, hi xi) from the same four instructions
-            const float hB1 = h.x, hB2 = packedLane ? 0.0f : -h.y, hB3 = packedLane ? h.y : h.x, hB4 = packedLane ? 0.0f : h.y;
-            // tile i multiplies segment sigma = i - J: slot (i - u) mod NS (J0 is a multiple of NS)
-            mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Dr[i] = mma(W[sl].x, hB1, Dr[i]); });
-            mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Di[i] = mma(W[sl].y, hB3, Di[i]); });
-            mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Dr[i] = mma(W[sl].y, hB2, Dr[i]); });
-            mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Di[i] = mma(W[sl].x, hB4, Di[i]); });
-            W[(NT - u + NS) % NS] = xn;                                     // the oldest segment (tile NT's) makes room for sigma = -(J + 1)
-        });
-    }
     // anti-diagonals: lane n of a quad collects D[m][(n + m) % 4] from register m; n + m < 4 belongs to y[t0 + n] of this tile (P),
     // n + m >= 4 to y[t0 - 4 + n], i.e. to the previous tile's outputs (Q)
     auto diag = [&](const f4v& D, float& Pn, float& Qn) {
@@ -595,13 +568,61 @@ __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t 
         if (mq + 2u < 4u) Pn += v2; else Qn += v2;
         if (mq + 3u < 4u) Pn += v3; else Qn += v3;
     };
-    float Pr[NT + 1], Qr[NT + 1], Pi[NT + 1], Qi[NT + 1];
+    gf2p Y = c.ysum + tile * 16u + mb;                                      // one partition run: partial sum 0 is the sum
+    constexpr int NS = NT + 1;
+    for (uint32_t ch = 0; ch < chunks; ++ch) {
+        const uint32_t jBase = jFirst + ch * kMfmaOut;
+        if (jBase >= batch) break;
+        // the next run's new rows (jBase + kMfmaOut, jBase + 2 kMfmaOut]: in flight during this run's arithmetic
+        constexpr uint32_t NP = kMfmaOut / 16u;
+        c2 pre[NP];
+        const bool more = ch + 1u < chunks && jBase + kMfmaOut < batch;
+        if (more) {
 #pragma unroll
-    for (int i = 0; i <= NT; ++i) { diag(Dr[i], Pr[i], Qr[i]); diag(Di[i], Pi[i], Qi[i]); }
+            for (uint32_t i = 0; i < NP; ++i) pre[i] = xat((int)(jBase + kMfmaOut + 1u + row + 16u * i));
+        }
+        const uint32_t Tw = jBase + wave * 32u;                             // this wave's first output block
+        // x segment sigma of this wave: lane (b, m) holds x[Tw + 4 sigma - m] of bin b. The window of segments lives in NT + 1
+        // registers used round-robin — segment sigma in slot sigma mod (NT + 1) — and the tap loop is unrolled NT + 1 times so that
+        // every slot index is a compile-time constant.
+        auto xseg = [&](int sigma) -> c2 { return Xs[ringRow((int)Tw + 4 * sigma - (int)mq)][mb]; };
+        c2 W[NS];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const uint32_t t = Tw + 4u * (uint32_t)i + mq;
-        if (t < batch) Y[(size_t)t * 512u] = mk(Pr[i] + Qr[i + 1], Pi[i] + Qi[i + 1]);
+        for (int i = 0; i < NS; ++i) W[i] = xseg(i);
+        f4v Dr[NS], Di[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { Dr[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f}; Di[i] = Dr[i]; }
+        for (int J0 = 0; J0 < (int)steps; J0 += NS) {                       // tap groups J0 .. J0 + NT (taps 4 J .. 4 J + 3 each)
+            mfma_static_for<0, NS>([&](auto Uc) {
+                constexpr int u = decltype(Uc)::value;
+                const int J = J0 + u;
+                if (J >= (int)steps) return;
+                const c2 h = Hs[4 * J + (int)mq][mb];                       // lane (b, n): h[4 J + n] of bin b
+                const c2 xn = xseg(-(J + 1));                               // enters the window after this group
+                // the four real products of a complex multiply-add; the packed bin's lanes get (hr xr, hi xi) from the same four instructions
+                const float hB1 = h.x, hB2 = packedLane ? 0.0f : -h.y, hB3 = packedLane ? h.y : h.x, hB4 = packedLane ? 0.0f : h.y;
+                // tile i multiplies segment sigma = i - J: slot (i - u) mod NS (J0 is a multiple of NS)
+                mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Dr[i] = mma(W[sl].x, hB1, Dr[i]); });
+                mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Di[i] = mma(W[sl].y, hB3, Di[i]); });
+                mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Dr[i] = mma(W[sl].y, hB2, Dr[i]); });
+                mfma_static_for<0, NS>([&](auto Ic) { constexpr int i = decltype(Ic)::value; constexpr int sl = (i - u + NS) % NS; Di[i] = mma(W[sl].x, hB4, Di[i]); });
+                W[(NT - u + NS) % NS] = xn;                                 // the oldest segment (tile NT's) makes room for sigma = -(J + 1)
+            });
+        }
+        float Pr[NS], Qr[NS], Pi[NS], Qi[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { diag(Dr[i], Pr[i], Qr[i]); diag(Di[i], Pi[i], Qi[i]); }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const uint32_t t = Tw + 4u * (uint32_t)i + mq;
+            if (t < batch) Y[(size_t)t * 512u] = mk(Pr[i] + Qr[i + 1], Pi[i] + Qi[i + 1]);
+        }
+        if (more) {   // every wave is done with this run's window: the new rows replace the oldest ones
+            __syncthreads();
+#pragma unroll
+            for (uint32_t i = 0; i < NP; ++i) Xs[ringRow((int)(jBase + kMfmaOut + 1u + row + 16u * i))][bin] = pre[i];
+            __syncthreads();
+        }
     }
 }
 
@@ -628,18 +649,18 @@ void elemhip_convolve_batch_mac(PlanView pv, uint32_t* recs, float* hbm, const G
 // operand roles exchanged (the layout probe of the bring-up: wrong sums by construction).
 __global__ __launch_bounds__(256)
 void elemhip_convolve_batch_mac_mfma(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                     uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t batch, uint32_t mode) {
-    const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, tile = blockIdx.y, tid = threadIdx.x, jB = blockIdx.z * kMfmaOut;
+                                     uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t batch, uint32_t mode, uint32_t chunks) {
+    const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, tile = blockIdx.y, tid = threadIdx.x, jFirst = blockIdx.z * chunks * kMfmaOut;
     const ConvDesc d = pv.convs[convIdx];
-    if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
+    if (jFirst >= batch || !root_running((gcup)recs, d.rootRec, g->numOut)) return;
     BatchCtx c;
     if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c) || c.st.P > kTileHist) return;
     __shared__ __attribute__((aligned(16))) char ldsRaw[kMfmaLdsBytes];
     c2 (*Xm)[16] = reinterpret_cast<c2 (*)[16]>(ldsRaw);
-    c2 (*Hm)[16] = reinterpret_cast<c2 (*)[16]>(ldsRaw + (size_t)kMfmaXRows * 16u * 8u);
-    if (mode == 2u) { if (tile == 0u) batch_mac_tile_mfma<true, true>(c, tile, jB, batch, tid, Xm, Hm); else batch_mac_tile_mfma<false, true>(c, tile, jB, batch, tid, Xm, Hm); }
-    else if (tile == 0u) batch_mac_tile_mfma<true, false>(c, tile, jB, batch, tid, Xm, Hm);
-    else batch_mac_tile_mfma<false, false>(c, tile, jB, batch, tid, Xm, Hm);
+    c2 (*Hm)[16] = reinterpret_cast<c2 (*)[16]>(ldsRaw + (size_t)kMfmaRing * 16u * 8u);
+    if (mode == 2u) { if (tile == 0u) batch_mac_tile_mfma<true, true>(c, tile, jFirst, chunks, batch, tid, Xm, Hm); else batch_mac_tile_mfma<false, true>(c, tile, jFirst, chunks, batch, tid, Xm, Hm); }
+    else if (tile == 0u) batch_mac_tile_mfma<true, false>(c, tile, jFirst, chunks, batch, tid, Xm, Hm);
+    else batch_mac_tile_mfma<false, false>(c, tile, jFirst, chunks, batch, tid, Xm, Hm);
 }
 
 // K2b (node, j): inverse FFT of the block's partition sum; head half -> the node's output buffer of block j, tail half -> tails[j + 1]
@@ -718,8 +739,13 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
     hipLaunchKernelGGL(elemhip_convolve_batch_fft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, macMode);
     // the partition sums: nodes whose IR has at most kTileHist partitions on the matrix cores (macMode != 0), the others through the
     // vector kernel — (node, 16-bin tile, 64-block chunk x partition run)
-    if (macMode != 0u && anyShortIr)
-        hipLaunchKernelGGL(elemhip_convolve_batch_mac_mfma, dim3(numNodes, conv::kBlock / 16u, (batch + kMfmaOut - 1u) / kMfmaOut), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, macMode);
+    if (macMode != 0u && anyShortIr) {
+        // persistent over the block axis: as many runs per workgroup as leave about one workgroup per CU (256 on this chip)
+        const uint32_t runs = (batch + kMfmaOut - 1u) / kMfmaOut, pairs = numNodes * (conv::kBlock / 16u);
+        uint32_t per = (runs * pairs) / 256u;
+        per = per < 1u ? 1u : (per > runs ? runs : per);
+        hipLaunchKernelGGL(elemhip_convolve_batch_mac_mfma, dim3(numNodes, conv::kBlock / 16u, (runs + per - 1u) / per), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, macMode, per);
+    }
     if (macMode == 0u || anyLongIr)
     hipLaunchKernelGGL(elemhip_convolve_batch_mac, dim3(numNodes, conv::kBlock / 16u, kMacParts * ((batch + 63u) / 64u)), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, macMode);
     hipLaunchKernelGGL(elemhip_convolve_batch_ifft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, macMode);
