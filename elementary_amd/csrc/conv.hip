@@ -520,8 +520,9 @@ __device__ __forceinline__ float quad_rot(float v) {      // value of lane (n + 
 // window (the compiler copied window AND accumulators every step) and 92 us with compile-time window slots; persistent: below.
 constexpr uint32_t kMfmaSteps = kTileHist / 4u;                      // tap groups of 4
 constexpr uint32_t kMfmaOut = 128;                                   // blocks per run
-constexpr uint32_t kMfmaRing = 512;                                  // ring rows (>= kMfmaOut + 4 kMfmaSteps + 8 live rows + kMfmaOut incoming)
-constexpr uint32_t kMfmaLdsBytes = (kMfmaRing + kTileHist) * 16u * 8u;    // 64 KB + 24 KB: one workgroup per CU
+constexpr uint32_t kMfmaRing = 336;                                  // ring rows: a run reads kMfmaOut + 4 kMfmaSteps + 5 = 325 of them; the next
+                                                                     // run's 128 new rows replace rows that are dead by then
+constexpr uint32_t kMfmaLdsBytes = (kMfmaRing + kTileHist) * 16u * 8u;    // 42 KB + 24 KB: two workgroups per CU
 template <bool HasPacked, bool Swap>
 __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t tile, uint32_t jFirst, uint32_t chunks, uint32_t batch, uint32_t tid,
                                                     c2 (*Xs)[16], c2 (*Hs)[16]) {
@@ -537,8 +538,8 @@ __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t 
         return Xt[(size_t)((int)kTileHist + t) * 16u];
     };
     const uint32_t steps = (P + 3u) / 4u;                                   // <= kMfmaSteps (P <= kTileHist: checked by the caller)
-    const int tBase = (int)jFirst - (int)kMfmaRing;                         // ring row of time t: (t - tBase) & (kMfmaRing - 1)
-    auto ringRow = [&](int t) -> uint32_t { return (uint32_t)(t - tBase) & (kMfmaRing - 1u); };
+    const int tBase = (int)jFirst - 3 * (int)kMfmaRing;                     // ring row of time t: (t - tBase) mod kMfmaRing (t - tBase > 0)
+    auto ringRow = [&](int t) -> uint32_t { return (uint32_t)(t - tBase) % kMfmaRing; };                 // (loads and window set-up only: the tap loop steps a row index)
     {   // IR rows and the first run's window [jFirst - 4 steps - 4, jFirst + kMfmaOut]
         constexpr uint32_t NX = (kMfmaOut + 4u * kMfmaSteps + 8u + 15u) / 16u, NH = kTileHist / 16u;
         const int tLo = (int)jFirst - 4 * (int)steps - 4;
@@ -592,13 +593,21 @@ __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t 
         f4v Dr[NS], Di[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) { Dr[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f}; Di[i] = Dr[i]; }
+        // the h values and the entering x segment of tap group J + 1 are read from LDS while group J's MFMAs execute (a lone wave
+        // per SIMD has nothing else to hide an LDS round trip behind)
+        int xr = (int)ringRow((int)Tw - 4 - (int)mq);                       // ring row of segment sigma = -1; steps down by 4 per group
+        c2 hN = Hs[mq][mb], xN = Xs[xr][mb];
         for (int J0 = 0; J0 < (int)steps; J0 += NS) {                       // tap groups J0 .. J0 + NT (taps 4 J .. 4 J + 3 each)
             mfma_static_for<0, NS>([&](auto Uc) {
                 constexpr int u = decltype(Uc)::value;
                 const int J = J0 + u;
                 if (J >= (int)steps) return;
-                const c2 h = Hs[4 * J + (int)mq][mb];                       // lane (b, n): h[4 J + n] of bin b
-                const c2 xn = xseg(-(J + 1));                               // enters the window after this group
+                const c2 h = hN, xn = xN;                                   // lane (b, n): h[4 J + n] of bin b; the segment entering after this group
+                {
+                    const int Jn = J + 1 < (int)steps ? J + 1 : J;          // (the last group re-reads its own rows: unused)
+                    xr -= 4; if (xr < 0) xr += (int)kMfmaRing;
+                    hN = Hs[4 * Jn + (int)mq][mb]; xN = Xs[xr][mb];
+                }
                 // the four real products of a complex multiply-add; the packed bin's lanes get (hr xr, hi xi) from the same four instructions
                 const float hB1 = h.x, hB2 = packedLane ? 0.0f : -h.y, hB3 = packedLane ? h.y : h.x, hB4 = packedLane ? 0.0f : h.y;
                 // tile i multiplies segment sigma = i - J: slot (i - u) mod NS (J0 is a multiple of NS)
@@ -740,9 +749,9 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
     // the partition sums: nodes whose IR has at most kTileHist partitions on the matrix cores (macMode != 0), the others through the
     // vector kernel — (node, 16-bin tile, 64-block chunk x partition run)
     if (macMode != 0u && anyShortIr) {
-        // persistent over the block axis: as many runs per workgroup as leave about one workgroup per CU (256 on this chip)
+        // persistent over the block axis: as many runs per workgroup as leave about two workgroups per CU (256 CUs on this chip)
         const uint32_t runs = (batch + kMfmaOut - 1u) / kMfmaOut, pairs = numNodes * (conv::kBlock / 16u);
-        uint32_t per = (runs * pairs) / 256u;
+        uint32_t per = (runs * pairs) / 512u;      // (two workgroups per CU: LDS)
         per = per < 1u ? 1u : (per > runs ? runs : per);
         hipLaunchKernelGGL(elemhip_convolve_batch_mac_mfma, dim3(numNodes, conv::kBlock / 16u, (runs + per - 1u) / per), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, macMode, per);
     }
