@@ -227,15 +227,19 @@ def main_c4(args) -> None:
     from elementary_amd.sharded import gather_outputs
 
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
+    if world != args.gpus and (args.gpus > 1 or world > 1):
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     if args.shared_gpu:
         local = 0
     torch.cuda.set_device(local)
+    ranks_seen = 1
     if world > 1:
         dist.init_process_group(args.backend, rank=rank, world_size=world)
+        ranks_seen = dist.get_world_size()
+        if ranks_seen != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {ranks_seen} ranks")
     inst, B = args.instances, max(1, min(1024, args.batch_blocks))
     rt = Runtime(graphs.C4_SAMPLE_RATE, BLOCK, device=local)
     rt.set_option("batch_blocks", B)
@@ -312,7 +316,7 @@ def main_c4(args) -> None:
             "config": {"workload": f"BASELINE configs[3] (C4): {inst} independent render instances per GPU ({inst * world} in all), "
                                    "each rand -> svf -> delay{24000} -> biquad -> sdelay -> tanh (odd instances: biquad before svf), "
                                    f"sr 48000, blockSize 512; one step = one launch set of {B} blocks of every instance",
-                       "instances_per_gpu": inst, "instances_total": inst * world,
+                       "instances_per_gpu": inst, "instances_total": inst * world, "ranks_seen": ranks_seen,
                        "blocks_per_step": B, "islands": stats["num_islands"], "launch_levels": stats["num_levels"],
                        "mode": "host buffers (elemhip_process_blocks_host): every job's samples delivered to the caller's arrays" if host_mode
                                else "device-resident render (elemhip_process_blocks)",
@@ -373,15 +377,19 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
+    if world != args.gpus and (args.gpus > 1 or world > 1):
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     if args.shared_gpu:
         local = 0
     torch.cuda.set_device(local)
+    ranks_seen = 1
     if world > 1:
         dist.init_process_group(args.backend, rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
+        ranks_seen = dist.get_world_size()
+        if ranks_seen != args.gpus:       # the driver computes scaling from n_gpus: never print a line for another job size
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {ranks_seen} ranks")
 
     # ---- this rank's shard of the synth (independent voices: no data-path collective) ----
     if args.scaling == "strong":
@@ -543,7 +551,7 @@ def main() -> None:
                 "frames_per_step": B * BLOCK,
                 "nodes_per_gpu": stats["num_nodes_in_plan"],
                 "voices_per_gpu": my_voices,
-                "voices_total": total_voices,
+                "voices_total": total_voices, "ranks_seen": ranks_seen,
                 "block_size": BLOCK,
                 "mode": ("host buffers: elemhip_process_blocks_host, every block delivered to the caller's planar host arrays "
                          "(pinned double-buffered launch sets, D2H of set k under the rendering of set k + 1); all K steps in one call")

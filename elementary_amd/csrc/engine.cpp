@@ -205,10 +205,11 @@ void Engine::setStream(hipStream_t s) {
     if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
 }
 
-void Engine::freeDeferred() {   // called right after a stream synchronize
+void Engine::freeDeferred() {   // called right after a synchronize of every stream the engine renders on (`mu` held)
     patchCursor = 0;
     for (void* p : deferredFree) (void)hipFree(p);
     deferredFree.clear();
+    retiredPlans.clear();         // plans replaced since the last synchronize: their tables / hipGraphs are idle now (~Plan frees them)
 }
 
 int Engine::ensureHbm(size_t buffers) {
@@ -1134,7 +1135,9 @@ size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
     }
     for (int32_t id : pruned) {
         Node& n = nodes.at(id);
-        if (n.ring.ptr) { if (dry) std::free(n.ring.ptr); else (void)hipFree(n.ring.ptr); }   // device is idle whenever `mu` is free
+        // (`mu` free does NOT mean the device is idle: elemhip_process_blocks_host drops it between launch sets while one renders.
+        //  Device memory is released after the next synchronize — freeDeferred — never under a kernel that may still read it.)
+        if (n.ring.ptr) { if (dry) std::free(n.ring.ptr); else deferredFree.push_back(n.ring.ptr); }
         if (n.hostInst && n.hostVt && n.hostVt->destroy) n.hostVt->destroy(n.hostInst, n.hostVt->user);
         // drop queued writes aimed at the record before it is recycled
         const uint32_t lo = n.rec * kRecDwords, hi = lo + kRecDwords;
@@ -1254,8 +1257,10 @@ void Engine::pruneSharedResources() {   // SharedResource.h:94-102
     if (!dry) (void)hipSetDevice(device);
     for (auto it = resources.begin(); it != resources.end();) {
         if (it->second.use_count() == 1) {
-            if (it->second->dev.ptr) { if (dry) std::free(it->second->dev.ptr); else (void)hipFree(it->second->dev.ptr); }
-            for (DevBuf& d : it->second->devCh) if (d.ptr) { if (dry) std::free(d.ptr); else (void)hipFree(d.ptr); }
+            if (it->second->dev.ptr) { if (dry) std::free(it->second->dev.ptr); else deferredFree.push_back(it->second->dev.ptr); }
+            for (DevBuf& d : it->second->devCh) if (d.ptr) { if (dry) std::free(d.ptr); else deferredFree.push_back(d.ptr); }
+            it->second->dev.ptr = nullptr;
+            for (DevBuf& d : it->second->devCh) d.ptr = nullptr;
             it = resources.erase(it);
         } else ++it;
     }
@@ -1374,6 +1379,7 @@ void Engine::setInRing(const float* ring, uint32_t blocks) {
 
 int Engine::swapInPending() {   // Runtime.h:277-285: newest sequence wins
     if (pending) {
+        if (current && !dry) retiredPlans.push_back(std::move(current));   // its kernels may still be queued (host path): freed after the next synchronize
         current = pending;
         pending.reset();
         st.numIslands = (uint32_t)current->islands.size();
@@ -1947,15 +1953,20 @@ int Engine::ensureHostStaging(size_t outFloats, size_t inFloats) {
         if (want <= have) return kOk;
         HIP_OK(hipStreamSynchronize(stream));
         HIP_OK(hipStreamSynchronize(ioStream));
+        // the new buffers first: a failed allocation leaves the old pair (and `have`) as they were
+        float* nh[2] = {nullptr, nullptr}; float* nd[2] = {nullptr, nullptr};
+        bool ok = true;
+        for (int k = 0; k < 2 && ok; ++k)
+            ok = hipHostMalloc((void**)&nh[k], want * sizeof(float), hipHostMallocDefault) == hipSuccess && hipMalloc(&nd[k], want * sizeof(float)) == hipSuccess;
+        if (!ok) {
+            for (int k = 0; k < 2; ++k) { if (nh[k]) (void)hipHostFree(nh[k]); if (nd[k]) (void)hipFree(nd[k]); }
+            (void)hipGetLastError();
+            return kHipError;
+        }
         for (int k = 0; k < 2; ++k) {
             if (h[k]) (void)hipHostFree(h[k]);
             if (d[k]) (void)hipFree(d[k]);
-            h[k] = nullptr; d[k] = nullptr;
-        }
-        have = 0;
-        for (int k = 0; k < 2; ++k) {
-            HIP_OK(hipHostMalloc((void**)&h[k], want * sizeof(float), hipHostMallocDefault));
-            HIP_OK(hipMalloc(&d[k], want * sizeof(float)));
+            h[k] = nh[k]; d[k] = nd[k];
         }
         have = want;
         return kOk;
@@ -2009,12 +2020,15 @@ int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* 
         for (auto& th : pool) th.join();
     };
     int result = kOk;
-    size_t issued = 0;
+    size_t issued = 0, scattered = 0;
+    // a failing HIP call ends the loop; the tail below drains both streams, releases what was deferred and reports the code —
+    // `out` then holds the sets scattered so far (whole launch sets, in order), nothing is left in flight
+#define HOST_TRY(call) { if ((call) != hipSuccess) { std::fprintf(stderr, "[elemhip] %s failed: %s\n", #call, hipGetErrorString(hipGetLastError())); result = kHipError; break; } }
     for (size_t k = 0; k < numSets; ++k) {
         const size_t b0 = k * setBlocks, nb = std::min(setBlocks, numBlocks - b0);
         const int half = (int)(k & 1);
         if (nIn) {
-            if (k >= 2) HIP_OK(hipEventSynchronize(evIn[half]));     // the H2D of set k - 2 has left this pinned half
+            if (k >= 2) HOST_TRY(hipEventSynchronize(evIn[half]));     // the H2D of set k - 2 has left this pinned half
             float* dst = hStageIn[half];
             for (size_t b = 0; b < nb; ++b) {
                 const size_t f0 = (b0 + b) * bs;
@@ -2032,35 +2046,37 @@ int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* 
             if (nIn) {
                 // (the copy stream is in order: this H2D runs behind the D2H of set k - 2, which waited for that set's render,
                 //  the last reader of this device half)
-                HIP_OK(hipMemcpyAsync(dStageIn[half], hStageIn[half], nb * nIn * bs * sizeof(float), hipMemcpyHostToDevice, ioStream));
-                HIP_OK(hipEventRecord(evIn[half], ioStream));
-                HIP_OK(hipStreamWaitEvent(stream, evIn[half], 0));
+                HOST_TRY(hipMemcpyAsync(dStageIn[half], hStageIn[half], nb * nIn * bs * sizeof(float), hipMemcpyHostToDevice, ioStream));
+                HOST_TRY(hipEventRecord(evIn[half], ioStream));
+                HOST_TRY(hipStreamWaitEvent(stream, evIn[half], 0));
             }
-            if (k >= 2) HIP_OK(hipStreamWaitEvent(stream, evOut[half], 0));   // the D2H of set k - 2 has drained this device half
+            if (k >= 2) HOST_TRY(hipStreamWaitEvent(stream, evOut[half], 0));   // the D2H of set k - 2 has drained this device half
             int rc = enqueueBlocks(nIn ? dStageIn[half] : nullptr, nIn, nOut ? dStageOut[half] : nullptr, nOut, nb,
                                    sampleTime + (int64_t)(b0 * bs));
             if (rc != kOk) { result = rc; break; }
-            HIP_OK(hipEventRecord(evRendered[half], stream));
-            HIP_OK(hipStreamWaitEvent(ioStream, evRendered[half], 0));
-            if (nOut) HIP_OK(hipMemcpyAsync(hStageOut[half], dStageOut[half], nb * nOut * bs * sizeof(float), hipMemcpyDeviceToHost, ioStream));
-            HIP_OK(hipEventRecord(evOut[half], ioStream));
+            HOST_TRY(hipEventRecord(evRendered[half], stream));
+            HOST_TRY(hipStreamWaitEvent(ioStream, evRendered[half], 0));
+            if (nOut) HOST_TRY(hipMemcpyAsync(hStageOut[half], dStageOut[half], nb * nOut * bs * sizeof(float), hipMemcpyDeviceToHost, ioStream));
+            HOST_TRY(hipEventRecord(evOut[half], ioStream));
             issued = k + 1;
         }
         if (k >= 1) {   // set k - 1 arrives while set k renders
-            HIP_OK(hipEventSynchronize(evOut[(k - 1) & 1]));
+            HOST_TRY(hipEventSynchronize(evOut[(k - 1) & 1]));
             if (nOut) scatter(k - 1);
+            scattered = k;
         }
     }
-    if (issued) {
+#undef HOST_TRY
+    if (issued > scattered && result == kOk) {       // the last set (every earlier one was scattered while its successor rendered)
         const size_t last = issued - 1;
-        if (hipEventSynchronize(evOut[last & 1]) != hipSuccess) return kHipError;
-        if (nOut && result == kOk) scatter(last);
+        if (hipEventSynchronize(evOut[last & 1]) != hipSuccess) result = kHipError;
+        else if (nOut) scatter(last);
     }
     {
         std::lock_guard<std::mutex> lock(mu);
-        HIP_OK(hipStreamSynchronize(stream));
-        HIP_OK(hipStreamSynchronize(ioStream));
-        HIP_OK(hipGetLastError());
+        if (hipStreamSynchronize(stream) != hipSuccess) result = result == kOk ? kHipError : result;
+        if (hipStreamSynchronize(ioStream) != hipSuccess) result = result == kOk ? kHipError : result;
+        if (hipGetLastError() != hipSuccess && result == kOk) result = kHipError;
         if (profUsed) profCollect();
         freeDeferred();
     }

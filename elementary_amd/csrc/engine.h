@@ -233,6 +233,7 @@ private:
     float* hOutDev = nullptr;                          // hOut as the device sees it (mapped)
     float* hIn = nullptr; size_t hInFloats = 0;       // pinned
     std::vector<void*> deferredFree;
+    std::vector<std::shared_ptr<Plan>> retiredPlans;   // replaced plans whose launches may still be in flight; released by freeDeferred()
 
     // host-buffer launch sets (processBlocksHost): copy stream, pinned + device staging halves, hand-over events
     hipStream_t ioStream = nullptr;

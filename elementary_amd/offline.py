@@ -57,9 +57,11 @@ class OfflineRenderer:
         bs = self.block_size
         total = len(outputs[0])
         host_batch = getattr(self._rt, "process_blocks_host", None)
-        if host_batch is not None and not self._listeners and total > bs:
+        if host_batch is not None and not any(self._listeners.values()) and total > bs:
             # no event listeners to serve between blocks: the whole block loop in one engine call
-            # (elemhip_process_blocks_host: launch sets staged through pinned double buffers)
+            # (elemhip_process_blocks_host: launch sets staged through pinned double buffers); the event queues are drained
+            # once afterwards, as the per-block loop's relay (index.ts:118-122) would have kept them drained — a listener
+            # attached later must not find a capture / scope ring that overran during this render
             x = None
             if self.num_in:
                 x = np.zeros((self.num_in, total), dtype=np.float32)
@@ -68,6 +70,7 @@ class OfflineRenderer:
                     x[i, :len(seg)] = seg
             y = host_batch(x, self.num_out, total, sample_time=self._time)
             self._time += ((total + bs - 1) // bs) * bs
+            self._rt.process_queued_events()
             for i, buf in enumerate(outputs):
                 m = min(total, len(buf))
                 buf[:m] = y[i, :m]

@@ -20,10 +20,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(extra):
+def _launch(extra, ranks=2):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ELEMHIP_SPECIALIZE="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--shared-gpu",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--shared-gpu",
            "--no-cpu-baseline"] + extra
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
@@ -47,3 +47,22 @@ def test_two_ranks_one_gpu_c4_gather(gpu_required):
     assert out["n_gpus"] == 2 and out["config"]["instances_total"] == 12
     assert "gather" in out["config"]["collectives"]
     assert out["value"] > 0
+
+
+def test_eight_ranks_one_gpu_both_workloads(gpu_required):
+    """The rank count the driver launches (8), on the hardware there is (one GPU, gloo): eight engines with their own streams,
+    pinned buffers and kernel caches side by side, the bus reduce / the output gather across eight ranks, the line's
+    `ranks_seen` = what the process group reports. No 1 -> 8 GPU curve exists: this checks the code path, not scaling."""
+    out = _launch(["--steps", "2", "--warmup", "1", "--batch-blocks", "32", "--voices", "8", "--steps-per-call", "1", "--check"], ranks=8)
+    assert out["n_gpus"] == 8 and out["config"]["ranks_seen"] == 8 and out["config"]["voices_total"] == 64
+    assert out["parity"]["ok"], out["parity"]
+    out = _launch(["--workload", "c4", "--instances", "3", "--steps", "2", "--warmup", "1", "--batch-blocks", "16"], ranks=8)
+    assert out["n_gpus"] == 8 and out["config"]["ranks_seen"] == 8 and out["config"]["instances_total"] == 24
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """`--gpus N` with a process group of another size prints no line (the driver computes scaling from n_gpus)."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=120, cwd=ROOT, env=env)
+    assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
