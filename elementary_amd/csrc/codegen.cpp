@@ -129,7 +129,8 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
     o << "struct P {\n    static constexpr uint32_t S = " << S << "u, D = " << I.copies << "u, slotArea = " << I.slotArea << "u, ldsProg = " << I.ldsProg
       << "u, memOff = " << I.memOff << "u, opndOff = " << I.opndOff << "u, cellOff = " << I.cellOff << "u, numCells = " << I.numCells
       << "u, recOff = " << I.recOff << "u, numRecs = " << I.numRecs << "u, progDwords = " << I.progDwords << "u, ldsCounters = " << I.ldsCounters
-      << "u, ldsRecs = " << I.ldsRecs << "u, specOpndOff = " << (I.recOff + I.numRecs + (uint32_t)sp.hbmTab.size()) << "u, lastStage = " << lastStage << "u, lastT = " << stageTab[lastStage] << "u, block = " << blockSize << "u;\n";
+      << "u, ldsRecs = " << I.ldsRecs << "u, specOpndOff = " << (I.recOff + I.numRecs + (uint32_t)sp.hbmTab.size()) << "u, lastStage = " << lastStage << "u, lastT = " << stageTab[lastStage] << "u, block = " << blockSize << "u, split = " << std::max(1u, I.split) << "u;\n";
+    o << "    static constexpr bool stateless = " << (I.stateless ? "true" : "false") << ";\n";
     o << "    static constexpr int waveSlots[8] = {";
     for (uint32_t w = 0; w < kWaves; ++w) o << (w ? ", " : "") << waveSlots[w];
     o << "};\n};\n} // namespace gen\n";

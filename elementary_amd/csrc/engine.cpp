@@ -1786,7 +1786,8 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         // the stream ring sits behind the `batch` block slices of this launch set
         uint32_t bt = batch, af = arenaFloats, sb = batch * arenaFloats, ss = p.numStreamBuffers * (uint32_t)blockSize;
         void* args[] = {&pv, &recs, &hbm, &g, &lcg, &list, &bt, &af, &sb, &ss};
-        HIP_WARN(hipModuleLaunchKernel(f.first, f.second->count, 1, 1, kThreads, 1, 1, 0, st_, args, nullptr));
+        const uint32_t gy = f.second->stateless ? std::max(1u, std::min(batch, statelessRows)) : 1u;
+        HIP_WARN(hipModuleLaunchKernel(f.first, f.second->count, gy, 1, kThreads, 1, 1, 0, st_, args, nullptr));
         st.specLaunches++;
         debugSync("set: specialised shape", f.second->count, batch);
     }

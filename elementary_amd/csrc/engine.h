@@ -367,7 +367,8 @@ struct Plan {
     struct SpecShape {
         std::shared_ptr<SpecEntry> entry;
         uint32_t level = 0;
-        uint32_t listBegin = 0, count = 0;     // its islands: specLists[listBegin, listBegin + count)
+        uint32_t listBegin = 0, count = 0;     // its workgroups: specLists[listBegin, listBegin + count) (island | split part << 24)
+        bool stateless = false;                // no block pipeline: the launch spreads the blocks of a set over gridDim.y
     };
     std::vector<SpecShape> shapes;
     std::vector<uint32_t> specLists;           // island indices, shape-major

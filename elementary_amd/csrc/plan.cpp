@@ -1252,7 +1252,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         // instruction), outputs leave as lane-0 global stores. The interpreter program above is left as it is (same LDS
         // layout); the variant only re-routes operands / outputs and names the arena buffers it needs extra.
         SpecProgram sp;
-        const bool specIsland = wantSpec && !statelessIsland && bs % 64u == 0u;   // (vector loads of a 64-frame unit must stay inside their arena buffer)
+        // (stateless islands too — mixers, root gains: their specialised kernel has no block pipeline, blocks go over gridDim.y)
+        const bool specIsland = wantSpec && bs % 64u == 0u;   // (vector loads of a 64-frame unit must stay inside their arena buffer)
         if (specIsland) {
             sp.members = members; sp.operands = operands;
             sp.gdirect.assign(tasks.size(), 0);
@@ -1391,7 +1392,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         I.ldsRecs = (I.ldsNext + S * kWaves + 3u) & ~3u;
         I.ldsWords = (I.ldsRecs + I.numRecs * kRecDwords + 3u) & ~3u;
         p.maxLdsBytes = std::max(p.maxLdsBytes, I.ldsWords * 4u);
-        if (specIsland && I.split == 1u) {
+        if (specIsland && (I.split == 1u || statelessIsland)) {
             if (p.specText.size() < ib.size()) p.specText.resize(ib.size());
             // signature of everything the text is a function of (arena indices by their position in the island's arena table)
             uint64_t h = 1469598103934665603ull;
@@ -1546,8 +1547,11 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
                 if (specialize == 1 && kv.second.size() < 2 && !Jit::get().knownKey(tx.key)) continue;
                 Plan::SpecShape sh;
                 sh.entry = Jit::get().requestKey(tx.key, tx.text, ldsW);
-                sh.level = (uint32_t)l; sh.listBegin = (uint32_t)p.specLists.size(); sh.count = (uint32_t)kv.second.size();
-                for (uint32_t isl : kv.second) { p.specLists.push_back(isl); covered[isl] = 1; }
+                sh.level = (uint32_t)l; sh.listBegin = (uint32_t)p.specLists.size();
+                sh.stateless = p.islands[kv.second[0]].stateless != 0u;
+                // (levelIslands entry format: island | split part << 24 — a split island is one workgroup per part)
+                for (uint32_t isl : kv.second) { for (uint32_t k = 0; k < std::max(1u, p.islands[isl].split); ++k) p.specLists.push_back(isl | (k << 24)); covered[isl] = 1; }
+                sh.count = (uint32_t)p.specLists.size() - sh.listBegin;
                 p.shapes.push_back(std::move(sh));
             }
             for (uint32_t q = p.levelOffsets[l]; q < p.levelOffsets[l + 1]; ++q)
