@@ -131,6 +131,38 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
       << "u, recOff = " << I.recOff << "u, numRecs = " << I.numRecs << "u, progDwords = " << I.progDwords << "u, ldsCounters = " << I.ldsCounters
       << "u, ldsRecs = " << I.ldsRecs << "u, specOpndOff = " << (I.recOff + I.numRecs + (uint32_t)sp.hbmTab.size()) << "u, lastStage = " << lastStage << "u, lastT = " << stageTab[lastStage] << "u, block = " << blockSize << "u, split = " << std::max(1u, I.split) << "u;\n";
     o << "    static constexpr bool stateless = " << (I.stateless ? "true" : "false") << ";\n";
+    // A stateless island whose eight waves run the SAME tasks of every stage on consecutive frame runs (a mixer: 64-frame runs of one
+    // 128-input fold) gets ONE copy of each task body, the wave's frame offset a run-time value: eight per-wave instantiations of a
+    // 128-child fold were 70 KB of straight-line code that a single-block launch executes once, from a cold instruction cache
+    // (37 us for the mixer level of a synchronous process() call against 18 us through the interpreter kernel).
+    bool uniform = I.stateless != 0u;
+    std::vector<std::vector<uint32_t>> perStage(S);          // wave 0's tasks per stage
+    uint32_t runLen = 0;
+    if (uniform) {
+        for (uint32_t w = 0; w < kWaves && uniform; ++w) {
+            std::vector<std::vector<uint32_t>> mine(S);
+            for (uint32_t q = I.waveTask[w]; q < I.waveTask[w + 1]; ++q) mine[tasks[q].stage].push_back(q);
+            if (w == 0) { perStage = mine; for (auto& v : mine) for (uint32_t q : v) { const uint32_t len = (uint32_t)tasks[q].s1 - tasks[q].s0; if (!runLen) runLen = len; if (len != runLen || tasks[q].s0 != 0) uniform = false; } continue; }
+            for (uint32_t st = 0; st < S && uniform; ++st) {
+                if (mine[st].size() != perStage[st].size()) { uniform = false; break; }
+                for (size_t k = 0; k < mine[st].size(); ++k) {
+                    const Task& a = tasks[perStage[st][k]]; const Task& b = tasks[mine[st][k]];
+                    if (a.opcode != b.opcode || a.first != b.first || a.count != b.count || (a.flags & 0x3Fu) != (b.flags & 0x3Fu) ||
+                        (uint32_t)b.s0 != w * runLen || (uint32_t)b.s1 != (w + 1u) * runLen) uniform = false;
+                }
+            }
+        }
+        if (!runLen) uniform = false;
+    }
+    o << "    static constexpr bool uniform = " << (uniform ? "true" : "false") << ";\n";
+    o << "    template <int STAGE> static __device__ __forceinline__ void ustage(const Ctx& c, uint32_t wave) {\n";
+    if (uniform)
+        for (uint32_t st = 0; st < S; ++st) {
+            o << "        if constexpr (STAGE == " << st << ") {\n";
+            for (uint32_t q : perStage[st]) o << "            spec_task_at<T" << q << ">(c, wave * " << runLen << "u);\n";
+            o << "        }\n";
+        }
+    o << "    }\n";
     o << "    static constexpr int waveSlots[8] = {";
     for (uint32_t w = 0; w < kWaves; ++w) o << (w ? ", " : "") << waveSlots[w];
     o << "};\n};\n} // namespace gen\n";

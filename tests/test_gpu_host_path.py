@@ -85,7 +85,7 @@ def test_bench_geometry_full_c4(gpu_required):
     wi, wb = np.unravel_index(int(err.argmax()), err.shape)
     assert float(err.max()) <= TOL * max(1.0, float(np.abs(ref).max())), f"instance {wi} block {wb}: {err.max():.3e}"
     # every instance produced its own stream (a scatter that mixed channels up would pass a max-error test on silence only)
-    assert len({got[k, 5000:5064].tobytes() for k in range(inst)}) == inst
+    assert len({got[k, -4096:].tobytes() for k in range(inst)}) == inst
 
 
 def test_commit_and_gc_from_another_thread_during_a_host_render(gpu_required):

@@ -1,7 +1,7 @@
 """A feedback loop through a tap (lowpass + 300-frame delay inside the loop, 8 such loops under two roots) rendered by
 elemhip_process_blocks: block-at-a-time (batch_blocks = 1: what every plan with a tapOut got before taps could be rendered
-inside launch sets) vs 64- and 256-block launch sets through the interpreter kernel and — with ELEMHIP_EXP_SPEC_TAPS=1 in the environment, an
-experiment that is not shipped (plan.cpp) — the run-time specialised one (without the variable those rows repeat the interpreter's). Usage: python tools/tap_loop_bench.py [blocks]"""
+inside launch sets) vs 64-block launch sets through the interpreter kernel vs 64- / 256-block sets through the run-time specialised
+kernels (r04: tap islands have them; the hand-over stays in the tapOut's LDS slot). Usage: python tools/tap_loop_bench.py [blocks]"""
 import os as _os, sys as _sys; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))); _sys.path[:0] = [_R, _os.path.join(_R, 'tests')]
 import json
 import sys
