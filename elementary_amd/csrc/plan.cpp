@@ -1533,17 +1533,27 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
         p.restOffsets.assign(L + 1, 0);
         std::vector<uint8_t> covered(p.islands.size(), 0);
         for (size_t l = 0; l < L; ++l) {
-            std::map<SpecText*, std::vector<uint32_t>> byText;   // identical text = the same cached object (alive: p.specText holds it)
+            // one shape per kernel: islands are grouped by the cache key of their text (two cached text objects can carry the same
+            // text — the text cache is keyed by a signature that also covers what the text leaves out); a split island appears
+            // once per part in levelIslands and once here
+            std::map<std::string, std::pair<SpecText*, std::vector<uint32_t>>> byText;
+            std::vector<uint8_t> seen(p.islands.size(), 0);
             for (uint32_t q = p.levelOffsets[l]; q < p.levelOffsets[l + 1]; ++q) {
                 const uint32_t isl = p.levelIslands[q] & 0xFFFFFFu;
-                if (isl < p.specText.size() && p.specText[isl] && !covered[isl]) byText[p.specText[isl].get()].push_back(isl);
+                if (!(isl < p.specText.size() && p.specText[isl]) || covered[isl] || seen[isl]) continue;
+                seen[isl] = 1;
+                SpecText& tx = *p.specText[isl];
+                const uint32_t ldsW = p.islands[isl].ldsWords;
+                if (tx.key.empty() || tx.keyLdsWords != ldsW) { tx.key = Jit::get().keyFor(tx.text, ldsW); tx.keyLdsWords = ldsW; }
+                auto& slot = byText[tx.key];
+                slot.first = &tx; slot.second.push_back(isl);
             }
-            for (auto& kv : byText) {
+            for (auto& kvk : byText) {
+                auto& kv = kvk.second;
                 // background mode: a shape only one island has (a voice that is fading out next to its replacement, a
                 // one-off graph) is not worth a compile of its own: it renders through the interpreter kernel
                 const uint32_t ldsW = p.islands[kv.second[0]].ldsWords;
                 SpecText& tx = *kv.first;
-                if (tx.key.empty() || tx.keyLdsWords != ldsW) { tx.key = Jit::get().keyFor(tx.text, ldsW); tx.keyLdsWords = ldsW; }
                 if (specialize == 1 && kv.second.size() < 2 && !Jit::get().knownKey(tx.key)) continue;
                 Plan::SpecShape sh;
                 sh.entry = Jit::get().requestKey(tx.key, tx.text, ldsW);

@@ -16,25 +16,29 @@ import torch
 from elementary_amd import graphs
 from elementary_amd.runtime import Runtime
 import oracle
-from cases import NODE_CASES, REF_ONLY, node_case_resources
 from helpers import lcg_noise
 
 assert os.environ.get("ELEMHIP_SPECIALIZE") == "1" and os.environ.get("ELEMHIP_KCACHE")
-CASES = ["pole", "biquad", "svf_modulated", "delay_long", "adsr", "taps", "pink_noise", "seq", "sample", "compress", "blepsaw", "mc"]
-CASES = [c for c in CASES if c in NODE_CASES and (c not in REF_ONLY or oracle.have_ref())]
+# Background mode compiles a shape only when at least two islands of the plan have it (a one-off island renders through the
+# interpreter kernel for good, plan.cpp), so the cases here are graphs of repeated islands: synth voices + their two mixers,
+# independent render jobs (two shapes), feedback loops through taps (one block in flight).
+CASES = ["c2x16", "c4x8", "eight_loops"]
 
 
 def make(name):
+    n_in = 0
     if name == "c2x16":
-        roots, n_in, sr = graphs.c2_graph(voices=16), 0, graphs.C2_SAMPLE_RATE
+        roots, sr = graphs.c2_graph(voices=16), graphs.C2_SAMPLE_RATE
+    elif name == "c4x8":
+        roots, sr = [graphs.c4_instance(k) for k in range(8)], graphs.C4_SAMPLE_RATE
     else:
-        roots, n_in, sr = NODE_CASES[name][0](), NODE_CASES[name][1], 44100.0
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import tap_soak
+        roots, sr, n_in = tap_soak._bench_graph(), 44100.0, 1
     a = Runtime(sr, 512, device=0)
     c = oracle.RefRuntime(sr, 512) if oracle.have_ref() else oracle.PortRuntime(sr, 512)
     a.set_option("batch_blocks", 6)
     for rt in (a, c):
-        for rname, data in node_case_resources().items():
-            assert rt.add_shared_resource(rname, data)
         assert rt.render(*roots)["result"] == 0          # (background mode: returns at once, the shapes are queued)
     return {"name": name, "a": a, "c": c, "n_in": n_in, "n_out": len(roots), "k": 0, "after": 0, "worst": 0.0, "scale": 1.0, "sets_interp": 0}
 
@@ -63,8 +67,8 @@ def step(e, nb=6):
 
 
 t0 = time.time()
-engines = [make(n) for n in CASES + ["c2x16"]]
-deadline = t0 + float(os.environ.get("PRODUCT_MODE_BUDGET_S", "150"))
+engines = [make(n) for n in CASES]
+deadline = t0 + float(os.environ.get("PRODUCT_MODE_BUDGET_S", "90"))
 while time.time() < deadline and any(e["after"] < 3 for e in engines):
     for e in engines:
         if e["after"] < 3:

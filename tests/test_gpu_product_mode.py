@@ -1,8 +1,8 @@
 """The suite pins ELEMHIP_SPECIALIZE=0 for deterministic kernel choice (tests/conftest.py); the product default is 1: render
 through the interpreter kernels while the island shapes compile in the background, switch kernels mid-stream. This leg runs
-a worker process with the product defaults and a COLD kernel-cache directory (so hiprtc runs on the GPU box): node cases with
-recurrences, delays, taps, samplers and a 16-voice C2 graph, each checked against the reference engine on both sides of the
-switch. Tolerance 1e-6 absolute (x max|ref| when > 1)."""
+a worker process with the product defaults and a COLD kernel-cache directory (so hiprtc runs on the GPU box): a 16-voice C2 graph
+(voices + mixers), 8 C4 render jobs (two shapes) and 8 feedback loops through taps, each checked against the reference engine on
+both sides of the switch. Tolerance 1e-6 absolute (x max|ref| when > 1)."""
 import json
 import os
 import subprocess
@@ -21,7 +21,7 @@ def test_background_compilation_and_mid_stream_kernel_switch(gpu_required):
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "product_mode_worker.py")], capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
         assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
         out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
-    assert out["compiled_here"] >= 5, out                     # hiprtc produced code objects on this machine
+    assert out["compiled_here"] >= 4, out                     # hiprtc produced code objects on this machine
     for row in out["rows"]:
         assert row["spec_shapes"] >= 1 and row["sets_through_specialised"] >= 3, row      # the switch happened ...
         assert row["max_err"] <= 1e-6 * max(1.0, row["scale"]), row                       # ... and no sample moved
