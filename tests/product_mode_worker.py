@@ -22,7 +22,7 @@ assert os.environ.get("ELEMHIP_SPECIALIZE") == "1" and os.environ.get("ELEMHIP_K
 # Background mode compiles a shape only when at least two islands of the plan have it (a one-off island renders through the
 # interpreter kernel for good, plan.cpp), so the cases here are graphs of repeated islands: synth voices + their two mixers,
 # independent render jobs (two shapes), feedback loops through taps (one block in flight).
-CASES = ["c2x16", "c4x8", "eight_loops"]
+CASES = ["c2x16", "c4x8", "four_tap_loops"]
 
 
 def make(name):
@@ -32,9 +32,13 @@ def make(name):
     elif name == "c4x8":
         roots, sr = [graphs.c4_instance(k) for k in range(8)], graphs.C4_SAMPLE_RATE
     else:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import tap_soak
-        roots, sr, n_in = tap_soak._bench_graph(), 44100.0, 1
+        from elementary_amd import el     # four roots, a filtered feedback loop through a tap each: four islands of one shape
+
+        def loop(k, x):
+            fb = el.tapIn({"name": f"rv{k}"})
+            body = el.lowpass(900.0 + 170.0 * k, 0.9, el.add(x, el.mul(0.7, el.sdelay({"size": 200 + 13 * k}, fb))))
+            return el.tanh(el.tapOut({"name": f"rv{k}"}, body))
+        roots, sr, n_in = [loop(k, el.in_({"channel": 0})) for k in range(4)], 44100.0, 1
     a = Runtime(sr, 512, device=0)
     c = oracle.RefRuntime(sr, 512) if oracle.have_ref() else oracle.PortRuntime(sr, 512)
     a.set_option("batch_blocks", 6)
