@@ -20,8 +20,25 @@ def newest(pattern):
     return g[-1] if g else None
 
 
-def key(r):
-    return (r.get("Kernel_Name", "").split("(")[0][:56], r.get("Grid_Size_X") or r.get("Grid_Size") or "?", r.get("Grid_Size_Y") or "1", r.get("Grid_Size_Z") or "1")
+def key_pmc(r):
+    # the counter files carry one Grid_Size = X * Y * Z work-items; the LDS size tells two code objects of one kernel name apart
+    # (every specialised island shape is an `elemhip_spec_island`)
+    return (r.get("Kernel_Name", "").split("(")[0][:56], int(r.get("Grid_Size") or 0), int(r.get("LDS_Block_Size") or 0))
+
+
+def key_trace(r):
+    return (r.get("Kernel_Name", "").split("(")[0][:56], f"{r.get('Grid_Size_X')}x{r.get('Grid_Size_Y') or 1}x{r.get('Grid_Size_Z') or 1}", int(r.get("LDS_Block_Size") or 0))
+
+
+def split(vals):
+    """A kernel that renders launch sets AND single blocks with the same grid (the specialised island kernel: elemhip_process uses
+    it as a set of one): "sets" = the values within 2x of the largest, the rest "single blocks"."""
+    if not vals:
+        return {}
+    big = [x for x in vals if x >= 0.5 * max(vals)]
+    if len(big) == len(vals) or max(vals) <= 0:
+        return {"": vals}
+    return {"sets": big, "single blocks": [x for x in vals if x < 0.5 * max(vals)]}
 
 
 dur = defaultdict(list)
@@ -29,9 +46,15 @@ kt = newest(f"prof_{name}_stats/**/*kernel_trace.csv")
 if kt:
     for r in csv.DictReader(open(kt)):
         try:
-            dur[key(r)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            dur[key_trace(r)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         except Exception:
             pass
+trace_rows = []
+for k, vals in dur.items():
+    for part, v in split(vals).items():
+        trace_rows.append({"kernel": k[0], "grid_work_items": k[1], "lds_bytes": k[2], "part": part, "dispatches": len(v), "mean_us": sum(v) / len(v) / 1e3,
+                           "min_us": min(v) / 1e3, "max_us": max(v) / 1e3, "total_us": sum(v) / 1e3})
+trace_rows.sort(key=lambda r: -r["total_us"])
 ctr = {}
 for c, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     f = newest(f"prof_{name}_{d}/**/*counter_collection.csv")
@@ -39,24 +62,26 @@ for c, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     if f:
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == c:
-                acc[key(r)].append(float(r["Counter_Value"]))
+                acc[key_pmc(r)].append(float(r["Counter_Value"]))
     ctr[c] = acc
-rows = []
-for k in sorted(set(dur) | set(ctr["FETCH_SIZE"]) | set(ctr["WRITE_SIZE"])):
-    v = dur.get(k, [])
-    fe, wr = ctr["FETCH_SIZE"].get(k, []), ctr["WRITE_SIZE"].get(k, [])
-    row = {"kernel": k[0], "grid": [k[1], k[2], k[3]], "dispatches": len(v) or len(fe) or len(wr)}
-    if v:
-        row.update(mean_us=sum(v) / len(v) / 1e3, min_us=min(v) / 1e3, max_us=max(v) / 1e3, total_us=sum(v) / 1e3)
-    if fe:
-        row["fetch_bytes_corrected_x2_mean"] = 2.0 * 1024.0 * sum(fe) / len(fe)
-    if wr:
-        row["write_bytes_mean"] = 1024.0 * sum(wr) / len(wr)
-    if fe and wr:
-        row["hbm_bytes_per_dispatch"] = row["fetch_bytes_corrected_x2_mean"] + row["write_bytes_mean"]
-    rows.append(row)
-rows.sort(key=lambda r: -r.get("total_us", 0.0))
+pmc_rows = []
+for k in sorted(set(ctr["FETCH_SIZE"]) | set(ctr["WRITE_SIZE"])):
+    fs, ws = split(ctr["FETCH_SIZE"].get(k, [])), split(ctr["WRITE_SIZE"].get(k, []))
+    for part in sorted(set(fs) | set(ws)):
+        fe, wr = fs.get(part, []), ws.get(part, [])
+        row = {"kernel": k[0], "grid_work_items_total": k[1], "lds_bytes": k[2], "part": part, "dispatches": len(fe) or len(wr)}
+        if fe:
+            row["fetch_bytes_corrected_x2_mean"] = 2.0 * 1024.0 * sum(fe) / len(fe)
+        if wr:
+            row["write_bytes_mean"] = 1024.0 * sum(wr) / len(wr)
+        if fe and wr:
+            row["hbm_bytes_per_dispatch"] = row["fetch_bytes_corrected_x2_mean"] + row["write_bytes_mean"]
+        pmc_rows.append(row)
+pmc_rows.sort(key=lambda r: -r.get("hbm_bytes_per_dispatch", 0.0) * r["dispatches"])
 json.dump({"command": cmd, "passes": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE (three separate runs), --output-format csv",
-           "hbm_bytes": "2 x FETCH_SIZE (KB) + WRITE_SIZE (KB), per dispatch", "kernels": rows}, open(out, "w"), indent=1)
-for r in rows[:12]:
-    print(f"{r['kernel'][:44]:44s} grid {'x'.join(r['grid']):>14s} n={r['dispatches']:4d} mean {r.get('mean_us', float('nan')):9.1f} us  hbm/dispatch {r.get('hbm_bytes_per_dispatch', float('nan')) / 1e6:9.2f} MB")
+           "hbm_bytes": "2 x FETCH_SIZE (KB) + WRITE_SIZE (KB), per dispatch; the counter files name a dispatch by its TOTAL grid (X * Y * Z work-items)",
+           "kernel_trace": trace_rows, "pmc": pmc_rows}, open(out, "w"), indent=1)
+for r in trace_rows[:12]:
+    print(f"trace {r['kernel'][:34]:34s} lds {r['lds_bytes']:6d} {r['part']:13s} grid {r['grid_work_items']:>16s} n={r['dispatches']:4d} mean {r['mean_us']:9.1f} us")
+for r in pmc_rows[:10]:
+    print(f"pmc   {r['kernel'][:34]:34s} lds {r['lds_bytes']:6d} {r['part']:13s} grid {r['grid_work_items_total']:>10d} n={r['dispatches']:4d} hbm/dispatch {r.get('hbm_bytes_per_dispatch', float('nan')) / 1e6:9.2f} MB (fetch x2 {r.get('fetch_bytes_corrected_x2_mean', float('nan')) / 1e6:8.2f} + write {r.get('write_bytes_mean', float('nan')) / 1e6:8.2f})")
