@@ -1283,6 +1283,7 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "pipeline_copies") { pipelineCopies = std::max(1, std::min(6, (int)value)); planStale = true; return kOk; }   // next commit re-plans
     if (key == "stream_ring") { streamRing = value != 0.0; return kOk; }   // 0: measurement only, needs kernels built with ELEMHIP_STREAM_PER_BLOCK
     if (key == "pack_islands") { packIslands = std::max(0, std::min(16, (int)value)); planStale = true; return kOk; }   // next commit re-plans
+    if (key == "pack_roots") { packRoots = value != 0; planStale = true; return kOk; }   // islands of different active roots may share a workgroup (C4: a root per render job)
     if (key == "pack_max") { packMax = std::max(1, std::min(16, (int)value)); planStale = true; return kOk; }
     if (key == "cu_count") { cuCount = std::max(1, (int)value); planStale = true; return kOk; }      // (dry handles / tests: the CU count the auto mode plans for)
     if (key == "chain_lds_out") { chainLdsOut = value != 0.0; planStale = true; return kOk; }
@@ -1481,6 +1482,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     if (rc != kOk) return rc;
     if (!current) return kOk;   // no render sequence yet: outputs untouched (Runtime.h:287-289)
     const Plan& p = *current;
+    if (p.packedRootChannels > 0 && nOut < (size_t)p.packedRootChannels) return kInvalidPropertyValue;   // (`pack_roots`, plan.cpp)
 
     if (hGlobals.ringSlots != 1 || hGlobals.blockSlot != 0) {
         hGlobals.ringSlots = 1; hGlobals.blockSlot = 0;
@@ -1853,6 +1855,10 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
     if (rc != kOk) return rc;
     if (!current || numBlocks == 0) return kOk;
     Plan& p = *current;
+    if (p.packedRootChannels > 0 && nOut < (size_t)p.packedRootChannels) {      // (plan.cpp `pack_roots`: a packed root would not run in the reference)
+        std::fprintf(stderr, "[elemhip] pack_roots: this plan needs calls with at least %d output channels\n", p.packedRootChannels);
+        return kInvalidPropertyValue;
+    }
     const size_t bs = (size_t)blockSize;
     const bool graphOk = useGraph && p.hosts.empty() && !debugSyncOn();   // call-out nodes synchronise inside a block: nothing to capture
     const bool haveIn = nIn > 0 && inDev != nullptr;

@@ -263,6 +263,7 @@ private:
     bool streamRing = true;                // stream buffers of the specialised kernels live in a ring of `copies` slices (0: one slice per block; measurement)
     int  packIslands = 0;                  // option "pack_islands": same-shape islands merged into one workgroup (0 auto: when a launch level has more
                                            // stateful islands than the device has CUs; 1 never; K: K per island)
+    bool packRoots = false;                // option "pack_roots": lane-packing may merge islands of different ACTIVE roots (render jobs with a root each)
     int  packMax = 2, cuCount = 256;       // auto mode: at most packMax per island (measured on C2: 2 per island pays, 3 leaves two buffer sets and loses); CUs of the device
     bool chainLdsOut = false;              // option "chain_lds_out" (experiment): streamed recurrences write their block to LDS, only their operands come through the arena
     bool mergePhases = true;               // option "merge_phases": constant-frequency phasors and oscillator phases of a stage share one recurrence task (OP_PHASE)
@@ -337,6 +338,7 @@ struct Plan {
     uint32_t numTasks = 0, numMembers = 0, numOperands = 0;
     std::vector<RootEntry> roots;
     std::vector<TapEntry> taps;
+    int packedRootChannels = 0;                              // > 0: islands of different roots share workgroups; a call must ask for at least this many outputs
     bool tapsInSets = true;                                  // every tapIn / tapOut pair sits in one island: launch sets may render this plan (plan.cpp)
     std::vector<std::pair<int32_t, int32_t>> tapPairs;       // (tapIn node id, id of the in-island tapOut whose private buffer it reads inside a launch set, or 0)
     std::vector<std::pair<int32_t, int32_t>> eventNodes;   // (node id, owning root id) of meter / snapshot nodes, render order

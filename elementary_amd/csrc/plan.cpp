@@ -184,6 +184,7 @@ struct PlanBuilder {
     bool wantSpec = false;                  // also write the specialised-kernel text of every pipelined island
     uint32_t packK = 1;                     // merge up to this many same-shape islands of a launch level into one (lane-packing); 0 = as many as it takes
     uint32_t packMax = 2, cuCount = 256;    // ... to bring the fullest launch level down to the CU count, at most packMax
+    bool packRoots = false;                 // option "pack_roots": merge across root sequences (active roots only)
     uint32_t packedIslands = 0;             // out: islands that disappeared into another
     uint32_t minPackedCopies = 0;           // out: fewest buffer sets of an island that carries more than one original island
     uint32_t statefulIslandsMax = 0;        // out: most stateful islands of one launch level (before packing)
@@ -451,6 +452,16 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     if (packK > 1) {
         struct Key { int level, seq; uint64_t shape; bool operator<(const Key& o) const { return level != o.level ? level < o.level : seq != o.seq ? seq < o.seq : shape < o.shape; } };
         std::map<Key, std::vector<int>> groups;
+        // `pack_roots` (opt-in): islands of DIFFERENT root sequences may share a workgroup when every one of those roots is active
+        // at plan time — an active root keeps running until the next commit (a change of root targets always arrives with one), so
+        // "renders while ITS root runs" (GraphRenderSequence.h:214-219) is the same fact for all members. The other half of that
+        // test, root channel < the caller's output count, is a per-call fact: the engine refuses a call that asks for fewer outputs
+        // than the packed roots' channels need (Plan::packedRootChannels).
+        std::vector<char> seqActive(seqRoots.size(), 0);
+        for (size_t sq = 0; sq < seqRoots.size(); ++sq) {
+            auto a = seqRoots[sq]->props.find("active");
+            seqActive[sq] = (a != seqRoots[sq]->props.end() && a->second.isBool() && a->second.b && seqRoots[sq]->channel >= 0) ? 1 : 0;
+        }
         for (size_t i = 0; i < ib.size(); ++i) {
             bool stateful = false, sealed = false;
             uint64_t h = 1469598103934665603ull;
@@ -461,7 +472,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 h ^= (uint64_t)x.n->op | ((uint64_t)x.n->inlets.size() << 16); h *= 1099511628211ull;
             }
             if (sealed || !stateful) continue;
-            groups[Key{ib[i].level, ib[i].seq, h}].push_back((int)i);
+            groups[Key{ib[i].level, (packRoots && seqActive[(size_t)ib[i].seq]) ? -1 : ib[i].seq, h}].push_back((int)i);
         }
         std::vector<int> mergedInto(ib.size(), -1);
         for (auto& kv : groups) {
@@ -476,6 +487,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                     mergedInto[from] = head;
                     packCount[head] += 1u;
                     ++packedIslands;
+                    if (ib[from].seq != ib[head].seq)
+                        p.packedRootChannels = std::max(p.packedRootChannels, 1 + std::max(seqRoots[(size_t)ib[from].seq]->channel, seqRoots[(size_t)ib[head].seq]->channel));
                 }
                 std::sort(ib[head].nodes.begin(), ib[head].nodes.end());          // NI indices are render-order positions
             }
@@ -1497,7 +1510,7 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
             PlanBuilder b(*this);
             // a dry handle (no device) only generates / compiles kernels when asked to wait for them (cache warming, tests)
             b.wantSpec = specialize != 0 && (!dry || specialize >= 2);
-            b.packK = packK; b.packMax = (uint32_t)std::max(1, packMax); b.cuCount = (uint32_t)std::max(1, cuCount);
+            b.packK = packK; b.packMax = (uint32_t)std::max(1, packMax); b.cuCount = (uint32_t)std::max(1, cuCount); b.packRoots = packRoots;
             plan = b.build(limit, (uint32_t)std::max(1, pipelineCopies));
             if (!plan) return nullptr;
             usedK = b.packK; minCopies = b.minPackedCopies;

@@ -100,3 +100,35 @@ def test_render_jobs_with_a_root_each_are_not_packed(gpu_required):
     got = _planar(a, 10, 40)
     ref = np.concatenate([c.process(None, 10, 512) for _ in range(40)], axis=1)
     assert float(np.abs(got - ref).max()) <= TOL
+
+
+@pytest.mark.parametrize("spec", [0, 2])
+@pytest.mark.parametrize("k", [2, 4])
+def test_render_jobs_packed_across_roots(gpu_required, spec, k):
+    """`pack_roots` = 1 (opt-in): islands of DIFFERENT root sequences share a workgroup when all of those roots are active at plan
+    time — 12 C4 render jobs, a root each, K per island. Bit-identical to the unpacked engine, within 1e-6 of the reference; a job
+    whose root is switched off is re-planned (the commit that changes the targets) and rendered like the reference; a call that
+    asks for fewer outputs than the packed roots' channels is refused."""
+    a = _hip(graphs.C4_SAMPLE_RATE, specialize=spec, batch_blocks=16, pack_islands=k, pack_roots=1)
+    b = _hip(graphs.C4_SAMPLE_RATE, specialize=spec, batch_blocks=16, pack_islands=1)
+    c = _checker(graphs.C4_SAMPLE_RATE, 512)
+    roots = [graphs.c4_instance(i) for i in range(12)]
+    for rt in (a, b, c):
+        assert rt.render(*roots)["result"] == 0
+    pa = a.describe_plan()
+    assert pa["pack_k"] == k and pa["level_sizes"][0] == 2 * -(-6 // k), pa["level_sizes"]      # two shapes (odd / even jobs) of 6 islands each
+    got, ref_hip = _planar(a, 12, 60), _planar(b, 12, 60)
+    assert np.array_equal(got, ref_hip)
+    ref = np.concatenate([c.process(None, 12, 512) for _ in range(60)], axis=1)
+    assert float(np.abs(got - ref).max()) <= TOL
+    if spec:
+        assert a.stats()["spec_launches"] > 0
+    with pytest.raises(Exception):
+        a.process_blocks_host(None, 5, 4 * 512)          # fewer outputs than the packed roots' channels
+    # jobs 3 and 8 end: their roots fade out in the new plan (not packed with anyone), the rest stay packed
+    sil = [graphs.c4_instance(i) if i not in (3, 8) else 0.0 for i in range(12)]
+    for rt in (a, c):
+        assert rt.render(*sil)["result"] == 0
+    got2 = _planar(a, 12, 40)
+    ref2 = np.concatenate([c.process(None, 12, 512) for _ in range(40)], axis=1)
+    assert float(np.abs(got2 - ref2).max()) <= TOL
