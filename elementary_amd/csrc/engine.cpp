@@ -1476,7 +1476,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     if (dry) return kNoDevice;
     if (hipSetDevice(device) != hipSuccess) return kHipError;
     if (n > (size_t)blockSize) return kBlockTooLarge;
-    if (nIn > kMaxHostIn || nOut > kMaxOut) return kTooManyChannels;
+    if (nIn > kMaxHostIn || nOut > kMaxOutBus) return kTooManyChannels;
     if (n != conv::kBlock) convAligned = false;   // a convolver's input block may now be partly filled at a call boundary
     int rc = swapInPending();
     if (rc != kOk) return rc;
@@ -1850,7 +1850,7 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
 
 // `mu` held, device current. Everything is enqueued on `stream`; the caller synchronises.
 int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime) {
-    if (nIn > kMaxHostIn || nOut > kMaxOut) return kTooManyChannels;
+    if (nIn > kMaxHostIn || nOut > kMaxOutBus) return kTooManyChannels;
     int rc = swapInPending();
     if (rc != kOk) return rc;
     if (!current || numBlocks == 0) return kOk;
@@ -1989,7 +1989,7 @@ int Engine::ensureHostStaging(size_t outFloats, size_t inFloats) {
 // k + 1 renders. The render lock is taken per set: a commit on another thread lands between two sets (block boundary).
 int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t numFrames, int64_t sampleTime) {
     if (dry) return kNoDevice;
-    if (nIn > kMaxHostIn || nOut > kMaxOut) return kTooManyChannels;
+    if (nIn > kMaxHostIn || nOut > kMaxOutBus) return kTooManyChannels;
     if ((nIn && !in) || (nOut && !out)) return kInvalidInstructionFormat;
     const size_t bs = (size_t)blockSize;
     const size_t numBlocks = (numFrames + bs - 1) / bs;

@@ -5,6 +5,10 @@
 
 namespace elemhip {
 
+// Output bus channels per process call (the epilogue kernels' thread-per-channel tables; device.h's kMaxOut = 256 was the r01-r03
+// limit and is still what the JIT-compiled island kernels see — they never look at it)
+constexpr uint32_t kMaxOutBus = 1024;
+
 hipError_t configure_kernels(uint32_t maxLdsBytes);
 void launch_level(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, const uint32_t* lcg,
                   uint32_t levelBegin, uint32_t numIslands, uint32_t ldsBytes, uint32_t batch = 1, uint32_t arenaFloats = 0,
