@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX: C4 render jobs (a root each) at 256 / 512 / 1024 jobs per GPU, one job per workgroup (rounds of 256) vs
 # lane-packed across roots (`pack_roots` = 1, K = ceil(jobs / CUs) up to 4). Each line carries the bench's own parity check.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; out=$PWD/gpurun_out/${1:-r4q}; mkdir -p $out
-run() { tag=$1; shift; timeout 200 python bench.py --workload c4 --no-cpu-baseline --steps 6 --warmup 2 --batch-blocks 64 "$@" < /dev/null > $out/$tag.json 2> $out/$tag.err
+run() { tag=$1; shift; timeout 200 python bench.py --workload c4 --no-cpu-baseline --steps 6 --warmup 2 --batch-blocks 128 --device-resident "$@" < /dev/null > $out/$tag.json 2> $out/$tag.err
   timeout 20 python - $out/$tag.json $tag <<'PY' | tee -a $out/summary.txt
 import json,sys
 try:
