@@ -38,8 +38,10 @@ def main():
     shapes = bad = 0
     jobs = []
     if what in ("bench", "all"):
-        jobs.append(("c2", graphs.C2_SAMPLE_RATE, 512, graphs.c2_graph(voices=8), None, None))
-        jobs.append(("c4", graphs.C4_SAMPLE_RATE, 512, [graphs.c4_instance(k) for k in range(8)], None, None))
+        # the graphs bench.py renders, at full size: the 128-input mixers of the 256-voice graph are a shape of their own
+        jobs.append(("c2", graphs.C2_SAMPLE_RATE, 512, graphs.c2_graph(), None, None))
+        jobs.append(("c2x8", graphs.C2_SAMPLE_RATE, 512, graphs.c2_graph(voices=8), None, None))       # __graft_entry__.smoke()
+        jobs.append(("c4", graphs.C4_SAMPLE_RATE, 512, [graphs.c4_instance(k) for k in range(128)], None, None))
         jobs.append(("c1", graphs.C1_SAMPLE_RATE, 512, graphs.c1_graph(), None, None))
     if what in ("tests", "all"):
         from cases import NODE_CASES, node_case_resources
