@@ -89,6 +89,7 @@ static double msToStep(double sr, double ms) {   // helpers/GainFade.h:10-12
 
 Plan::~Plan() {
     if (graphExec) (void)hipGraphExecDestroy(graphExec);
+    if (specGraphExec) (void)hipGraphExecDestroy(specGraphExec);
     if (dev.ptr) (void)hipFree(dev.ptr);
 }
 
@@ -202,7 +203,13 @@ void Engine::setStream(hipStream_t s) {
     if (stream) (void)hipStreamSynchronize(stream);
     if (ownStream && stream) (void)hipStreamDestroy(stream);
     stream = s; ownStream = false;
-    if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
+    dropGraphs();
+}
+
+void Engine::dropGraphs() {
+    if (!current) return;
+    if (current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
+    if (current->specGraphExec) { (void)hipGraphExecDestroy(current->specGraphExec); current->specGraphExec = nullptr; }
 }
 
 void Engine::freeDeferred() {   // called right after a synchronize of every stream the engine renders on (`mu` held)
@@ -222,7 +229,7 @@ int Engine::ensureHbm(size_t buffers) {
     HIP_OK(hipMemsetAsync(nb, 0, floats * sizeof(float), stream));   // ordered with the kernels: they run on `stream` (non-blocking w.r.t. the null stream)
     if (dHbm) deferredFree.push_back(dHbm);
     dHbm = nb; hbmBuffers = want;
-    if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
+    dropGraphs();
     return kOk;
 }
 
@@ -247,7 +254,7 @@ int Engine::ensureOutRing(size_t floats) {
     HIP_OK(hipMemsetAsync(nb, 0, floats * sizeof(float), stream));
     if (dOutRing) deferredFree.push_back(dOutRing);
     dOutRing = nb; outRingFloats = floats;
-    if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
+    dropGraphs();
     return kOk;
 }
 
@@ -1272,6 +1279,7 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
     if (key == "host_out_direct") { hostOutDirect = value != 0; return kOk; }   // elemhip_process: epilogue writes the pinned host block itself
     if (key == "conv_mfma") { convMfma = std::max(0, std::min(2, (int)value)); return kOk; }   // partition MAC of launch sets: 1 matrix cores (default), 0 packed vector FMAs
+    if (key == "spec_block_graph") { specBlockGraph = value != 0; dropGraphs(); return kOk; }   // elemhip_process: replay the launch set of one from a hipGraph
     if (key == "spec_blocks") { specBlocks = value != 0; return kOk; }      // elemhip_process through the specialised kernels when it can
     if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(1024, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
     if (key == "debug_build_delay_ms") { debugBuildDelayMs = std::max(0, (int)value); return kOk; }   // tests: stretches the unlocked part of a plan build
@@ -1295,7 +1303,7 @@ int Engine::setOption(const std::string& key, double value) {
         return kOk;
     }
     if (key == "time_batch") { timeBatch = std::max(1, std::min(256, (int)value)); return kOk; }
-    if (key == "graph_blocks") { graphBlocks = std::max(1, (int)value); if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; } return kOk; }
+    if (key == "graph_blocks") { graphBlocks = std::max(1, (int)value); dropGraphs(); return kOk; }
     return kInvalidPropertyValue;
 }
 
@@ -1312,7 +1320,7 @@ int Engine::flushPending() {
         HIP_OK(hipStreamSynchronize(stream));
         (void)hipFree(dRecs);
         dRecs = nr; recCapacity = cap;
-        if (current && current->graphExec) { (void)hipGraphExecDestroy(current->graphExec); current->graphExec = nullptr; }
+        dropGraphs();
     }
     if (!freshRecs.empty()) {
         std::sort(freshRecs.begin(), freshRecs.end());
@@ -1481,7 +1489,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     int rc = swapInPending();
     if (rc != kOk) return rc;
     if (!current) return kOk;   // no render sequence yet: outputs untouched (Runtime.h:287-289)
-    const Plan& p = *current;
+    Plan& p = *current;
     if (p.packedRootChannels > 0 && nOut < (size_t)p.packedRootChannels) return kInvalidPropertyValue;   // (`pack_roots`, plan.cpp)
 
     if (hGlobals.ringSlots != 1 || hGlobals.blockSlot != 0) {
@@ -1532,7 +1540,26 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
         }
         outDev = hostOutDirect ? hOutDev : nullptr;
     }
-    if (specBlock) enqueueBatch(p, 1u, outDev);
+    if (specBlock && specBlockGraph && useGraph && !profileLaunches && !debugSyncOn()) {
+        // the launch set of one (level launches, side-stream forks and joins, batch epilogue) replayed from a captured graph
+        float* const target = outDev ? outDev : dOutRing;
+        if (!p.specGraphExec || p.specGraphOut != target) {
+            if (p.specGraphExec) { (void)hipGraphExecDestroy(p.specGraphExec); p.specGraphExec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIP_OK(hipStreamSynchronize(stream));
+            const uint64_t before = st.specLaunches;
+            HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            enqueueBatch(p, 1u, outDev);
+            HIP_OK(hipStreamEndCapture(stream, &graph));
+            HIP_OK(hipGraphInstantiate(&p.specGraphExec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            p.specGraphOut = target; p.specGraphLaunches = (uint32_t)(st.specLaunches - before);
+            st.specLaunches = before;
+            st.graphCaptures++;
+        }
+        HIP_OK(hipGraphLaunch(p.specGraphExec, stream));
+        st.specLaunches += p.specGraphLaunches; st.graphReplays++;
+    } else if (specBlock) enqueueBatch(p, 1u, outDev);
     else enqueueBlock(p, outDev);
     if (nOut > 0 && !outDev) HIP_OK(hipMemcpyAsync(hOut, dOutRing, nOut * (size_t)blockSize * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));

@@ -252,6 +252,7 @@ private:
     bool hostOutDirect = true;             // process(): the epilogue kernel writes into the mapped pinned output block
     uint32_t convMinP = 0xFFFFFFFFu, convMaxP = 0;   // fewest / most partitions of any impulse response set so far
     int convMfma = 1;                      // conv.hip elemhip_convolve_batch_mac: 1 v_mfma_f32_4x4x1_16B_f32 Toeplitz tiles, 0 v_pk_fma_f32 (r03)
+    bool specBlockGraph = false;           // option "spec_block_graph": replay elemhip_process' launch set of one from a captured hipGraph
     bool specBlocks = true;                // process(): whole blocks of a settled, fully compiled sequence use the specialised kernels
     int  batchBlocks = 64;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)
     int  pipelineCopies = 6;               // blocks a stateful island keeps in flight inside a multi-block launch
@@ -300,6 +301,7 @@ private:
     void rootUpdateStep(Node& n);
     int  flushPending();                   // fresh records + patches -> device (stream-ordered)
     void freeDeferred();
+    void dropGraphs();                     // the current plan's captured graphs (a pointer or launch geometry baked into them changed)
     int  ensureHbm(size_t buffers);
     size_t arenaBuffers(const Plan& p, size_t blocks) const;
     size_t maxSetBlocks(const Plan& p) const;
@@ -382,6 +384,10 @@ struct Plan {
     // captured launch sequence for multi-block offline rendering
     hipGraphExec_t graphExec = nullptr;
     int graphBlocks = 0;
+    // elemhip_process of a settled, fully compiled sequence: the launch set of ONE (levels + batch epilogue) as a captured graph
+    hipGraphExec_t specGraphExec = nullptr;
+    float* specGraphOut = nullptr;          // the output pointer baked into it
+    uint32_t specGraphLaunches = 0;         // specialised launches it replays (stats)
     ~Plan();
 };
 

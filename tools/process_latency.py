@@ -14,11 +14,12 @@ from elementary_amd.runtime import Runtime
 
 voices = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-for spec_blocks, direct in ((0, 0), (0, 1), (1, 0), (1, 1)):
+for spec_blocks, direct, graph in ((0, 1, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1)):
     rt = Runtime(graphs.C2_SAMPLE_RATE, 512, device=0)
     rt.set_option("specialize", 2)
     rt.set_option("spec_blocks", spec_blocks)
     rt.set_option("host_out_direct", direct)
+    rt.set_option("spec_block_graph", graph)
     assert rt.render(*graphs.c2_graph(voices=voices))["result"] == 0
     for _ in range(60):
         rt.process(None, 2, 512)
@@ -33,6 +34,6 @@ for spec_blocks, direct in ((0, 0), (0, 1), (1, 0), (1, 1)):
         rt.process(None, 2, 512)
     prof = rt.launch_profile()
     rt.set_option("profile_launches", 0)
-    print(json.dumps({"voices": voices, "spec_blocks": spec_blocks, "host_out_direct": direct, "us_mean": float(ts.mean()), "us_p50": float(np.percentile(ts, 50)),
+    print(json.dumps({"voices": voices, "spec_blocks": spec_blocks, "host_out_direct": direct, "spec_block_graph": graph, "us_mean": float(ts.mean()), "us_p50": float(np.percentile(ts, 50)),
                       "us_p99": float(np.percentile(ts, 99)), "device_level_us": [1e3 * x / max(1, prof["blocks"]) for x in prof["level_ms"]],
                       "device_epilogue_us": 1e3 * prof["epilogue_ms"] / max(1, prof["blocks"]), "profiled_blocks": prof["blocks"]}), flush=True)
