@@ -271,6 +271,8 @@ enum : uint32_t {
     // capture (Capture.h): device ring of bitceil(sr) floats, its mask; ring write / read positions (MultiChannelRingBuffer.h), frames
     // in the 128-frame scratch (they sit in the ring ahead of the write position), change detector, relay-ready flag
     CAP_RING = P0, CAP_MASK = P2, CAP_WRITE = 8, CAP_READ = 9, CAP_SCRATCH = 10, CAP_CHANGE = 11, CAP_READY = 12,
+    CAP_CHANS = P3,      // mc.capture: capture channels (= children - 1; 0: the mono `capture` node), ring k at CAP_RING + k * (CAP_MASK + 1) floats
+    CAP_CH = P4,         // mc.capture: the output channel this record renders (channel 0's record carries the recording state)
     // meter: S0 min, S1 max, S2 readout count; snapshot: S0 previous trigger sample, S1 captured value, S2 capture count
     EVT_A = 8, EVT_B = 9, EVT_COUNT = 10,
     // scope: device ring [4 channels][8192] (MultiChannelRingBuffer.h), write / read positions shared with the host relay

@@ -67,7 +67,7 @@ static const std::unordered_map<std::string, uint16_t>& opTable() {
         {"pole", OP_POLE}, {"env", OP_ENV}, {"biquad", OP_BIQUAD}, {"prewarp", OP_PREWARP}, {"mm1p", OP_MM1P}, {"svf", OP_SVF}, {"svfshelf", OP_SVFSHELF},
         {"tapIn", OP_TAPIN}, {"tapOut", OP_TAPOUT},
         {"blepsaw", OP_BLEPSAW}, {"blepsquare", OP_BLEPSQUARE}, {"bleptriangle", OP_BLEPTRIANGLE},
-        {"mc.table", OP_TABLE}, {"mc.sample", OP_MCSAMPLE}, {"mc.sampleseq", OP_SAMPLESEQ}, {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2}, {"sparseq", OP_SPARSEQ}, {"capture", OP_CAPTURE}, {"sample", OP_SAMPLE}, {"meter", OP_METER}, {"snapshot", OP_SNAPSHOT}, {"scope", OP_SCOPE},
+        {"mc.table", OP_TABLE}, {"mc.sample", OP_MCSAMPLE}, {"mc.sampleseq", OP_SAMPLESEQ}, {"time", OP_TIME}, {"metro", OP_METRO}, {"sampleseq", OP_SAMPLESEQ}, {"convolve", OP_CONVOLVE}, {"table", OP_TABLE}, {"seq2", OP_SEQ2}, {"sparseq2", OP_SPARSEQ2}, {"sparseq", OP_SPARSEQ}, {"capture", OP_CAPTURE}, {"mc.capture", OP_CAPTURE}, {"sample", OP_SAMPLE}, {"meter", OP_METER}, {"snapshot", OP_SNAPSHOT}, {"scope", OP_SCOPE},
     };
     return t;
 }
@@ -331,7 +331,8 @@ uint32_t Engine::channelRec(Node& n, uint32_t ch) {
         n.chanRecs.push_back(r);
         // parameters and INITIAL state as the host last wrote them for channel 0 (pending-buffer flags included)
         std::memcpy(shadow.data() + (size_t)r * kRecDwords, shadow.data() + (size_t)n.rec * kRecDwords, kRecDwords * 4);
-        writeChannelBuffer(n, (uint32_t)n.chanRecs.size(), r);
+        if (n.op == OP_CAPTURE) shadow[(size_t)r * kRecDwords + rec::CAP_CH] = (uint32_t)n.chanRecs.size();   // mc.capture: passes input ch + 1 through (channel 0 records)
+        else writeChannelBuffer(n, (uint32_t)n.chanRecs.size(), r);
         // channel 0 has been on the device already (it may be mid-playback): the new channel continues from channel 0's
         // LIVE reader state and consumed flags — the reference keeps one state for all channels (mc/Sample.h, mc/SampleSeq.h)
         if (!freshFlag[n.rec]) recClones.push_back({n.rec, r});
@@ -533,7 +534,7 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
     } else if (nn.op == OP_SCOPE) {                                               // Analyzers.h:145: MultiChannelRingBuffer(4) x 8192
         rc = allocRing(nn, 4u * 8192u);
         if (rc == kOk) writeParamPtr(nn, rec::SCP_RING, nn.ring.ptr);
-    } else if (nn.op == OP_CAPTURE) {                                             // Capture.h:17: ringBuffer(1, bitceil(sr))
+    } else if (nn.op == OP_CAPTURE && !nn.mc) {                                   // Capture.h:17: ringBuffer(1, bitceil(sr)); (mc.capture: at commit)
         const size_t cap = (size_t)bitceil((int)(size_t)sampleRate);
         rc = allocRing(nn, cap);
         if (rc == kOk) { writeParamPtr(nn, rec::CAP_RING, nn.ring.ptr); writeParam(nn, rec::CAP_MASK, (uint32_t)(cap - 1)); }
@@ -969,6 +970,25 @@ int Engine::commit(std::unique_lock<std::mutex>& renderLock) {   // Runtime.h:20
         // the rebuild stays owed so that the next commit retries instead of rendering the old sequence forever.)
         if (!p) { rebuildOwed = true; return kUnsupportedGraph; }
         rebuildOwed = false;
+        // mc.capture: the reference (re)creates the node's multi-channel ring whenever a render sequence that holds it is pushed
+        // (GraphRenderSequence.h:165-169 sets `_internal:numChildren`, mc/Capture.h:21-31 allocates children - 1 channels of
+        // bitceil(sr) frames): unread samples are dropped, the change detector and the relay flag live on
+        for (int32_t id : p->nodeIds) {
+            auto it = nodes.find(id);
+            if (it == nodes.end() || it->second.op != OP_CAPTURE || !it->second.mc) continue;
+            Node& n = it->second;
+            const size_t chans = n.inlets.size() > 1 ? n.inlets.size() - 1 : 0, cap = (size_t)bitceil((int)(size_t)sampleRate);
+            if (chans == 0) continue;
+            if (n.ring.bytes != chans * cap * sizeof(float)) {
+                const int rc = allocRing(n, chans * cap);
+                if (rc != kOk) return rc;
+                writeParamPtr(n, rec::CAP_RING, n.ring.ptr);
+                for (uint32_t cr : n.chanRecs) { writeRec(cr, rec::CAP_RING, shadow[(size_t)n.rec * kRecDwords + rec::CAP_RING]); writeRec(cr, rec::CAP_RING + 1, shadow[(size_t)n.rec * kRecDwords + rec::CAP_RING + 1]); }
+            }
+            writeParam(n, rec::CAP_MASK, (uint32_t)(cap - 1));
+            writeParam(n, rec::CAP_CHANS, (uint32_t)chans);
+            writeParam(n, rec::CAP_WRITE, 0u); writeParam(n, rec::CAP_READ, 0u);
+        }
         pending = p;
         shouldRebuild = false;
         st.plansBuilt++;
@@ -1063,6 +1083,46 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
             HIP_OK(hipMemcpy(dRecs + (size_t)n.rec * kRecDwords + rec::SCP_READ, &nr, 4, hipMemcpyHostToDevice));
             shadow[(size_t)n.rec * kRecDwords + rec::SCP_READ] = nr;
             cb("scope", j.c_str(), user);
+            continue;
+        }
+        if (n.op == OP_CAPTURE && n.mc) {                                 // mc/Capture.h:107-146: drain every channel's ring, emit once the gate fell
+            uint32_t cs[5] = {0, 0, 0, 0, 0};                             // write, read, (scratch), change, ready
+            HIP_OK(hipMemcpy(cs, dRecs + (size_t)n.rec * kRecDwords + rec::CAP_WRITE, sizeof cs, hipMemcpyDeviceToHost));
+            const uint32_t mask = shadow[(size_t)n.rec * kRecDwords + rec::CAP_MASK], cap = mask + 1u, chans = shadow[(size_t)n.rec * kRecDwords + rec::CAP_CHANS];
+            const uint32_t w = cs[0], r = cs[1];
+            const uint32_t avail = w > r ? w - r : ((cap - (r - w)) & mask);
+            if (avail > 0 && n.ring.ptr && chans > 0) {
+                if (n.relayCh.size() != chans) n.relayCh.resize(chans);       // (pendingEventData.resize(numChansToRead))
+                const uint32_t first = std::min(avail, cap - r);
+                for (uint32_t k = 0; k < chans; ++k) {
+                    std::vector<float>& dst = n.relayCh[k];
+                    const size_t at = dst.size();
+                    dst.resize(at + avail);
+                    const float* base = (const float*)n.ring.ptr + (size_t)k * cap;
+                    HIP_OK(hipMemcpy(dst.data() + at, base + r, (size_t)first * 4, hipMemcpyDeviceToHost));
+                    if (avail > first) HIP_OK(hipMemcpy(dst.data() + at + first, base, (size_t)(avail - first) * 4, hipMemcpyDeviceToHost));
+                }
+                const uint32_t nr = (r + avail) & mask;
+                HIP_OK(hipMemcpy(dRecs + (size_t)n.rec * kRecDwords + rec::CAP_READ, &nr, 4, hipMemcpyHostToDevice));
+                shadow[(size_t)n.rec * kRecDwords + rec::CAP_READ] = nr;
+            }
+            if (cs[4]) {
+                const uint32_t zero = 0u;
+                HIP_OK(hipMemcpy(dRecs + (size_t)n.rec * kRecDwords + rec::CAP_READY, &zero, 4, hipMemcpyHostToDevice));
+                shadow[(size_t)n.rec * kRecDwords + rec::CAP_READY] = 0u;
+                std::string src = "null";
+                auto nm = n.props.find("name");
+                if (nm != n.props.end() && nm->second.isString()) { src = "\""; for (char ch : nm->second.str) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; } src += "\""; }
+                std::string j = "{\"source\": " + src + ", \"data\": [";
+                for (size_t k = 0; k < n.relayCh.size(); ++k) {
+                    j += k ? ", [" : "[";
+                    for (size_t i = 0; i < n.relayCh[k].size(); ++i) { if (i) j += ", "; j += numStr(n.relayCh[k][i]); }
+                    j += "]";
+                    n.relayCh[k].clear();
+                }
+                j += "]}";
+                cb("mc.capture", j.c_str(), user);
+            }
             continue;
         }
         if (n.op == OP_CAPTURE) {                                         // Capture.h:60-95: drain the ring into the relay, emit once the gate fell

@@ -84,6 +84,7 @@ struct Node {
     uint32_t convSlices = 1;    // convolve: helper slices its current impulse response wants (conv.hip)
     bool mc = false;            // multi-output node (mc.*): one record per output channel, planned as one entry per channel
     std::vector<uint32_t> chanRecs;   // records of output channels 1, 2, ... (allocated when a plan first needs them)
+    std::vector<std::vector<float>> relayCh;   // mc.capture: one relay per capture channel (pendingEventData, mc/Capture.h:152)
     std::vector<float> relay;   // OP_CAPTURE: samples drained from the device ring, waiting for the gate's falling edge (Capture.h:102)
     void* hostInst = nullptr;   // OP_HOST: the instance its type's create() returned
     const HostVTable* hostVt = nullptr;

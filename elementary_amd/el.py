@@ -423,3 +423,9 @@ class mc:
     def sampleseq(props: Dict[str, Any], t: ElemNode) -> List[NodeRepr]:
         """lib/mc.ts:36-56"""
         return mc._n("mc.sampleseq", props, t)
+
+    @staticmethod
+    def capture(props: Dict[str, Any], g: ElemNode, *args: ElemNode) -> List[NodeRepr]:
+        """lib/mc.ts:94-113: records every input while the gate g is non-zero (any drop of g hands the take over); output channel
+        k passes args[k] through; the recording arrives as an "mc.capture" event with one array per input."""
+        return mc._n("mc.capture", props, g, *args)

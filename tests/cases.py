@@ -100,10 +100,13 @@ NODE_CASES = {
                    + el.mc.sampleseq({"path": "/t/stereo", "channels": 2, "duration": 300,
                                       "seq": [{"time": 0, "value": 1}, {"time": 900, "value": 0}, {"time": 2000, "value": 1}, {"time": 5000, "value": 0}]},
                                      el.counter(1)), 1),
+    # builtins/mc/Capture.h: pass-through of the inputs behind the gate (three capture channels, two of them consumed; one consumed)
+    "mc_capture": (lambda: el.mc.capture({"name": "take", "channels": 2}, el.train(23.0), X(0), el.mul(0.5, X(1)), el.cycle(300.0))
+                           + el.mc.capture({"channels": 1}, el.le(X(1), 0.1), el.mul(2.0, X(0))), 2),
 }
 
 # shared resources the cases above load (name -> channel-0 samples)
-REF_ONLY = {"mc"}      # cases the plain-C port oracle cannot render (checked against oracle/_ref only)
+REF_ONLY = {"mc", "mc_capture"}      # cases the plain-C port oracle cannot render (checked against oracle/_ref only)
 
 
 def node_case_resources():

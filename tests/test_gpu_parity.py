@@ -236,6 +236,46 @@ def test_event_relay(gpu_required):
                     assert float(np.abs(np.asarray(pa[key], np.float64) - np.asarray(pb[key], np.float64)).max()) <= TOL, (key, pa, pb)
 
 
+def test_mc_capture_events(gpu_required):
+    """builtins/mc/Capture.h: the "mc.capture" relay of the HIP engine vs the reference engine — a slow gate (takes spanning
+    several blocks), a noisy gate (many rises and falls inside one block: the writeStart / writeStop marker logic), events
+    polled at irregular intervals, a re-render in between (the reference re-creates the node's ring on every push)."""
+    import oracle
+    if not oracle.have_ref():
+        pytest.skip("needs oracle/_ref")
+    from elementary_amd.runtime import Runtime
+    logs, outs = [], []
+    for mk in (lambda sr, bs: Runtime(sr, bs, device=0), lambda sr, bs: oracle.RefRuntime(sr, bs)):
+        rt = mk(44100.0, 512)
+        x0, x1 = el.in_({"channel": 0}), el.in_({"channel": 1})
+        def graph(extra):
+            return (el.mc.capture({"name": "slow", "channels": 2}, el.train(7.0), x0, el.mul(0.5, x1), el.mul(extra, x0))
+                    + el.mc.capture({"name": "noisy", "channels": 1}, el.ge(x1, 0.2), x0, x1))
+        assert rt.render(*graph(0.25))["result"] == 0
+        log, out = [], []
+        for k in range(40):
+            x = np.stack([lcg_noise(512, 5 + k, 0.5), lcg_noise(512, 105 + k, 0.5)])
+            out.append(rt.process(x, 3, 512))
+            if k == 20:
+                assert rt.render(*graph(0.75))["result"] == 0
+            if k % 4 != 2:
+                log.append(rt.process_queued_events())
+        logs.append(log); outs.append(np.stack(out))
+    assert float(np.abs(outs[0] - outs[1]).max()) <= TOL
+    assert len(logs[0]) == len(logs[1])
+    n_events = 0
+    for a, b in zip(*logs):
+        assert [(t, p.get("source")) for t, p in a] == [(t, p.get("source")) for t, p in b], (a, b)
+        for (_, pa), (_, pb) in zip(a, b):
+            assert len(pa["data"]) == len(pb["data"])
+            for ca, cb in zip(pa["data"], pb["data"]):
+                assert len(ca) == len(cb), (len(ca), len(cb))
+                if len(cb):
+                    assert float(np.abs(np.asarray(ca, np.float64) - np.asarray(cb, np.float64)).max()) <= TOL
+                n_events += 1
+    assert n_events >= 10
+
+
 def test_stranger_things_example(gpu_required):
     """cli/examples/02_StrangerThings.js:10-31 (the reference's own example patch, also the 69-node voice of
     hashing.test.js) rendered on both engines, two channels, 3 s of audio at the cli's sample rate."""
