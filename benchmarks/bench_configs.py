@@ -288,6 +288,7 @@ def c5(args):
     rt.set_option("specialize", 1)   # a live graph never waits for a compiler: background mode (the product default)
     gpu = drive(rt, lambda k: rt.process_blocks(k, 2, out_ptr=out.data_ptr()), args.seconds)
     st = rt.stats()
+    plan_info = rt.describe_plan()
     rt2 = Runtime(graphs.C2_SAMPLE_RATE, BLOCK, device=0)
     rt2.set_option("specialize", 1)
     threaded = drive_two_threads(rt2, min(args.seconds, 6.0))
@@ -296,7 +297,8 @@ def c5(args):
     return {"config": "C5 dynamic graph: 128 live voices (~2060 nodes), one voice replaced per batch, 28 batches per wall-clock second, gc every 16",
             "instructions_per_batch": sum(sizes[1:]) / max(1, len(sizes) - 1), "nodes_created_per_batch": sum(creates[1:]) / max(1, len(creates) - 1),
             "node_adds_per_second": rate * sum(creates[1:]) / max(1, len(creates) - 1),
-            "gpu": gpu, "gpu_two_threads": threaded, "plan_build_ms_last": st["last_plan_build_ms"], "hipgraph_capture_ms_last": st["last_graph_capture_ms"],
+            "gpu": gpu, "gpu_two_threads": threaded, "plan_build_ms_last": st["last_plan_build_ms"], "plan_build_us_last": plan_info["build_us"],
+            "island_programs_reused_per_replan": plan_info["plan_islands_reused"] / max(1, st["plans_built"] - 1), "program_heaps": plan_info["plan_prog_heaps"], "hipgraph_capture_ms_last": st["last_graph_capture_ms"],
             "hipgraph_captures": st["graph_captures"], "plans_built": st["plans_built"],
             "cpu_reference": ref, "cpu_kind": kind,
             "note": "instruction batches are generated before the timed region; commit -> first block = apply_instructions (graph "

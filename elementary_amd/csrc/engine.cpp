@@ -87,11 +87,35 @@ static double msToStep(double sr, double ms) {   // helpers/GainFade.h:10-12
     return ms > 1e-6 ? 1.0 / (sr * ms / 1000.0) : 1.0;
 }
 
+ProgHeap::~ProgHeap() { if (dev) (void)hipFree(dev); }
+
 Plan::~Plan() {
     if (graphExec) (void)hipGraphExecDestroy(graphExec);
     if (specGraphExec) (void)hipGraphExecDestroy(specGraphExec);
-    if (dev.ptr) (void)hipFree(dev.ptr);
+    if (dev.ptr) { if (pool) pool->give(dev); else (void)hipFree(dev.ptr); }
 }
+
+DevBuf TablePool::take(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lock(m);
+        size_t best = free.size();
+        for (size_t k = 0; k < free.size(); ++k)
+            if (free[k].bytes >= bytes && free[k].bytes <= 4 * bytes && (best == free.size() || free[k].bytes < free[best].bytes)) best = k;
+        if (best != free.size()) { DevBuf b = free[best]; free.erase(free.begin() + (long)best); return b; }
+    }
+    DevBuf b;
+    b.bytes = bytes + bytes / 4 + 4096;    // (the next plan of a live graph is a little bigger or smaller)
+    if (hipMalloc(&b.ptr, b.bytes) != hipSuccess) { b.ptr = nullptr; b.bytes = 0; }
+    return b;
+}
+
+void TablePool::give(DevBuf b) {
+    std::lock_guard<std::mutex> lock(m);
+    free.push_back(b);
+    if (free.size() > 8) { (void)hipFree(free.front().ptr); free.erase(free.begin()); }
+}
+
+TablePool::~TablePool() { for (DevBuf& b : free) (void)hipFree(b.ptr); }
 
 // ---------------------------------------------------------------------------------------------
 Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), device(dev) {
@@ -1187,7 +1211,7 @@ size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
     std::vector<int32_t> pruned;
     for (auto it = nodes.begin(); it != nodes.end(); ++it) {
         const int32_t id = it->first;
-        const bool held = (current && current->nodeIds.count(id)) || (pending && pending->nodeIds.count(id));
+        const bool held = (current && current->holdsNode(id)) || (pending && pending->holdsNode(id));
         if (!held) pruned.push_back(id);
     }
     std::set<int32_t> prunedSet(pruned.begin(), pruned.end());
@@ -1351,6 +1375,7 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "pipeline_copies") { pipelineCopies = std::max(1, std::min(6, (int)value)); planStale = true; return kOk; }   // next commit re-plans
     if (key == "stream_ring") { streamRing = value != 0.0; return kOk; }   // 0: measurement only, needs kernels built with ELEMHIP_STREAM_PER_BLOCK
     if (key == "pack_islands") { packIslands = std::max(0, std::min(16, (int)value)); planStale = true; return kOk; }   // next commit re-plans
+    if (key == "prog_heap_dwords") { progHeapCap = (size_t)std::max(0.0, value); progHeap.reset(); islandCache.clear(); planStale = true; return kOk; }   // 0: sized by the engine
     if (key == "pack_roots") { packRoots = value != 0; planStale = true; return kOk; }   // islands of different active roots may share a workgroup (C4: a root per render job)
     if (key == "pack_max") { packMax = std::max(1, std::min(16, (int)value)); planStale = true; return kOk; }
     if (key == "cu_count") { cuCount = std::max(1, (int)value); planStale = true; return kOk; }      // (dry handles / tests: the CU count the auto mode plans for)

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -102,9 +103,32 @@ struct SpecText {
 
 // One island's scheduled program as the planner left it (plan.cpp "island program cache"): an island whose nodes, edges,
 // arena positions and options are unchanged at the next build takes these instead of being scheduled again.
+// Table buffers of retired plans, kept for the next plan (a live graph re-plans dozens of times a second; hipMalloc / hipFree
+// cost more than the upload, and hipFree synchronises the device). A buffer comes back when its plan dies, which is after the
+// synchronize that follows the plan's last launch (Engine::freeDeferred) or before any launch (a pending plan replaced).
+struct TablePool {
+    std::mutex m;
+    std::vector<DevBuf> free;
+    DevBuf take(size_t bytes);           // a pooled buffer of at least `bytes` (not more than 4x), or a fresh allocation; ptr null = out of memory
+    void give(DevBuf b);
+    ~TablePool();
+};
+
+// Device home of the island programs. Blobs are appended and never rewritten, so a re-plan uploads only the programs of the
+// islands it had to schedule (the replaced voice) while kernels of the current plan keep reading their own blobs; unchanged
+// islands are referenced where they already sit. Replaced islands leave garbage behind: when the heap runs out the engine
+// starts a fresh one and forgets the cache (plans keep the heap they point into alive).
+struct ProgHeap {
+    uint32_t* dev = nullptr;             // null on a dry engine (offsets are still handed out)
+    size_t capDwords = 0, usedDwords = 0;
+    ~ProgHeap();
+};
+
 struct IslandProgram {
     Island I;                            // progBegin / rootRec are re-made per plan
-    std::vector<uint32_t> blob;          // its slice of Plan::prog (16-byte padded)
+    std::vector<uint32_t> blob;          // host copy of the program (16-byte padded): describePlan, plan_cache = 2
+    std::shared_ptr<ProgHeap> heap;      // where the device copy lives ...
+    uint32_t heapBegin = 0;              // ... as a dword offset (= Island::progBegin of every plan that uses it)
     std::shared_ptr<SpecText> spec;      // specialised-kernel text of its shape (null: none)
     uint32_t numMembers = 0, numOperands = 0, streamDelta = 0;
 };
@@ -115,6 +139,7 @@ struct Stats {
     double   lastPlanBuildMs = 0.0;
     uint32_t numIslands = 0, numLevels = 0, numTasks = 0, numNodesInPlan = 0, maxLdsBytes = 0, numHbmBuffers = 0;
     uint64_t graphReplays = 0, graphCaptures = 0, batchLaunches = 0;
+    uint64_t progHeaps = 0;              // program heaps started (1 = the first still serves)
     uint64_t planIslandsReused = 0, planIslandsScheduled = 0, planCacheMismatches = 0;   // island program cache (plan.cpp)
     uint64_t specLaunches = 0;             // launches of run-time specialised island kernels
     uint32_t specShapes = 0, specIslands = 0;
@@ -191,6 +216,9 @@ private:
     Stats st;
 
     std::unordered_map<int32_t, Node> nodes;
+    std::shared_ptr<TablePool> tablePool = std::make_shared<TablePool>();
+    std::shared_ptr<ProgHeap> progHeap;    // island programs on the device (plan.cpp); owned by the mutator side (`ctl`)
+    size_t lastPlanProgDwords = 0, progHeapCap = 0;
     std::set<int32_t> currentRoots;
     std::unordered_map<std::string, ResourcePtr> resources;
     std::unordered_map<std::string, std::unique_ptr<HostVTable>> hostTypes;
@@ -337,7 +365,11 @@ struct Plan {
     std::vector<uint32_t> levelIslands;
     std::vector<uint32_t> levelOffsets;    // numLevels + 1
     std::vector<uint32_t> levelLdsBytes;
-    std::vector<uint32_t> prog;            // per-island program blobs (device.h: Island)
+    std::vector<uint32_t> prog;            // program blobs of the islands THIS build scheduled (staging for the heap upload)
+    std::shared_ptr<ProgHeap> progHeap;    // Island::progBegin is an offset into it
+    std::vector<std::shared_ptr<IslandProgram>> islandProg;   // per island (null: convolve / call-out islands)
+    size_t progDwordsTotal = 0;            // all islands' programs (sizes the next heap)
+    size_t heapOverflowDwords = 0;         // build failed: the heap lacked room for this many dwords
     uint32_t numTasks = 0, numMembers = 0, numOperands = 0;
     std::vector<RootEntry> roots;
     std::vector<TapEntry> taps;
@@ -350,14 +382,21 @@ struct Plan {
     std::vector<uint32_t> convLevelOffsets; // numLevels + 1
     std::vector<int32_t> rootIds;          // same order as `roots`
     std::vector<uint32_t> islandLevel;     // launch level of each island
-    std::set<int32_t> nodeIds;             // every node the render sequence references (gc)
+    mutable std::vector<int32_t> nodeIds;  // every node the render sequence references (gc); sorted by the first holdsNode (gc is rare, a build is not)
+    mutable bool nodeIdsSorted = false;
+    bool holdsNode(int32_t id) const {
+        if (!nodeIdsSorted) { std::sort(nodeIds.begin(), nodeIds.end()); nodeIdsSorted = true; }
+        return std::binary_search(nodeIds.begin(), nodeIds.end(), id);
+    }
+    double buildUs[6] = {0, 0, 0, 0, 0, 0}; // where the build went: render order, islands, island programs, levels + roots, shapes + tables, upload
     uint32_t numHbmBuffers = kMaxHostIn;       // per block of a launch set: host inputs + exports
     uint32_t numStreamBuffers = 0;             // per slice of the stream ring (specialised kernels; device.h kOpStream)
     uint32_t maxCopies = 1;                    // most buffer sets an island of the plan keeps in flight = slices of the stream ring
     uint32_t packK = 1;                        // islands merged per workgroup by the lane-packing step (1 = none were)
     uint32_t maxLdsBytes = 0;
     // device copies
-    DevBuf dev;                            // one allocation holding all tables
+    DevBuf dev;                            // one allocation holding all tables (from / back to `pool`)
+    std::shared_ptr<TablePool> pool;
     PlanView view{};
     // host call-out nodes (OP_HOST): rendered on the CPU after the kernels of their launch level
     struct HostDesc {

@@ -134,6 +134,40 @@ struct IslandBuild {
     std::vector<int> deps;       // islands it imports from
 };
 
+// (node id, channel) -> NI index: open addressing, sized once per build. The planner asks this table about every inlet in every
+// phase (~20 lookups per node and build); a node-per-entry std::unordered_map made the render-order phase allocation-bound.
+struct FlatIdx {
+    struct Slot { int64_t first; int second; };
+    std::vector<Slot> tab;
+    uint64_t mask = 0;
+    static constexpr int64_t kEmpty = INT64_MIN;
+    static uint64_t hash(int64_t k) { uint64_t h = (uint64_t)k * 0x9E3779B97F4A7C15ull; return h ^ (h >> 29); }
+    void reserve(size_t n) { size_t cap = 64; while (cap < 2 * n) cap <<= 1; tab.assign(cap, Slot{kEmpty, 0}); mask = cap - 1; used = 0; }
+    size_t used = 0;
+    int& operator[](int64_t k) {
+        if (2 * (used + 1) > tab.size()) {   // (multi-output nodes add an entry per channel: grow, keep the load under one half)
+            std::vector<Slot> old;
+            old.swap(tab);
+            tab.assign(std::max<size_t>(64, 2 * old.size()), Slot{kEmpty, 0}); mask = tab.size() - 1; used = 0;
+            for (const Slot& o : old) if (o.first != kEmpty) (*this)[o.first] = o.second;
+        }
+        for (uint64_t i = hash(k) & mask;; i = (i + 1) & mask) {
+            if (tab[i].first == k) return tab[i].second;
+            if (tab[i].first == kEmpty) { tab[i].first = k; ++used; return tab[i].second; }
+        }
+    }
+    const Slot* find(int64_t k) const {
+        if (tab.empty()) return nullptr;
+        for (uint64_t i = hash(k) & mask;; i = (i + 1) & mask) {
+            if (tab[i].first == k) return &tab[i];
+            if (tab[i].first == kEmpty) return nullptr;
+        }
+    }
+    const Slot* end() const { return nullptr; }
+    size_t count(int64_t k) const { return find(k) ? 1 : 0; }
+    int at(int64_t k) const { const Slot* s = find(k); if (!s) throw std::out_of_range("plan index"); return s->second; }
+};
+
 struct UF {
     std::vector<int> p;
     int find(int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
@@ -150,7 +184,7 @@ struct PlanBuilder {
     // (node id, output channel) -> NI index. Multi-output nodes (mc.*, GraphRenderSequence.h:15-24) are planned as one
     // single-output entry per channel; every other node only has channel 0, so an inlet that names another channel of it
     // finds nothing and reads as a missing input, like before.
-    std::unordered_map<int64_t, int> idx;
+    FlatIdx idx;
     static int64_t K(int32_t id, uint32_t ch = 0) { return ((int64_t)id << 8) | (int64_t)(ch & 0xFFu); }
     std::vector<std::vector<int>> seqNodes; // per root sequence
     std::vector<Node*> seqRoots;
@@ -198,10 +232,12 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
 
     static const bool planTiming = std::getenv("ELEMHIP_PLAN_TIMING") != nullptr;   // phase times of a build on stderr
     auto tPhase = std::chrono::steady_clock::now();
+    int phaseNo = 0;
     auto phase = [&](const char* name) {
-        if (!planTiming) return;
         const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[elemhip] plan %-18s %7.3f ms\n", name, std::chrono::duration<double, std::milli>(now - tPhase).count());
+        const double us = std::chrono::duration<double, std::micro>(now - tPhase).count();
+        if (phaseNo < 4) p.buildUs[phaseNo++] = us;
+        if (planTiming) std::fprintf(stderr, "[elemhip] plan %-18s %7.3f ms\n", name, us * 1e-3);
         tPhase = now;
     };
     // ---- 1. render order ---------------------------------------------------------------------
@@ -221,7 +257,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     }
     if (++e.planEpoch == 0u) { for (auto& kv : e.nodes) kv.second.planVisited = kv.second.planOnStack = 0u; e.planEpoch = 1u; }
     const uint32_t epoch = e.planEpoch;
-    idx.reserve(e.nodes.size() + e.nodes.size() / 4 + 16);
+    idx.reserve(2 * e.nodes.size() + 64);   // (one entry per node and output channel; the table doubles that again)
     ni.reserve(e.nodes.size() + 16);
     std::vector<int32_t> planNodeIds;
     planNodeIds.reserve(e.nodes.size());
@@ -251,9 +287,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             planNodeIds.push_back(id);
         }
     }
-    std::sort(planNodeIds.begin(), planNodeIds.end());
-    planNodeIds.erase(std::unique(planNodeIds.begin(), planNodeIds.end()), planNodeIds.end());
-    p.nodeIds = std::set<int32_t>(planNodeIds.begin(), planNodeIds.end());   // (built from the sorted range: linear)
+    // (no duplicates: the visit marks are shared by all root sequences, a node belongs to the first sequence that reaches it)
+    p.nodeIds.swap(planNodeIds);
 
     // ---- 1b. nodes folded into the convolve launch ------------------------------------------------------
     // `root(convolve(in))` is the whole graph of a convolution reverb channel: three launch levels for one
@@ -290,45 +325,55 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     // ---- 2. islands ---------------------------------------------------------------------------------
     UF uf;
     std::vector<uint32_t> weight;            // per island representative
-    std::vector<std::set<int>> succ;         // island DAG (by representative at insertion time)
+    std::vector<std::vector<int>> succ;      // island DAG (by representative at insertion time; small unsorted sets)
     std::vector<int> ilevel;                 // running estimate of each island's launch level
+    std::vector<uint32_t> seenMark;          // reaches(): visit marks by epoch (no hash set per query)
+    uint32_t seenEpoch = 0;
+    uf.p.reserve(ni.size()); weight.reserve(ni.size()); succ.reserve(ni.size()); ilevel.reserve(ni.size()); seenMark.reserve(ni.size());
     auto rep = [&](int i) { return uf.find(i); };
-    auto newIsland = [&]() { int i = uf.add(); weight.push_back(0); succ.emplace_back(); ilevel.push_back(0); return i; };
+    auto newIsland = [&]() { int i = uf.add(); weight.push_back(0); succ.emplace_back(); ilevel.push_back(0); seenMark.push_back(0); return i; };
+    using Small = std::vector<int>;          // a handful of island ids: linear search beats a tree
+    auto has = [](const Small& v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+    auto put = [&](Small& v, int x) { if (!has(v, x)) v.push_back(x); };
+    auto putSucc = [&](int from, int to) { Small& v = succ[(size_t)from]; if (v.size() >= 64 || !has(v, to)) v.push_back(to); };   // (a duplicate edge is harmless; a fan-out of thousands stays linear)
 
-    auto reaches = [&](const std::vector<int>& from, const std::set<int>& targets, const std::set<int>& skip) {
+    auto reaches = [&](const Small& from, const Small& targets, const Small& skip) {
         // is any island of `targets` reachable from `from` without starting inside `skip`?
         std::vector<int> stack;
-        std::unordered_set<int> seen;
-        for (int f : from) for (int s : succ[f]) { int r = rep(s); if (!skip.count(r) && seen.insert(r).second) stack.push_back(r); }
+        ++seenEpoch;
+        auto first = [&](int r) { if (seenMark[(size_t)r] == seenEpoch) return false; seenMark[(size_t)r] = seenEpoch; return true; };
+        for (int f : from) for (int s : succ[f]) { int r = rep(s); if (!has(skip, r) && first(r)) stack.push_back(r); }
         size_t budget = 20000;
         while (!stack.empty()) {
             if (budget-- == 0) return true;   // give up: treat as unsafe
             int x = stack.back(); stack.pop_back();
-            if (targets.count(x)) return true;
-            for (int s : succ[x]) { int r = rep(s); if (targets.count(r)) return true; if (seen.insert(r).second) stack.push_back(r); }
+            if (has(targets, x)) return true;
+            for (int s : succ[x]) { int r = rep(s); if (has(targets, r)) return true; if (first(r)) stack.push_back(r); }
         }
         return false;
     };
 
+    Small deps, foreign, others;
     for (size_t k = 0; k < ni.size(); ++k) {
         NI& x = ni[k];
         if (x.kind == K_CONST) continue;
         const uint32_t w = 1 + scratchSlots(x.n->op);
-        std::set<int> deps, foreign;
+        deps.clear(); foreign.clear();
         for (auto& in : x.n->inlets) {
             auto it = idx.find(K(in.source, in.channel));
             if (it == idx.end()) continue;
             NI& s = ni[it->second];
             if (s.kind == K_CONST) continue;
-            if (s.seq != x.seq) { foreign.insert(rep(s.island)); continue; }
-            deps.insert(rep(s.island));
+            if (s.seq != x.seq) { put(foreign, rep(s.island)); continue; }
+            put(deps, rep(s.island));
         }
+        std::sort(deps.begin(), deps.end()); std::sort(foreign.begin(), foreign.end());   // (the order a std::set walked them in)
         int target = -1;
         const bool sealed = x.kind == K_CONV || x.kind == K_HOST;
         if (!deps.empty() && !sealed) {
             uint32_t total = w;
             for (int d : deps) total += weight[d];
-            std::vector<int> dv(deps.begin(), deps.end());
+            const Small dv(deps);
             if (total <= maxIslandNodes && (deps.size() == 1 || !reaches(dv, deps, deps))) {
                 // a foreign (other-sequence) producer must not be downstream of the merged set
                 if (foreign.empty() || !reaches(dv, foreign, {})) {
@@ -339,7 +384,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                         uf.p[b] = a;
                         ilevel[a] = std::max(ilevel[a], ilevel[b]);
                         weight[a] += weight[b];
-                        succ[a].insert(succ[b].begin(), succ[b].end());
+                        for (int sb : succ[b]) putSucc(a, sb);
                         target = a;
                     }
                     target = rep(target);
@@ -352,11 +397,13 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 int best = -1;
                 for (int d : dv) {
                     if (weight[d] + w > maxIslandNodes) continue;
-                    std::set<int> others(deps); others.erase(d);
-                    for (int f : foreign) others.insert(f);
                     bool raises = false;
-                    for (int o : others) if (ilevel[o] >= ilevel[d]) { raises = true; break; }
+                    for (int o : deps) if (o != d && ilevel[o] >= ilevel[d]) { raises = true; break; }
+                    if (!raises) for (int o : foreign) if (ilevel[o] >= ilevel[d]) { raises = true; break; }
                     if (raises) continue;
+                    others.clear();
+                    for (int o : deps) if (o != d) others.push_back(o);
+                    for (int f : foreign) put(others, f);
                     if (!others.empty() && reaches({d}, others, {})) continue;
                     if (best < 0 || weight[d] > weight[best]) best = d;
                 }
@@ -373,8 +420,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         x.island = target;
         weight[target] += w;
         if (sealed) weight[target] += maxIslandNodes;   // nothing joins a convolve island
-        for (int d : deps) if (rep(d) != target) succ[rep(d)].insert(target);
-        for (int f : foreign) if (rep(f) != target) succ[rep(f)].insert(target);
+        for (int d : deps) if (rep(d) != target) putSucc(rep(d), target);
+        for (int f : foreign) if (rep(f) != target) putSucc(rep(f), target);
     }
 
     // canonical island list
@@ -560,6 +607,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     }
     // ---- 3/4. per-island schedule, LDS allocation, task emission -------------------------------------
     p.islands.resize(ib.size());
+    p.islandProg.assign(ib.size(), nullptr);
+    std::vector<uint32_t> scheduled;         // islands whose program this build made (p.prog holds them, progBegin relative to it)
     std::vector<int> convLevel;              // launch level of p.convs[i]
     for (size_t ii = 0; ii < ib.size(); ++ii) {
         IslandBuild& B = ib[ii];
@@ -615,6 +664,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         // of exactly that, an unchanged island takes its Island header, program blob and kernel text from the previous build.
         // `plan_cache` = 2 schedules anyway and compares (tests).
         const uint32_t streamStart = p.numStreamBuffers;
+        const auto tIsl0 = std::chrono::steady_clock::now();
         uint64_t ikey = 0;
         std::shared_ptr<IslandProgram> cached;
         if (e.planCache != 0) {
@@ -639,12 +689,13 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             }
             ikey = h;
             auto it = e.islandCache.find(ikey);
-            if (it != e.islandCache.end()) cached = it->second;
+            if (it != e.islandCache.end() && it->second->heap == e.progHeap) cached = it->second;
             if (cached && e.planCache == 1) {
                 I = cached->I;
-                I.progBegin = (uint32_t)p.prog.size();
+                I.progBegin = cached->heapBegin;          // the program is on the device already
                 I.rootRec = seqRoots[B.seq]->rec;
-                p.prog.insert(p.prog.end(), cached->blob.begin(), cached->blob.end());
+                p.islandProg[ii] = cached;
+                p.progDwordsTotal += cached->blob.size();
                 p.numStreamBuffers += cached->streamDelta;
                 if (packCount[ii] > 1u) minPackedCopies = minPackedCopies ? std::min(minPackedCopies, I.copies) : I.copies;
                 p.maxCopies = std::max(p.maxCopies, I.copies);
@@ -1429,10 +1480,12 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             p.specText[ii] = it->second;
         }
         p.numTasks += I.numTasks; p.numMembers += (uint32_t)members.size(); p.numOperands += (uint32_t)operands.size();
-        if (e.planCache != 0) {
+        {
             auto ent = std::make_shared<IslandProgram>();
             ent->I = I;
             ent->blob.assign(p.prog.begin() + I.progBegin, p.prog.end());
+            p.islandProg[ii] = ent; scheduled.push_back((uint32_t)ii);
+            p.progDwordsTotal += ent->blob.size();
             if (ii < p.specText.size()) ent->spec = p.specText[ii];
             ent->numMembers = (uint32_t)members.size(); ent->numOperands = (uint32_t)operands.size();
             ent->streamDelta = p.numStreamBuffers - streamStart;
@@ -1443,11 +1496,26 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                                   cached->streamDelta == ent->streamDelta && cached->numMembers == ent->numMembers;
                 if (!same) { e.st.planCacheMismatches++; std::fprintf(stderr, "[elemhip] plan cache: island %zu differs from its cached program\n", ii); }
             }
-            e.islandCache[ikey] = std::move(ent);
-            e.st.planIslandsScheduled++;
+            if (e.planCache != 0) { e.islandCache[ikey] = std::move(ent); e.st.planIslandsScheduled++; }
         }
+        if (planTiming) std::fprintf(stderr, "[elemhip] plan   island %zu scheduled in %.3f ms (%zu nodes)\n", ii, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tIsl0).count(), B.nodes.size());
     }
 
+    // the scheduled islands' programs go to the heap as one contiguous upload; everything else is there already
+    {
+        ProgHeap& H = *e.progHeap;
+        const size_t need = p.prog.size();
+        if (H.usedDwords + need > H.capDwords) { p.heapOverflowDwords = std::max<size_t>(need, 1); return plan; }
+        const uint32_t base = (uint32_t)H.usedDwords;
+        H.usedDwords += need;
+        for (uint32_t ii : scheduled) {
+            p.islands[ii].progBegin += base;
+            p.islandProg[ii]->heap = e.progHeap; p.islandProg[ii]->heapBegin = p.islands[ii].progBegin;
+        }
+        if (H.dev && need && hipMemcpy(H.dev + base, p.prog.data(), need * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        p.progHeap = e.progHeap;
+        p.prog.clear(); p.prog.shrink_to_fit();
+    }
     phase("island programs");
     // ---- 5. launch levels, roots, taps ------------------------------------------------------------------
     p.islandLevel.resize(ib.size());
@@ -1503,6 +1571,21 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     // Lane-packing (option "pack_islands": 0 auto, 1 off, K): the first attempt packs as the option says; a packed island
     // that does not fit in LDS, or fits with a single buffer set (no blocks in flight: the stages of a block would run back
     // to back), sends the build back with one island fewer per pack.
+    // room in the program heap for this build's new programs: a few islands on a live graph, all of them on a first build
+    auto freshHeap = [&](size_t needDwords) -> bool {
+        auto h = std::make_shared<ProgHeap>();
+        h->capDwords = std::max<size_t>((size_t)4 << 20, 8 * needDwords);       // 16 MB, or eight builds' worth
+        if (progHeapCap) h->capDwords = std::max(progHeapCap, needDwords);       // option "prog_heap_dwords" (tests: a heap that keeps running out)
+        else if (dry) h->capDwords = (size_t)1 << 30;
+        if (dry) {}
+        else if (hipMalloc(reinterpret_cast<void**>(&h->dev), h->capDwords * 4) != hipSuccess) return false;
+        islandCache.clear();                   // (its entries name offsets of the old heap; plans in flight keep that heap alive)
+        progHeap = std::move(h);
+        st.progHeaps++;
+        return true;
+    };
+    if (!progHeap || progHeap->capDwords - progHeap->usedDwords < (progHeapCap ? 0 : std::max<size_t>((size_t)1 << 18, 2 * lastPlanProgDwords)))
+        if (!freshHeap(lastPlanProgDwords)) return nullptr;
     uint32_t packK = (uint32_t)packIslands;
     for (;;) {
         uint32_t usedK = 1, minCopies = 0;
@@ -1512,6 +1595,15 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
             b.wantSpec = specialize != 0 && (!dry || specialize >= 2);
             b.packK = packK; b.packMax = (uint32_t)std::max(1, packMax); b.cuCount = (uint32_t)std::max(1, cuCount); b.packRoots = packRoots;
             plan = b.build(limit, (uint32_t)std::max(1, pipelineCopies));
+            if (plan && plan->heapOverflowDwords) {        // a graph far bigger than the last one: a heap sized for it, same attempt again
+                if (!freshHeap(plan->heapOverflowDwords)) return nullptr;
+                PlanBuilder b2(*this);
+                b2.wantSpec = b.wantSpec; b2.packK = packK; b2.packMax = b.packMax; b2.cuCount = b.cuCount; b2.packRoots = packRoots;
+                plan = b2.build(limit, (uint32_t)std::max(1, pipelineCopies));
+                if (plan && plan->heapOverflowDwords) plan.reset();
+                if (!plan) return nullptr;
+                b.packK = b2.packK; b.minPackedCopies = b2.minPackedCopies; b.packedIslands = b2.packedIslands;
+            }
             if (!plan) return nullptr;
             usedK = b.packK; minCopies = b.minPackedCopies;
             plan->packK = b.packedIslands ? usedK : 1u;
@@ -1524,13 +1616,14 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     }
     if (!plan) { std::fprintf(stderr, "[elemhip] plan: could not fit islands into LDS\n"); return nullptr; }
     Plan& p = *plan;
+    lastPlanProgDwords = p.progDwordsTotal;
 
     // pack + upload the tables
+    const auto tTables = std::chrono::steady_clock::now();
     size_t off = 0;
     auto place = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
     const size_t oIslands = place(p.islands.size() * sizeof(Island));
     const size_t oLevel = place(p.levelIslands.size() * 4);
-    const size_t oProg = place(p.prog.size() * 4);
     const size_t oRoots = place(p.roots.size() * sizeof(RootEntry));
     const size_t oTaps = place(p.taps.size() * sizeof(TapEntry));
     const size_t oConvs = place(p.convs.size() * sizeof(ConvDesc));
@@ -1594,7 +1687,6 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(host.data() + o, src, bytes); };
     put(oIslands, p.islands.data(), p.islands.size() * sizeof(Island));
     put(oLevel, p.levelIslands.data(), p.levelIslands.size() * 4);
-    put(oProg, p.prog.data(), p.prog.size() * 4);
     put(oRoots, p.roots.data(), p.roots.size() * sizeof(RootEntry));
     put(oTaps, p.taps.data(), p.taps.size() * sizeof(TapEntry));
     put(oConvs, p.convs.data(), p.convs.size() * sizeof(ConvDesc));
@@ -1602,7 +1694,8 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     put(oSpecLists, p.specLists.data(), p.specLists.size() * 4);
     put(oRest, p.restIslands.data(), p.restIslands.size() * 4);
 
-    if (std::getenv("ELEMHIP_PLAN_TIMING")) std::fprintf(stderr, "[elemhip] plan shapes + pack done\n");
+    const auto tUpload = std::chrono::steady_clock::now();
+    p.buildUs[4] = std::chrono::duration<double, std::micro>(tUpload - tTables).count();
     renderLock.lock();   // ---- from here on: render-side state ----
     st.specShapes = (uint32_t)p.shapes.size(); st.specIslands = (uint32_t)p.specLists.size();
     if (jitWaitMs >= 0.0) st.lastJitWaitMs = jitWaitMs;
@@ -1613,13 +1706,14 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
         if (shadow[r.rec * kRecDwords + rec::ROOT_HASIN] != has) writeParam(r, rec::ROOT_HASIN, has);
     }
     if (dry) return plan;
-    if (hipMalloc(&p.dev.ptr, host.size()) != hipSuccess) return nullptr;
-    p.dev.bytes = host.size();
+    p.pool = tablePool;
+    p.dev = tablePool->take(host.size());
+    if (!p.dev.ptr) return nullptr;
     if (hipMemcpy(p.dev.ptr, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     const uint8_t* d = static_cast<const uint8_t*>(p.dev.ptr);
     p.view.islands = reinterpret_cast<const Island*>(d + oIslands);
     p.view.levelIslands = reinterpret_cast<const uint32_t*>(d + oLevel);
-    p.view.prog = reinterpret_cast<const uint32_t*>(d + oProg);
+    p.view.prog = p.progHeap->dev;          // island programs live in the engine's program heap (Island::progBegin is relative to it)
     p.view.roots = reinterpret_cast<const RootEntry*>(d + oRoots);
     p.view.taps = reinterpret_cast<const TapEntry*>(d + oTaps);
     p.view.convs = reinterpret_cast<const ConvDesc*>(d + oConvs);
@@ -1629,6 +1723,7 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     p.view.numConvs = (uint32_t)p.convs.size();
     p.view.numRoots = (uint32_t)p.roots.size();
     p.view.numTaps = (uint32_t)p.taps.size();
+    p.buildUs[5] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tUpload).count();
     return plan;
 }
 
@@ -1647,9 +1742,16 @@ std::string Engine::describePlan() {
     auto kv = [&](const char* k, uint64_t v, bool comma = true) { s += "\"" + std::string(k) + "\":" + std::to_string(v) + (comma ? "," : ""); };
     kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.numTasks);
     kv("num_members", p.numMembers); kv("num_operands", p.numOperands); kv("num_nodes", p.nodeIds.size());
+    kv("plan_prog_heaps", st.progHeaps); kv("plan_prog_heap_used_dwords", p.progHeap ? p.progHeap->usedDwords : 0);
     kv("plan_islands_reused", st.planIslandsReused); kv("plan_islands_scheduled", st.planIslandsScheduled); kv("plan_cache_mismatches", st.planCacheMismatches);
     kv("num_hbm_buffers", p.numHbmBuffers); kv("num_stream_buffers", p.numStreamBuffers); kv("pack_k", p.packK);
     kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());
+    s += "\"build_us\":{";
+    {
+        static const char* names[6] = {"render_order", "islands", "island_programs", "levels_roots", "shapes_tables", "upload"};
+        for (int k = 0; k < 6; ++k) { char b[64]; std::snprintf(b, sizeof b, "%s\"%s\":%.1f", k ? "," : "", names[k], p.buildUs[k]); s += b; }
+    }
+    s += "},";
     kv("num_taps", p.taps.size()); kv("taps_in_sets", p.tapsInSets ? 1 : 0); kv("num_tap_nodes", p.taps.size() + p.tapPairs.size()); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());
     s += "\"level_sizes\":[";
     for (size_t l = 0; l + 1 < p.levelOffsets.size(); ++l) { if (l) s += ","; s += std::to_string(p.levelOffsets[l + 1] - p.levelOffsets[l]); }
@@ -1663,16 +1765,16 @@ std::string Engine::describePlan() {
              ",\"lds_bytes\":" + std::to_string(I.ldsWords * 4) + ",\"consts\":" + std::to_string(I.numCells) +
              ",\"prog_dwords\":" + std::to_string(I.progDwords) + ",\"copies\":" + std::to_string(I.copies) +
              ",\"stateless\":" + std::to_string(I.stateless) + ",\"phases\":[";
-        {   // first stage of each pipeline phase (stage tables of the island's program blob)
-            const uint32_t* tab = p.prog.data() + I.progBegin + I.stageOff + 2 * I.numStages + kWaves * (I.numStages + 1);
+        if (p.islandProg[i]) {   // first stage of each pipeline phase (stage tables of the island's program blob)
+            const uint32_t* tab = p.islandProg[i]->blob.data() + I.stageOff + 2 * I.numStages + kWaves * (I.numStages + 1);
             for (uint32_t d = 0; d <= I.copies; ++d) { if (d) s += ","; s += std::to_string(tab[d]); }
         }
         s += "],\"waves\":[";
         for (uint32_t w = 0; w < kWaves; ++w) {   // per program wave: [opcode, stage] of its tasks in program order
             if (w) s += ",";
             s += "[";
-            for (uint32_t t = I.waveTask[w]; t < I.waveTask[w + 1]; ++t) {
-                const uint32_t d0 = p.prog[I.progBegin + t * 8u];
+            for (uint32_t t = I.waveTask[w]; p.islandProg[i] && t < I.waveTask[w + 1]; ++t) {
+                const uint32_t d0 = p.islandProg[i]->blob[t * 8u];
                 if (t != I.waveTask[w]) s += ",";
                 s += "[" + std::to_string(d0 & 0xFFFFu) + "," + std::to_string((d0 >> 16) & 0xFFu) + "]";
             }

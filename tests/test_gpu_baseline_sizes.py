@@ -66,12 +66,14 @@ def test_gc_timing_on_a_rendering_engine(gpu_required):
     assert float(np.abs(ya - yb).max()) <= TOL
 
 
-@pytest.mark.parametrize("path", ["process", "process_blocks"])
+@pytest.mark.parametrize("path", ["process", "process_blocks", "small_heap"])
 def test_c5_mutation_stream(gpu_required, path):
     """BASELINE configs[4]: a live 128-voice graph (2060 nodes), one voice replaced per batch the way the reconciler does
     it (new voice nodes, a new mix add and a new root per channel; the old root fades out over 20 ms), gc() every 16
     batches. Every block and every pruned-id set must equal the reference engine's."""
     a, c = _hip(graphs.C2_SAMPLE_RATE, 512, batch_blocks=4), _checker(graphs.C2_SAMPLE_RATE, 512)
+    if path == "small_heap":      # the device heap of island programs runs out every few re-plans: a fresh heap, everything uploaded again,
+        a.set_option("prog_heap_dwords", 290_000)   # while the blocks in flight still read the old one
     ids = list(range(128))
     nxt = 128
     worst = 0.0
@@ -94,6 +96,8 @@ def test_c5_mutation_stream(gpu_required, path):
             assert pa == pc, (batch, len(pa), len(pc))
             pruned_total += len(pa)
     assert pruned_total > 100                                # replaced voices, old mix adds and old roots were reclaimed
+    heaps = a.describe_plan()["plan_prog_heaps"]
+    assert heaps >= 4 if path == "small_heap" else heaps == 1
     # the stream settles: a last long stretch, then everything that is not in the live graph goes
     ref = np.stack([c.process(None, 2, 512) for _ in range(8)])
     got = _blocks(a, 8, 2) if path == "process_blocks" else np.stack([a.process(None, 2, 512) for _ in range(8)])
