@@ -211,7 +211,7 @@ def c5(args):
         while time.perf_counter() - t0 < 1.0:
             render_chunk(64); n += 64
         static = n * BLOCK / (time.perf_counter() - t0)
-        lat, applied, frames = [], 0, 0
+        lat, lat_commit, lat_block, applied, frames = [], [], [], 0, 0
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < seconds:
             due = int((time.perf_counter() - t0) * rate)
@@ -219,17 +219,21 @@ def c5(args):
                 applied += 1
                 ta = time.perf_counter()
                 assert rt.apply_instructions_json(texts[applied]) == 0
+                tb = time.perf_counter()
                 render_chunk(1)                    # the first block rendered by the new render sequence
-                lat.append(1e3 * (time.perf_counter() - ta))
+                tc = time.perf_counter()
+                lat.append(1e3 * (tc - ta)); lat_commit.append(1e3 * (tb - ta)); lat_block.append(1e3 * (tc - tb))
                 frames += BLOCK
                 if applied % 16 == 0:
                     rt.gc()
             else:
                 render_chunk(64); frames += 64 * BLOCK
         dt = time.perf_counter() - t0
-        lat.sort()
+        lat.sort(); lat_commit.sort(); lat_block.sort()
         pct = lambda a, q: a[min(len(a) - 1, int(q * len(a)))] if a else None
-        return {"static_frames_per_s": static, "mutating_frames_per_s": frames / dt, "ratio": frames / dt / static, "batches_applied": applied,
+        return {"commit_call_ms_p50": pct(lat_commit, 0.5), "commit_call_ms_p99": pct(lat_commit, 0.99),
+                "first_block_ms_p50": pct(lat_block, 0.5), "first_block_ms_p99": pct(lat_block, 0.99),
+                "static_frames_per_s": static, "mutating_frames_per_s": frames / dt, "ratio": frames / dt / static, "batches_applied": applied,
                 "commit_to_first_block_ms_p50": pct(lat, 0.5), "commit_to_first_block_ms_p99": pct(lat, 0.99)}
 
     def drive_two_threads(rt, seconds):
@@ -271,6 +275,8 @@ def c5(args):
             done.set()
         th = threading.Thread(target=control)
         import gc as _gc
+        import sys as _sys
+        _sys.setswitchinterval(1e-4)               # (CPython hands the GIL over every 5 ms by default: that, not the engine, would be the tail)
         _gc.collect(); _gc.disable()
         th.start()
         busy = render_for(seconds + 1.0, stop=done)

@@ -997,7 +997,8 @@ int Engine::commit(std::unique_lock<std::mutex>& renderLock) {   // Runtime.h:20
         // mc.capture: the reference (re)creates the node's multi-channel ring whenever a render sequence that holds it is pushed
         // (GraphRenderSequence.h:165-169 sets `_internal:numChildren`, mc/Capture.h:21-31 allocates children - 1 channels of
         // bitceil(sr) frames): unread samples are dropped, the change detector and the relay flag live on
-        for (int32_t id : p->nodeIds) {
+        bool ringsReset = false;
+        for (int32_t id : p->mcCaptureIds) {
             auto it = nodes.find(id);
             if (it == nodes.end() || it->second.op != OP_CAPTURE || !it->second.mc) continue;
             Node& n = it->second;
@@ -1012,7 +1013,11 @@ int Engine::commit(std::unique_lock<std::mutex>& renderLock) {   // Runtime.h:20
             writeParam(n, rec::CAP_MASK, (uint32_t)(cap - 1));
             writeParam(n, rec::CAP_CHANS, (uint32_t)chans);
             writeParam(n, rec::CAP_WRITE, 0u); writeParam(n, rec::CAP_READ, 0u);
+            ringsReset = true;
         }
+        // (the reference drops the unread samples when the sequence is PUSHED, not when it is first rendered: an event poll between
+        //  this commit and the next block finds the new ring empty — the resets go to the device now, behind the blocks in flight)
+        if (ringsReset && !dry) { const int rc = flushPending(); if (rc != kOk) return rc; }
         pending = p;
         shouldRebuild = false;
         st.plansBuilt++;
@@ -1415,11 +1420,20 @@ int Engine::flushPending() {
             while (j < freshRecs.size() && freshRecs[j] == freshRecs[j - 1] + 1) ++j;
             const uint32_t first = freshRecs[i];
             const size_t count = j - i;
-            HIP_WARN(hipMemcpyAsync(dRecs + (size_t)first * kRecDwords, shadow.data() + (size_t)first * kRecDwords,
-                                    count * kRecDwords * 4, hipMemcpyHostToDevice, stream));
+            // through the pinned staging area the patches use (`shadow` is pageable and changes under the copy otherwise): a new
+            // voice's records reach the device without waiting for the blocks that are still rendering
+            constexpr size_t slotsPerRec = (kRecDwords * 4 + sizeof(Patch) - 1) / sizeof(Patch);
+            size_t done = 0;
+            while (done < count) {
+                if (patchCursor + slotsPerRec > patchCap) { HIP_WARN(hipStreamSynchronize(stream)); patchCursor = 0; }
+                const size_t fit = std::min(count - done, (patchCap - patchCursor) / slotsPerRec);
+                std::memcpy(hPatches + patchCursor, shadow.data() + ((size_t)first + done) * kRecDwords, fit * kRecDwords * 4);
+                HIP_WARN(hipMemcpyAsync(dRecs + ((size_t)first + done) * kRecDwords, hPatches + patchCursor, fit * kRecDwords * 4, hipMemcpyHostToDevice, stream));
+                patchCursor += fit * slotsPerRec;
+                done += fit;
+            }
             i = j;
         }
-        HIP_WARN(hipStreamSynchronize(stream));   // `shadow` is pageable; keep it stable until copied
         for (uint32_t r : freshRecs) freshFlag[r] = 0;
         freshRecs.clear();
     }
@@ -2027,7 +2041,9 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
         if (haveIn) HIP_OK(hipMemcpyAsync(dHbm, inDev + done * nIn * bs, nIn * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
         rc = flushPending();
         if (rc != kOk) return rc;
-        if (graphOk && chunk == G) {
+        // (a plan is captured at its third block-at-a-time chunk: a live graph's plan renders the two blocks of its root fades this
+        //  way, then launch sets take over and the next commit replaces it — a capture would be made and thrown away every time)
+        if (graphOk && chunk == G && (p.graphExec || ++p.blockChunks > 2u)) {
             if (!p.graphExec || p.graphBlocks != (int)G) {
                 if (p.graphExec) { (void)hipGraphExecDestroy(p.graphExec); p.graphExec = nullptr; }
                 hipGraph_t graph = nullptr;

@@ -388,6 +388,7 @@ struct Plan {
         if (!nodeIdsSorted) { std::sort(nodeIds.begin(), nodeIds.end()); nodeIdsSorted = true; }
         return std::binary_search(nodeIds.begin(), nodeIds.end(), id);
     }
+    std::vector<int32_t> mcCaptureIds;     // mc.capture nodes of the sequence (their rings are re-made when it is pushed: Engine::commit)
     double buildUs[6] = {0, 0, 0, 0, 0, 0}; // where the build went: render order, islands, island programs, levels + roots, shapes + tables, upload
     uint32_t numHbmBuffers = kMaxHostIn;       // per block of a launch set: host inputs + exports
     uint32_t numStreamBuffers = 0;             // per slice of the stream ring (specialised kernels; device.h kOpStream)
@@ -424,6 +425,7 @@ struct Plan {
     // captured launch sequence for multi-block offline rendering
     hipGraphExec_t graphExec = nullptr;
     int graphBlocks = 0;
+    uint32_t blockChunks = 0;               // block-at-a-time chunks rendered before the capture
     // elemhip_process of a settled, fully compiled sequence: the launch set of ONE (levels + batch epilogue) as a captured graph
     hipGraphExec_t specGraphExec = nullptr;
     float* specGraphOut = nullptr;          // the output pointer baked into it

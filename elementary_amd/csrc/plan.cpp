@@ -285,6 +285,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 ni.push_back(x);
             }
             planNodeIds.push_back(id);
+            if (node.op == OP_CAPTURE && node.mc) p.mcCaptureIds.push_back(id);
         }
     }
     // (no duplicates: the visit marks are shared by all root sequences, a node belongs to the first sequence that reaches it)
