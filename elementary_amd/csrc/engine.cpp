@@ -1032,11 +1032,22 @@ int Engine::apply(const Value& batch) {   // Runtime.h:170-218
     if (!dry && hipSetDevice(device) != hipSuccess) return kHipError;
     if (!batch.isArray()) return kInvalidInstructionFormat;
     shouldRebuild = false;   // a local in the reference: ACTIVATE_ROOTS and COMMIT must share a batch
+    static const bool applyTiming = std::getenv("ELEMHIP_APPLY_TIMING") != nullptr;   // time per instruction kind of a batch, on stderr
+    double kindUs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    struct Report {
+        const double* us; bool on;
+        ~Report() { if (on) std::fprintf(stderr, "[elemhip] apply: create %.1f delete %.1f append %.1f set %.1f activate %.1f commit %.1f us\n", us[0], us[1], us[2], us[3], us[4], us[5]); }
+    } report{kindUs, applyTiming};
     for (const Value& next : batch.arr) {
         if (!next.isArray()) return kInvalidInstructionFormat;
         const auto& ar = next.arr;
         if (ar.empty() || !ar[0].isNumber()) return kInvalidInstructionFormat;
         const int cmd = (int)ar[0].num;
+        const auto tCmd = applyTiming ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        struct Acc {
+            double* slot; std::chrono::steady_clock::time_point t0; bool on;
+            ~Acc() { if (on) *slot += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+        } acc{&kindUs[(cmd >= 0 && cmd < 6) ? cmd : 7], tCmd, applyTiming};
         int res = kOk;
         static const Value undef;
         auto arg = [&](size_t i) -> const Value& { return i < ar.size() ? ar[i] : undef; };

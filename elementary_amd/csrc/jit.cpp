@@ -21,6 +21,7 @@
 #include <deque>
 #include <fstream>
 #include <thread>
+#include <unordered_set>
 
 #include "build/spec_text.inc"   // kSpecDeviceH, kSpecOpsInc, kSpecInc: the sources as raw string literals
 
@@ -46,6 +47,9 @@ struct Jit::Impl {
     std::condition_variable cv;
     std::unordered_map<std::string, std::shared_ptr<SpecEntry>> entries;   // key -> entry
     std::deque<std::shared_ptr<SpecEntry>> queue;
+    std::unordered_map<uint32_t, std::pair<uint64_t, uint64_t>> prefixHash;   // LDS words -> key hash state behind the fixed part of the source
+    std::string prefixDefs;                                                 // ... under this ELEMHIP_JIT_DEFINES
+    std::unordered_set<std::string> notOnDisk;                             // keys the disk cache was asked about in vain
     std::vector<std::thread> workers;
     bool stop = false;
     static Impl* exitHookTarget;
@@ -155,9 +159,10 @@ Jit::Jit() : impl(new Impl) {}
 Jit::~Jit() { delete impl; }
 void Jit::shutdownAtExit() { impl->shutdown(); }
 
-std::string Jit::fullSource(const std::string& generated, uint32_t ldsWords) {
+// everything in front of the generated text (a function of the LDS size and of ELEMHIP_JIT_DEFINES)
+static std::string sourcePrefix(uint32_t ldsWords, size_t reserveExtra) {
     std::string s;
-    s.reserve(sizeof(kSpecDeviceH) + sizeof(kSpecOpsInc) + sizeof(kSpecInc) + generated.size() + 256);
+    s.reserve(sizeof(kSpecDeviceH) + sizeof(kSpecOpsInc) + sizeof(kSpecInc) + reserveExtra + 256);
     s += "#define ELEMHIP_SPEC 1\n#define ELEMHIP_SPEC_LDS_WORDS " + std::to_string(ldsWords) + "\n";
     if (const char* d = std::getenv("ELEMHIP_JIT_DEFINES")) {   // tuning experiments: "NAME=VALUE NAME2=VALUE2" -> #define lines (part of the cache key)
         std::string t = d, tok;
@@ -171,27 +176,53 @@ std::string Jit::fullSource(const std::string& generated, uint32_t ldsWords) {
     // hiprtc has no host headers: the fixed-width names the sources use (same underlying types as <stdint.h> on this target)
     s += "typedef unsigned char uint8_t; typedef unsigned short uint16_t; typedef unsigned int uint32_t; typedef unsigned long uint64_t;\n"
          "typedef signed char int8_t; typedef short int16_t; typedef int int32_t; typedef long int64_t; typedef unsigned long uintptr_t;\n";
-    s += kSpecDeviceH; s += "\n"; s += kSpecOpsInc; s += "\n"; s += kSpecInc; s += "\n"; s += generated;
+    s += kSpecDeviceH; s += "\n"; s += kSpecOpsInc; s += "\n"; s += kSpecInc; s += "\n";
     return s;
 }
 
-static std::string keyOf(const std::string& versionTag, const std::string& src) {
-    uint64_t h1 = fnv1a(versionTag, 1469598103934665603ull), h2 = fnv1a(versionTag, 0x9E3779B97F4A7C15ull);
-    h1 = fnv1a(src, h1); h2 = fnv1a(src, h2 ^ 0xA5A5A5A5ull);
+std::string Jit::fullSource(const std::string& generated, uint32_t ldsWords) {
+    std::string s = sourcePrefix(ldsWords, generated.size());
+    s += generated;
+    return s;
+}
+
+// The key is a hash of the whole translation unit; its first ~300 KB are the same for every shape of one LDS size, so the hash
+// state behind them is kept (FNV-1a runs front to back: same keys as hashing the full source, a tenth of the time).
+std::string Jit::keyFor(const std::string& generated, uint32_t ldsWords) {
+    const char* d = std::getenv("ELEMHIP_JIT_DEFINES");
+    const std::string defs = d ? d : "";
+    uint64_t h1 = 0, h2 = 0;
+    bool have = false;
+    {
+        std::lock_guard<std::mutex> l(impl->mu);
+        if (impl->prefixDefs == defs) { auto it = impl->prefixHash.find(ldsWords); if (it != impl->prefixHash.end()) { h1 = it->second.first; h2 = it->second.second; have = true; } }
+    }
+    if (!have) {
+        const std::string pre = sourcePrefix(ldsWords, 0);
+        h1 = fnv1a(pre, fnv1a(impl->versionTag, 1469598103934665603ull));
+        h2 = fnv1a(pre, fnv1a(impl->versionTag, 0x9E3779B97F4A7C15ull) ^ 0xA5A5A5A5ull);
+        std::lock_guard<std::mutex> l(impl->mu);
+        if (impl->prefixDefs != defs) { impl->prefixHash.clear(); impl->prefixDefs = defs; }
+        impl->prefixHash[ldsWords] = {h1, h2};
+    }
+    h1 = fnv1a(generated, h1); h2 = fnv1a(generated, h2);
     char key[40];
     std::snprintf(key, sizeof key, "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
     return key;
 }
 
-std::string Jit::keyFor(const std::string& generated, uint32_t ldsWords) { return keyOf(impl->versionTag, fullSource(generated, ldsWords)); }
-
 bool Jit::knownKey(const std::string& key) {
     {
         std::lock_guard<std::mutex> l(impl->mu);
         if (impl->entries.count(key)) return true;
+        if (impl->notOnDisk.count(key)) return false;
     }
+    // (asked on every re-plan of a live graph for the one-island shapes of a voice that is fading out: the answer from the
+    //  file system — 100 us and more on a network mount — is remembered; a key that gets compiled later is found in `entries`)
     struct stat st;
-    return ::stat((impl->cacheDir + "/" + key + ".hsaco").c_str(), &st) == 0;
+    const bool there = ::stat((impl->cacheDir + "/" + key + ".hsaco").c_str(), &st) == 0;
+    if (!there) { std::lock_guard<std::mutex> l(impl->mu); if (impl->notOnDisk.size() > 4096) impl->notOnDisk.clear(); impl->notOnDisk.insert(key); }
+    return there;
 }
 bool Jit::known(const std::string& generated, uint32_t ldsWords) { return knownKey(keyFor(generated, ldsWords)); }
 
