@@ -167,8 +167,10 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
     for (uint32_t w = 0; w < kWaves; ++w) o << (w ? ", " : "") << waveSlots[w];
     o << "};\n};\n} // namespace gen\n";
     o << "extern \"C\" __global__ __launch_bounds__(512) void elemhip_spec_island(PlanView pv, uint32_t* recs, float* hbm, const Globals* g,\n"
-         "        const uint32_t* lcg, const uint32_t* islandList, uint32_t batch, uint32_t arenaFloats, uint32_t streamBase, uint32_t streamSlice) {\n"
-         "    spec_island_main<gen::P>(pv, recs, hbm, g, lcg, islandList, batch, arenaFloats, streamBase, streamSlice);\n}\n";
+         "        const uint32_t* lcg, const uint32_t* islandList, uint32_t batch, uint32_t arenaFloats, uint32_t streamBase, uint32_t streamSlice,\n"
+         "        uint32_t epiGroups, float* epiOut) {\n"
+         "    spec_island_main<gen::P>(pv, recs, hbm, g, lcg, islandList, batch, arenaFloats, streamBase, streamSlice);\n"
+         "    spec_epilogue_tail(pv, recs, hbm, g, epiGroups, epiOut);\n}\n";
     return o.str();
 }
 

@@ -218,6 +218,8 @@ struct Globals {
     uint64_t trace;        // debug: device pointer to a per-task timestamp log for workgroup 0 of every launch, or 0
     uint64_t inRing;       // multi-block path: device pointer to [inBlocks][numIn][blockStride] host-input blocks; the
                            // epilogue stages the NEXT block's inputs into arena buffers 0..numIn-1 (0 = host copies them)
+    uint32_t epiTicket;    // fused epilogue (island_spec.inc spec_epilogue_tail): workgroups of the last level that have finished
+    uint32_t pad_;
 };
 
 // Device view of a compiled plan (all pointers are device pointers).

@@ -1379,6 +1379,7 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
     if (key == "host_out_direct") { hostOutDirect = value != 0; return kOk; }   // elemhip_process: epilogue writes the pinned host block itself
     if (key == "conv_mfma") { convMfma = std::max(0, std::min(2, (int)value)); return kOk; }   // partition MAC of launch sets: 1 matrix cores (default), 0 packed vector FMAs
+    if (key == "fuse_epilogue") { fuseEpilogue = value != 0; dropGraphs(); return kOk; }
     if (key == "spec_block_graph") { specBlockGraph = value != 0; dropGraphs(); return kOk; }   // elemhip_process: replay the launch set of one from a hipGraph
     if (key == "spec_blocks") { specBlocks = value != 0; return kOk; }      // elemhip_process through the specialised kernels when it can
     if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(1024, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
@@ -1865,9 +1866,9 @@ int Engine::launchProfile(double* msOut, size_t cap, uint64_t* launchSets, uint6
 // One launch level of a multi-block launch. When every island shape of the level has its specialised kernel compiled
 // (jit.cpp) the level runs as one launch per shape plus an interpreter launch for the islands no shape covers
 // (stateless mixers and roots); until then the whole level goes through the interpreter kernel.
-void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t arenaFloats) {
+bool Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t arenaFloats, float* epiOut) {
     const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
-    if (e <= b) return;
+    if (e <= b) return false;
     bool spec = specialize != 0 && !p.shapes.empty();
     std::vector<std::pair<hipFunction_t, const Plan::SpecShape*>> fns;   // function null: the shape is not compiled (yet)
     if (spec) {
@@ -1880,13 +1881,14 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         }
         if (!any) spec = false;
     }
-    if (!spec) { launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats, statelessRows); debugSync("set: interpreter level", (unsigned)l, batch); return; }
+    if (!spec) { launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats, statelessRows); debugSync("set: interpreter level", (unsigned)l, batch); return false; }
     // The launches of one level are independent of each other (different islands): with more than one they go to side
     // streams forked from / joined to the engine's stream, so two shapes of 64 islands each fill 128 CUs at once
     // instead of 64 CUs twice.
     const uint32_t rb = p.restOffsets[l], re = p.restOffsets[l + 1];
     const size_t launches = fns.size() + (re > rb ? 1 : 0);
     const bool fork = launches > 1;
+    const bool fused = epiOut != nullptr && batch == 1u && launches == 1 && fns.size() == 1 && fns[0].first != nullptr;
     if (fork) {
         while (auxStreams.size() < launches - 1) {
             hipStream_t s2 = nullptr; hipEvent_t ev = nullptr;
@@ -1924,7 +1926,9 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         const uint32_t* list = p.dSpecLists + f.second->listBegin;
         // the stream ring sits behind the `batch` block slices of this launch set
         uint32_t bt = batch, af = arenaFloats, sb = batch * arenaFloats, ss = p.numStreamBuffers * (uint32_t)blockSize;
-        void* args[] = {&pv, &recs, &hbm, &g, &lcg, &list, &bt, &af, &sb, &ss};
+        uint32_t eg = fused ? f.second->count : 0u;
+        float* eo = fused ? epiOut : nullptr;
+        void* args[] = {&pv, &recs, &hbm, &g, &lcg, &list, &bt, &af, &sb, &ss, &eg, &eo};
         const uint32_t gy = f.second->stateless ? std::max(1u, std::min(batch, statelessRows)) : 1u;
         HIP_WARN(hipModuleLaunchKernel(f.first, f.second->count, gy, 1, kThreads, 1, 1, 0, st_, args, nullptr));
         st.specLaunches++;
@@ -1942,6 +1946,7 @@ void Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
             HIP_WARN(hipStreamWaitEvent(stream, auxDone[i - 1], 0));
         }
     }
+    return fused;
 }
 
 // the convolve nodes of level l over a whole launch set: four launches (fft, mac, ifft, finish: conv.hip, "multi-block launches")
@@ -1958,16 +1963,20 @@ void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
     const uint32_t arenaFloats = p.numHbmBuffers * (uint32_t)blockSize;
     const size_t L = p.levelOffsets.size() - 1;
     const bool prof = profileLaunches;
+    // a launch set of ONE block (elemhip_process): the last level's kernel ends with the epilogue when it can (spec_epilogue_tail)
+    const bool mayFuse = fuseEpilogue && batch == 1u && L > 0 && p.convs.empty() && p.taps.empty() && p.roots.size() <= 32 && !debugSyncOn();
+    bool fused = false;
     for (size_t l = 0; l < L; ++l) {
         const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
         if (e <= b && p.convLevelOffsets[l + 1] <= p.convLevelOffsets[l]) continue;
         if (prof) (void)hipEventRecord(profEvent(), stream);
-        launchLevelBatch(p, l, batch, arenaFloats);
+        fused = launchLevelBatch(p, l, batch, arenaFloats, (mayFuse && l + 1 == L) ? outRing : nullptr);
         launchConvolveBatch(p, l, batch, arenaFloats);
         if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)l); }
     }
     if (prof) (void)hipEventRecord(profEvent(), stream);
-    launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, outRing, batch, arenaFloats);
+    if (!fused) launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, outRing, batch, arenaFloats);
+    else st.fusedEpilogues++;
     debugSync("set: epilogue", batch);
     if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)L); profSets++; profBlocks += batch; }
 }

@@ -139,6 +139,7 @@ struct Stats {
     double   lastPlanBuildMs = 0.0;
     uint32_t numIslands = 0, numLevels = 0, numTasks = 0, numNodesInPlan = 0, maxLdsBytes = 0, numHbmBuffers = 0;
     uint64_t graphReplays = 0, graphCaptures = 0, batchLaunches = 0;
+    uint64_t fusedEpilogues = 0;         // launch sets of one whose last level kernel ran the epilogue
     uint64_t progHeaps = 0;              // program heaps started (1 = the first still serves)
     uint64_t planIslandsReused = 0, planIslandsScheduled = 0, planCacheMismatches = 0;   // island program cache (plan.cpp)
     uint64_t specLaunches = 0;             // launches of run-time specialised island kernels
@@ -281,6 +282,7 @@ private:
     bool hostOutDirect = true;             // process(): the epilogue kernel writes into the mapped pinned output block
     uint32_t convMinP = 0xFFFFFFFFu, convMaxP = 0;   // fewest / most partitions of any impulse response set so far
     int convMfma = 1;                      // conv.hip elemhip_convolve_batch_mac: 1 v_mfma_f32_4x4x1_16B_f32 Toeplitz tiles, 0 v_pk_fma_f32 (r03)
+    bool fuseEpilogue = true;              // option "fuse_epilogue": elemhip_process' launch set of one ends in the last level's kernel (no epilogue launch)
     bool specBlockGraph = false;           // option "spec_block_graph": replay elemhip_process' launch set of one from a captured hipGraph
     bool specBlocks = true;                // process(): whole blocks of a settled, fully compiled sequence use the specialised kernels
     int  batchBlocks = 64;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)
@@ -340,7 +342,9 @@ private:
     int  renderHostNodes(const Plan& p, size_t level);   // call-out nodes of one launch level (synchronises the stream)
     void enqueueBatch(const Plan& p, uint32_t batch, float* outRing = nullptr);
     void launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32_t arenaFloats);
-    void launchLevelBatch(const Plan& p, size_t level, uint32_t batch, uint32_t arenaFloats);   // specialised kernels when ready, else the interpreter
+    // specialised kernels when ready, else the interpreter. `epiOut` non-null: if the level is one specialised launch, let its last
+    // workgroup run the epilogue into `epiOut` (island_spec.inc spec_epilogue_tail); returns whether it will
+    bool launchLevelBatch(const Plan& p, size_t level, uint32_t batch, uint32_t arenaFloats, float* epiOut = nullptr);
     bool batchEligible(const Plan& p, size_t nOut, bool oneBlock = false) const;
     bool specReady(const Plan& p) const;
     void mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn);

@@ -1743,7 +1743,7 @@ std::string Engine::describePlan() {
     auto kv = [&](const char* k, uint64_t v, bool comma = true) { s += "\"" + std::string(k) + "\":" + std::to_string(v) + (comma ? "," : ""); };
     kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.numTasks);
     kv("num_members", p.numMembers); kv("num_operands", p.numOperands); kv("num_nodes", p.nodeIds.size());
-    kv("plan_prog_heaps", st.progHeaps); kv("plan_prog_heap_used_dwords", p.progHeap ? p.progHeap->usedDwords : 0);
+    kv("plan_fused_epilogues", st.fusedEpilogues); kv("plan_prog_heaps", st.progHeaps); kv("plan_prog_heap_used_dwords", p.progHeap ? p.progHeap->usedDwords : 0);
     kv("plan_islands_reused", st.planIslandsReused); kv("plan_islands_scheduled", st.planIslandsScheduled); kv("plan_cache_mismatches", st.planCacheMismatches);
     kv("num_hbm_buffers", p.numHbmBuffers); kv("num_stream_buffers", p.numStreamBuffers); kv("pack_k", p.packK);
     kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());

@@ -200,3 +200,51 @@ def test_process_uses_the_specialised_kernels_block_by_block(gpu_required, voice
             before = a.stats()["spec_launches"]
     assert before is not None and a.stats()["spec_launches"] >= before + 19        # blocks 31..39 and 42..51
     assert b.stats()["spec_launches"] == 0
+
+
+def _fuse_graphs():
+    x = el.in_({"channel": 0})
+    six_roots = [el.mul(0.1 * (k + 1), el.cycle(110.0 * (k + 1))) for k in range(6)]     # (render() roots: channel = position)
+    return {
+        "c1": (graphs.C1_SAMPLE_RATE, graphs.c1_graph, 0),
+        "c2x16": (graphs.C2_SAMPLE_RATE, lambda: graphs.c2_graph(voices=16), 0),
+        "six_channels": (44100.0, lambda: six_roots, 0),
+        "filters_on_input": (44100.0, lambda: [el.lowpass(800.0, 1.2, x), el.add(el.pole(0.99, x), el.mul(0.3, el.cycle(330.0)))], 1),
+    }
+
+
+@pytest.mark.parametrize("name", ["c1", "c2x16", "six_channels", "filters_on_input"])
+def test_fused_epilogue_of_a_single_block_call(gpu_required, name):
+    """elemhip_process on a settled, fully compiled sequence: the last level's kernel ends with the epilogue (its last workgroup
+    sums the output bus and advances the clock: island_spec.inc spec_epilogue_tail) instead of a launch of its own. Same adds in
+    the same order: bit-identical to the separate epilogue launch, <= 1e-6 from the reference engine; a re-render in the middle
+    (root fades: the engine falls back to block-at-a-time until they settle) and a different output count are part of the run."""
+    from elementary_amd.runtime import Runtime
+    sr, mk, n_in = _fuse_graphs()[name]
+    roots = mk()
+    n_out = len(roots)
+    outs = {}
+    for fuse in (1, 0):
+        rt = Runtime(sr, 512, device=0)
+        rt.set_option("specialize", 2); rt.set_option("fuse_epilogue", fuse)
+        assert rt.render(*roots)["result"] == 0
+        ys = []
+        for k in range(40):
+            xin = np.stack([lcg_noise(512, 11 + k, 0.5)]) if n_in else None
+            if k == 22:
+                assert rt.render(*roots[::-1])["result"] == 0          # roots swap channels: old ones fade out, new ones fade in
+            ys.append(rt.process(xin, n_out + (1 if 30 <= k < 34 else 0), 512)[:n_out])
+        outs[fuse] = np.stack(ys)
+        fused = rt.describe_plan()["plan_fused_epilogues"]
+        assert (fused >= 20) if fuse else (fused == 0), fused
+    assert np.array_equal(outs[1], outs[0])
+    c = _checker(sr, 512)
+    assert c.render(*roots)["result"] == 0
+    ref = []
+    for k in range(40):
+        xin = np.stack([lcg_noise(512, 11 + k, 0.5)]) if n_in else None
+        if k == 22:
+            assert c.render(*roots[::-1])["result"] == 0
+        ref.append(c.process(xin, n_out + (1 if 30 <= k < 34 else 0), 512)[:n_out])
+    ref = np.stack(ref)
+    assert float(np.abs(outs[1] - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))

@@ -12,15 +12,18 @@ import torch  # noqa: F401
 from elementary_amd import graphs
 from elementary_amd.runtime import Runtime
 
-voices = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+which = sys.argv[1] if len(sys.argv) > 1 else "256"     # a voice count of the C2 graph, "c1" (cli/Benchmark graph) or "floor" (a constant per channel)
+voices = int(which) if which.isdigit() else which
 blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 for spec_blocks, direct, graph in ((0, 1, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1)):
-    rt = Runtime(graphs.C2_SAMPLE_RATE, 512, device=0)
+    rt = Runtime(graphs.C1_SAMPLE_RATE if which == "c1" else graphs.C2_SAMPLE_RATE, 512, device=0)
     rt.set_option("specialize", 2)
     rt.set_option("spec_blocks", spec_blocks)
     rt.set_option("host_out_direct", direct)
     rt.set_option("spec_block_graph", graph)
-    assert rt.render(*graphs.c2_graph(voices=voices))["result"] == 0
+    from elementary_amd import el
+    roots = graphs.c1_graph() if which == "c1" else [el.const({"value": 0.25}), el.const({"value": 0.5})] if which == "floor" else graphs.c2_graph(voices=voices)
+    assert rt.render(*roots)["result"] == 0
     for _ in range(60):
         rt.process(None, 2, 512)
     ts = []

@@ -62,6 +62,10 @@ def main():
         for name, case in sorted(test_gpu_taps.CASES.items()):
             if not case[2]: jobs.append((f"taps_{name}", 44100.0, 512, case[0](), None, None))
         jobs.append(("tap_loop_bench", 48000.0, 512, tap_soak._bench_graph(), None, None))
+        import test_gpu_spec                              # tests/test_gpu_spec.py::test_fused_epilogue_of_a_single_block_call
+        for name, (sr, mk, _n_in) in sorted(test_gpu_spec._fuse_graphs().items()):
+            jobs.append((f"fuse_{name}", sr, 512, mk(), None, None))
+            jobs.append((f"fuse_{name}_swapped", sr, 512, mk()[::-1], None, None))
         for copies in (1, 3, 6):
             jobs.append((f"stateful_d{copies}", 48000.0, 512, every_stateful_roots(), None, copies))
     if len(sys.argv) > 2:      # "i/n": this process takes every n-th job (several processes warm the cache in parallel)
