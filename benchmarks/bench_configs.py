@@ -67,6 +67,28 @@ def _time_gpu(rt, n_in, n_out, blocks, xin=None, chunk=256):
     return dt
 
 
+def _native_host(roots, sr, blocks=4000, env=None):
+    """The reference's cli/Benchmark.cpp protocol on a native host: examples/bench_cli (C++ over the facade, no Python, no HIP on
+    its side of the C-ABI) renders `roots` with one synchronous process() call per 512-frame block."""
+    import json
+    import subprocess
+    import tempfile
+    from elementary_amd.reconciler import Renderer, batch_to_json
+    exe = os.path.join(ROOT, "examples", "bench_cli")
+    if not os.path.exists(exe):
+        return None
+    sent = []
+    Renderer(lambda b: sent.append(b) or 0).render(*roots)
+    with tempfile.TemporaryDirectory() as d:
+        bpath = os.path.join(d, "batch.json")
+        open(bpath, "w").write(batch_to_json(sent[0]))
+        res = subprocess.run([exe, bpath, str(blocks), str(sr)], capture_output=True, text=True, timeout=300, env=dict(os.environ, **(env or {})))
+    if res.returncode != 0:
+        return {"error": res.stderr[-300:]}
+    line = [l for l in res.stderr.splitlines() if l.startswith("{")]
+    return json.loads(line[-1]) if line else None
+
+
 def c1(args):
     from elementary_amd import graphs
     from elementary_amd.runtime import Runtime
@@ -80,7 +102,9 @@ def c1(args):
     lv = rt.time_launches(2, 200)
     return {"config": "C1 cli/Benchmark graph (18 nodes, sr 44100)", "gpu_us_per_block": 1e6 * g, "gpu_samples_per_s": BLOCK / g,
             "cpu_us_per_block": 1e6 * c, "cpu_kind": kind, "cpu_blocks_timed": m, "speedup": c / g,
-            "launch_us": [1e3 * v for v in lv], "note": "latency-bound: one serial phasor -> svf chain per channel"}
+            "launch_us": [1e3 * v for v in lv], "note": "latency-bound: one serial phasor -> svf chain per channel",
+            "native_host_process_call": _native_host(graphs.c1_graph(), 44100.0, env={"ELEMHIP_SPECIALIZE": "2"}),
+            "native_host_process_call_c2_256_voices": _native_host(graphs.c2_graph(), graphs.C2_SAMPLE_RATE, env={"ELEMHIP_SPECIALIZE": "2"})}
 
 
 def c3(args):

@@ -127,6 +127,7 @@ struct ProgHeap {
 struct IslandProgram {
     Island I;                            // progBegin / rootRec are re-made per plan
     std::vector<uint32_t> blob;          // host copy of the program (16-byte padded): describePlan, plan_cache = 2
+    std::vector<uint32_t> members;       // (node id, opcode, record, arena buffer) of every member in render order: checked on a cache hit (the key is a hash)
     std::shared_ptr<ProgHeap> heap;      // where the device copy lives ...
     uint32_t heapBegin = 0;              // ... as a dword offset (= Island::progBegin of every plan that uses it)
     std::shared_ptr<SpecText> spec;      // specialised-kernel text of its shape (null: none)
@@ -282,7 +283,8 @@ private:
     bool hostOutDirect = true;             // process(): the epilogue kernel writes into the mapped pinned output block
     uint32_t convMinP = 0xFFFFFFFFu, convMaxP = 0;   // fewest / most partitions of any impulse response set so far
     int convMfma = 1;                      // conv.hip elemhip_convolve_batch_mac: 1 v_mfma_f32_4x4x1_16B_f32 Toeplitz tiles, 0 v_pk_fma_f32 (r03)
-    bool fuseEpilogue = true;              // option "fuse_epilogue": elemhip_process' launch set of one ends in the last level's kernel (no epilogue launch)
+    bool fuseEpilogue = false;             // option "fuse_epilogue": elemhip_process' launch set of one ends in the last level's kernel (no epilogue launch);
+                                           // measured break-even (the ticket's release / acquire costs what the dependent launch did): off
     bool specBlockGraph = false;           // option "spec_block_graph": replay elemhip_process' launch set of one from a captured hipGraph
     bool specBlocks = true;                // process(): whole blocks of a settled, fully compiled sequence use the specialised kernels
     int  batchBlocks = 64;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)

@@ -690,7 +690,16 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             }
             ikey = h;
             auto it = e.islandCache.find(ikey);
-            if (it != e.islandCache.end() && it->second->heap == e.progHeap) cached = it->second;
+            if (it != e.islandCache.end() && it->second->heap == e.progHeap) {
+                // the key is 64 bits of hash: a hit is only taken when the members it was built from are the members in front of us
+                const std::vector<uint32_t>& m = it->second->members;
+                bool same = m.size() == 4 * B.nodes.size();
+                for (size_t q = 0; same && q < B.nodes.size(); ++q) {
+                    const NI& x = ni[B.nodes[q]];
+                    same = m[4 * q] == (uint32_t)x.n->id && m[4 * q + 1] == ((uint32_t)x.n->op | (x.ch << 16)) && m[4 * q + 2] == x.rec && m[4 * q + 3] == x.hbm;
+                }
+                if (same) cached = it->second; else e.st.planCacheMismatches++;
+            }
             if (cached && e.planCache == 1) {
                 I = cached->I;
                 I.progBegin = cached->heapBegin;          // the program is on the device already
@@ -1485,6 +1494,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             auto ent = std::make_shared<IslandProgram>();
             ent->I = I;
             ent->blob.assign(p.prog.begin() + I.progBegin, p.prog.end());
+            ent->members.reserve(4 * B.nodes.size());
+            for (int k : B.nodes) { const NI& x = ni[k]; ent->members.insert(ent->members.end(), {(uint32_t)x.n->id, (uint32_t)x.n->op | (x.ch << 16), x.rec, x.hbm}); }
             p.islandProg[ii] = ent; scheduled.push_back((uint32_t)ii);
             p.progDwordsTotal += ent->blob.size();
             if (ii < p.specText.size()) ent->spec = p.specText[ii];

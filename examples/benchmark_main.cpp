@@ -6,6 +6,7 @@
 //
 //   g++ -std=c++17 -O2 -Iinclude examples/benchmark_main.cpp -Lelementary_amd -lelemhip -Wl,-rpath,$PWD/elementary_amd -o examples/bench_cli
 // (`make -C elementary_amd/csrc` builds it; tests/test_gpu_parity.py::test_cli_benchmark_host runs it on the GPU box)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -39,6 +40,13 @@ int main(int argc, char** argv) {
         deltas.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());   // ns resolution, not truncated
     }
     const double sum = std::accumulate(deltas.begin(), deltas.end(), 0.0);
+    {   // + the distribution, as one JSON line on stderr (benchmarks/bench_configs.py c1 reads it)
+        std::vector<double> sorted(deltas);
+        std::sort(sorted.begin(), sorted.end());
+        auto pct = [&](double q) { return sorted.empty() ? 0.0 : sorted[std::min(sorted.size() - 1, (size_t)(q * (double)sorted.size()))]; };
+        std::fprintf(stderr, "{\"host\": \"native C++ over include/elemhip/Runtime.hpp\", \"blocks\": %zu, \"us_mean\": %.3f, \"us_p50\": %.3f, \"us_p99\": %.3f, \"us_max\": %.3f}\n",
+                     deltas.size(), sum / (double)std::max<size_t>(1, deltas.size()), pct(0.5), pct(0.99), sorted.empty() ? 0.0 : sorted.back());
+    }
     if (argc > 4) {   // the last rendered block (2 x 512 floats), for a checker
         std::ofstream o(argv[4], std::ios::binary);
         for (auto& c : scratch) o.write(reinterpret_cast<const char*>(c.data()), 512 * sizeof(float));
