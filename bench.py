@@ -526,6 +526,17 @@ def main() -> None:
         for _ in range(200):
             rt.process(None, 2, BLOCK)
         sync_us = 1e6 * (time.perf_counter() - t1) / 200
+        # the same call from a native host (examples/bench_cli: the reference's cli/Benchmark.cpp protocol, C++ over the C-ABI, no
+        # Python between the calls), rank 0 only, outside the timed region
+        sync_native = None
+        if rank == 0:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+                import bench_configs as _bc
+                sync_native = _bc._native_host(graphs.c2_graph(voices=my_voices, channels=2, first_voice=first), graphs.C2_SAMPLE_RATE, blocks=2000,
+                                               env={"ELEMHIP_SPECIALIZE": "2"})
+            except Exception as e:      # noqa: BLE001  (a missing binary is reported, not fatal)
+                sync_native = {"error": str(e)[:200]}
 
         out = {
             "metric": "audio samples/sec (48kHz-equiv), 4107-node/256-voice synth graph, blockSize=512",
@@ -573,6 +584,7 @@ def main() -> None:
             "realtime_factor_48k": value / 48000.0,
             "plan_build_ms": build_ms,
             "sync_process_us_per_block": sync_us,
+            "sync_process_native_host": sync_native,
             "device_resident": device_resident,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
