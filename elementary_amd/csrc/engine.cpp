@@ -1379,6 +1379,7 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
     if (key == "host_out_direct") { hostOutDirect = value != 0; return kOk; }   // elemhip_process: epilogue writes the pinned host block itself
     if (key == "conv_mfma") { convMfma = std::max(0, std::min(2, (int)value)); return kOk; }   // partition MAC of launch sets: 1 matrix cores (default), 0 packed vector FMAs
+    if (key == "skip_idle_launches") { skipIdleLaunches = value != 0; dropGraphs(); return kOk; }
     if (key == "fuse_epilogue") { fuseEpilogue = value != 0; dropGraphs(); return kOk; }
     if (key == "spec_block_graph") { specBlockGraph = value != 0; dropGraphs(); return kOk; }   // elemhip_process: replay the launch set of one from a hipGraph
     if (key == "spec_blocks") { specBlocks = value != 0; return kOk; }      // elemhip_process through the specialised kernels when it can
@@ -1654,7 +1655,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     if (specBlock && specBlockGraph && useGraph && !profileLaunches && !debugSyncOn()) {
         // the launch set of one (level launches, side-stream forks and joins, batch epilogue) replayed from a captured graph
         float* const target = outDev ? outDev : dOutRing;
-        if (!p.specGraphExec || p.specGraphOut != target) {
+        if (!p.specGraphExec || p.specGraphOut != target || p.specGraphNumOut != (uint32_t)nOut) {   // (which launches are left out depends on the output count)
             if (p.specGraphExec) { (void)hipGraphExecDestroy(p.specGraphExec); p.specGraphExec = nullptr; }
             hipGraph_t graph = nullptr;
             HIP_OK(hipStreamSynchronize(stream));
@@ -1664,7 +1665,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
             HIP_OK(hipStreamEndCapture(stream, &graph));
             HIP_OK(hipGraphInstantiate(&p.specGraphExec, graph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(graph);
-            p.specGraphOut = target; p.specGraphLaunches = (uint32_t)(st.specLaunches - before);
+            p.specGraphOut = target; p.specGraphNumOut = (uint32_t)nOut; p.specGraphLaunches = (uint32_t)(st.specLaunches - before);
             st.specLaunches = before;
             st.graphCaptures++;
         }
@@ -1804,6 +1805,17 @@ bool Engine::specReady(const Plan& p) const {
     return true;
 }
 
+bool Engine::anyRootRuns(const std::vector<int32_t>& rootIds, size_t nOut) const {
+    for (int32_t id : rootIds) {
+        auto it = nodes.find(id);
+        if (it == nodes.end()) return true;          // (cannot tell: launch)
+        const Node& r = it->second;
+        const bool on = r.target > 0.5f, settled = std::fabs(r.target - r.gain) <= 1e-6f;
+        if ((on || !settled) && r.channel >= 0 && (uint32_t)r.channel < nOut) return true;
+    }
+    return false;
+}
+
 // (oneBlock: a launch set of ONE — the batch epilogue promotes the taps after it like the per-block epilogue does, so tap
 // pairs that do not sit in one island are no obstacle)
 bool Engine::batchEligible(const Plan& p, size_t nOut, bool oneBlock) const {
@@ -1877,6 +1889,11 @@ bool Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
             if (sh.level != (uint32_t)l) continue;
             hipFunction_t fn = sh.entry->function(device);
             any = any || fn != nullptr;
+            // A launch whose islands all belong to roots that do not run (a replaced root once its fade-out has settled stays in
+            // the plan until the next commit) would start workgroups that return at once — and, as a second launch of its
+            // level, cost a fork to a side stream and a join. The host mirrors the root fades (mirrorRootFades), and launch
+            // sets are only rendered while every running root's fade is settled: what runs does not change inside a set.
+            if (skipIdleLaunches && !anyRootRuns(sh.roots, hGlobals.numOut)) { st.idleLaunchesSkipped++; continue; }
             fns.emplace_back(fn, &sh);
         }
         if (!any) spec = false;
@@ -1885,8 +1902,10 @@ bool Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
     // The launches of one level are independent of each other (different islands): with more than one they go to side
     // streams forked from / joined to the engine's stream, so two shapes of 64 islands each fill 128 CUs at once
     // instead of 64 CUs twice.
-    const uint32_t rb = p.restOffsets[l], re = p.restOffsets[l + 1];
+    uint32_t rb = p.restOffsets[l], re = p.restOffsets[l + 1];
+    if (re > rb && skipIdleLaunches && l < p.restRoots.size() && !anyRootRuns(p.restRoots[l], hGlobals.numOut)) { re = rb; st.idleLaunchesSkipped++; }
     const size_t launches = fns.size() + (re > rb ? 1 : 0);
+    if (launches == 0) return false;
     const bool fork = launches > 1;
     const bool fused = epiOut != nullptr && batch == 1u && launches == 1 && fns.size() == 1 && fns[0].first != nullptr;
     if (fork) {

@@ -140,6 +140,7 @@ struct Stats {
     double   lastPlanBuildMs = 0.0;
     uint32_t numIslands = 0, numLevels = 0, numTasks = 0, numNodesInPlan = 0, maxLdsBytes = 0, numHbmBuffers = 0;
     uint64_t graphReplays = 0, graphCaptures = 0, batchLaunches = 0;
+    uint64_t idleLaunchesSkipped = 0;    // launches left out because no root of their islands ran
     uint64_t fusedEpilogues = 0;         // launch sets of one whose last level kernel ran the epilogue
     uint64_t progHeaps = 0;              // program heaps started (1 = the first still serves)
     uint64_t planIslandsReused = 0, planIslandsScheduled = 0, planCacheMismatches = 0;   // island program cache (plan.cpp)
@@ -283,6 +284,7 @@ private:
     bool hostOutDirect = true;             // process(): the epilogue kernel writes into the mapped pinned output block
     uint32_t convMinP = 0xFFFFFFFFu, convMaxP = 0;   // fewest / most partitions of any impulse response set so far
     int convMfma = 1;                      // conv.hip elemhip_convolve_batch_mac: 1 v_mfma_f32_4x4x1_16B_f32 Toeplitz tiles, 0 v_pk_fma_f32 (r03)
+    bool skipIdleLaunches = true;          // option "skip_idle_launches": launches of a level whose islands all belong to roots that do not run are left out
     bool fuseEpilogue = false;             // option "fuse_epilogue": elemhip_process' launch set of one ends in the last level's kernel (no epilogue launch);
                                            // measured break-even (the ticket's release / acquire costs what the dependent launch did): off
     bool specBlockGraph = false;           // option "spec_block_graph": replay elemhip_process' launch set of one from a captured hipGraph
@@ -349,6 +351,7 @@ private:
     bool launchLevelBatch(const Plan& p, size_t level, uint32_t batch, uint32_t arenaFloats, float* epiOut = nullptr);
     bool batchEligible(const Plan& p, size_t nOut, bool oneBlock = false) const;
     bool specReady(const Plan& p) const;
+    bool anyRootRuns(const std::vector<int32_t>& rootIds, size_t nOut) const;   // host mirror of spec_root_running (Core.h:28-31, GraphRenderSequence.h:214-219)
     void mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn);
     int  setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime);
     void setInRing(const float* ring, uint32_t blocks);
@@ -388,6 +391,8 @@ struct Plan {
     std::vector<uint32_t> convLevelOffsets; // numLevels + 1
     std::vector<int32_t> rootIds;          // same order as `roots`
     std::vector<uint32_t> islandLevel;     // launch level of each island
+    std::vector<int32_t> islandRoot;       // node id of the root whose sequence owns the island (packed islands: of the head island)
+    std::vector<std::vector<int32_t>> restRoots;   // per level: the roots that own the islands of the interpreter launch (launchLevelBatch skips idle launches)
     mutable std::vector<int32_t> nodeIds;  // every node the render sequence references (gc); sorted by the first holdsNode (gc is rare, a build is not)
     mutable bool nodeIdsSorted = false;
     bool holdsNode(int32_t id) const {
@@ -420,6 +425,7 @@ struct Plan {
         uint32_t level = 0;
         uint32_t listBegin = 0, count = 0;     // its workgroups: specLists[listBegin, listBegin + count) (island | split part << 24)
         bool stateless = false;                // no block pipeline: the launch spreads the blocks of a set over gridDim.y
+        std::vector<int32_t> roots;            // the roots that own its islands: when none of them runs the launch is skipped
     };
     std::vector<SpecShape> shapes;
     std::vector<uint32_t> specLists;           // island indices, shape-major
@@ -435,6 +441,7 @@ struct Plan {
     // elemhip_process of a settled, fully compiled sequence: the launch set of ONE (levels + batch epilogue) as a captured graph
     hipGraphExec_t specGraphExec = nullptr;
     float* specGraphOut = nullptr;          // the output pointer baked into it
+    uint32_t specGraphNumOut = 0;           // ... and the output count it was captured for
     uint32_t specGraphLaunches = 0;         // specialised launches it replays (stats)
     ~Plan();
 };

@@ -609,12 +609,14 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     // ---- 3/4. per-island schedule, LDS allocation, task emission -------------------------------------
     p.islands.resize(ib.size());
     p.islandProg.assign(ib.size(), nullptr);
+    p.islandRoot.assign(ib.size(), 0);
     std::vector<uint32_t> scheduled;         // islands whose program this build made (p.prog holds them, progBegin relative to it)
     std::vector<int> convLevel;              // launch level of p.convs[i]
     for (size_t ii = 0; ii < ib.size(); ++ii) {
         IslandBuild& B = ib[ii];
         Island& I = p.islands[ii];
         I.rootRec = seqRoots[B.seq]->rec;
+        p.islandRoot[ii] = seqRoots[B.seq]->id;
         if (ni[B.nodes[0]].kind == K_CONV) {     // one node, no island program: a ConvDesc instead
             NI& x = ni[B.nodes[0]];
             ConvDesc d{};
@@ -1649,6 +1651,7 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     {
         const size_t L = p.levelOffsets.size() - 1;
         p.restOffsets.assign(L + 1, 0);
+        p.restRoots.assign(L, {});
         std::vector<uint8_t> covered(p.islands.size(), 0);
         for (size_t l = 0; l < L; ++l) {
             // one shape per kernel: islands are grouped by the cache key of their text (two cached text objects can carry the same
@@ -1678,12 +1681,21 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
                 sh.level = (uint32_t)l; sh.listBegin = (uint32_t)p.specLists.size();
                 sh.stateless = p.islands[kv.second[0]].stateless != 0u;
                 // (levelIslands entry format: island | split part << 24 — a split island is one workgroup per part)
-                for (uint32_t isl : kv.second) { for (uint32_t k = 0; k < std::max(1u, p.islands[isl].split); ++k) p.specLists.push_back(isl | (k << 24)); covered[isl] = 1; }
+                for (uint32_t isl : kv.second) {
+                    for (uint32_t k = 0; k < std::max(1u, p.islands[isl].split); ++k) p.specLists.push_back(isl | (k << 24));
+                    covered[isl] = 1;
+                    if (std::find(sh.roots.begin(), sh.roots.end(), p.islandRoot[isl]) == sh.roots.end()) sh.roots.push_back(p.islandRoot[isl]);
+                }
                 sh.count = (uint32_t)p.specLists.size() - sh.listBegin;
                 p.shapes.push_back(std::move(sh));
             }
-            for (uint32_t q = p.levelOffsets[l]; q < p.levelOffsets[l + 1]; ++q)
-                if (!covered[p.levelIslands[q] & 0xFFFFFFu]) p.restIslands.push_back(p.levelIslands[q]);
+            for (uint32_t q = p.levelOffsets[l]; q < p.levelOffsets[l + 1]; ++q) {
+                const uint32_t isl = p.levelIslands[q] & 0xFFFFFFu;
+                if (covered[isl]) continue;
+                p.restIslands.push_back(p.levelIslands[q]);
+                auto& rr = p.restRoots[l];
+                if (std::find(rr.begin(), rr.end(), p.islandRoot[isl]) == rr.end()) rr.push_back(p.islandRoot[isl]);
+            }
             p.restOffsets[l + 1] = (uint32_t)p.restIslands.size();
         }
         p.specText.clear(); p.specText.shrink_to_fit();
@@ -1754,7 +1766,7 @@ std::string Engine::describePlan() {
     auto kv = [&](const char* k, uint64_t v, bool comma = true) { s += "\"" + std::string(k) + "\":" + std::to_string(v) + (comma ? "," : ""); };
     kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.numTasks);
     kv("num_members", p.numMembers); kv("num_operands", p.numOperands); kv("num_nodes", p.nodeIds.size());
-    kv("plan_fused_epilogues", st.fusedEpilogues); kv("plan_prog_heaps", st.progHeaps); kv("plan_prog_heap_used_dwords", p.progHeap ? p.progHeap->usedDwords : 0);
+    kv("plan_idle_launches_skipped", st.idleLaunchesSkipped); kv("plan_fused_epilogues", st.fusedEpilogues); kv("plan_prog_heaps", st.progHeaps); kv("plan_prog_heap_used_dwords", p.progHeap ? p.progHeap->usedDwords : 0);
     kv("plan_islands_reused", st.planIslandsReused); kv("plan_islands_scheduled", st.planIslandsScheduled); kv("plan_cache_mismatches", st.planCacheMismatches);
     kv("num_hbm_buffers", p.numHbmBuffers); kv("num_stream_buffers", p.numStreamBuffers); kv("pack_k", p.packK);
     kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());

@@ -203,3 +203,31 @@ def test_launch_set_geometry_options(gpu_required, batch, rows, split, spec):
     ref = np.stack([c.process(None, 2, 512) for _ in range(300)])
     assert a.stats()["batch_launches"] >= max(1, 300 // batch)
     assert float(np.abs(got - ref).max()) <= TOL
+
+
+@pytest.mark.parametrize("path", ["process", "process_blocks"])
+def test_idle_launches_of_a_replaced_root_are_left_out(gpu_required, path):
+    """A replaced root stays in the plan until the next commit (GraphRenderSequence.h:214-219: it renders while its fade-out
+    runs, then not at all). Once its fade has settled the launch that would only start its islands is left out by the host
+    (launchLevelBatch: mirror of the root fades) — every block still equals the reference engine's, also when the number of
+    output channels the caller asks for changes what runs."""
+    a, c = _hip(graphs.C2_SAMPLE_RATE, 512, batch_blocks=4), _checker(graphs.C2_SAMPLE_RATE, 512)
+    # background compilation: the replaced voice's one-off island shape stays with the interpreter (an idle interpreter launch);
+    # waiting for every shape: it gets a kernel of its own (an idle specialised launch; one ~10 s compile on a cold cache)
+    a.set_option("specialize", 1 if path == "process" else 2)
+    ids = list(range(32))
+    worst, nxt = 0.0, 32
+    for batch in range(6):
+        if batch:
+            ids[(batch * 11) % 32] = nxt
+            nxt += 1
+        roots = _voices_graph(ids)
+        assert a.render(*roots)["result"] == 0 and c.render(*roots)["result"] == 0
+        for k in range(4):
+            n_out = 1 if (batch == 3 and k == 2) else 2                      # one call that leaves channel 1 out
+            nb = 1 if path == "process" else 5
+            ref = np.stack([c.process(None, n_out, 512) for _ in range(nb)])
+            got = np.stack([a.process(None, n_out, 512) for _ in range(nb)]) if path == "process" else _blocks(a, nb, n_out)
+            worst = max(worst, float(np.abs(got - ref).max()))
+            assert worst <= TOL, (batch, k, worst)
+    assert a.describe_plan()["plan_idle_launches_skipped"] > 0

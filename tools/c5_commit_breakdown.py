@@ -55,4 +55,6 @@ if __name__ == "__main__":
     names = ["create", "delete", "append", "set", "activate", "commit"]
     for i, nm in enumerate(names):
         out["apply_" + nm + "_us_p50"] = med([k[i] for k in kinds[4:]])
+    slow = sorted(range(4, len(rows)), key=lambda i: -rows[i]["call_us"])[:6]
+    out["slowest_calls"] = [dict(batch=i + 1, after_gc=((i + 1) % 16 == 1), **{k: round(v, 1) for k, v in rows[i].items()}) for i in slow]
     print(json.dumps(out))
