@@ -212,9 +212,7 @@ def test_idle_launches_of_a_replaced_root_are_left_out(gpu_required, path):
     (launchLevelBatch: mirror of the root fades) — every block still equals the reference engine's, also when the number of
     output channels the caller asks for changes what runs."""
     a, c = _hip(graphs.C2_SAMPLE_RATE, 512, batch_blocks=4), _checker(graphs.C2_SAMPLE_RATE, 512)
-    # background compilation: the replaced voice's one-off island shape stays with the interpreter (an idle interpreter launch);
-    # waiting for every shape: it gets a kernel of its own (an idle specialised launch; one ~10 s compile on a cold cache)
-    a.set_option("specialize", 1 if path == "process" else 2)
+    a.set_option("specialize", 2)       # (the replaced voice's one-off island shape gets a kernel of its own: ~10 s of compiles on a cold cache)
     ids = list(range(32))
     worst, nxt = 0.0, 32
     for batch in range(6):
