@@ -1615,8 +1615,10 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     if (rc != kOk) return rc;
     // A whole block of a settled sequence whose island shapes are all compiled goes through the specialised kernels as a
     // launch set of one (stages pipelined inside the workgroup, no interpreter image); everything else block by block.
-    const bool specBlock = specBlocks && n == (size_t)blockSize && p.convs.empty() && specReady(p) && batchEligible(p, nOut, true);
-    if (specBlock) {
+    const bool specLevels = n == (size_t)blockSize && specBlockOk(p);
+    const bool specBlock = specLevels && batchEligible(p, nOut, true);
+    const bool specFade = specLevels && !specBlock;      // root fades running: same level launches, the per-block epilogue behind them
+    if (specLevels) {
         rc = ensureHbm(arenaBuffers(p, 1));
         if (rc != kOk) return rc;
     }
@@ -1672,6 +1674,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
         HIP_OK(hipGraphLaunch(p.specGraphExec, stream));
         st.specLaunches += p.specGraphLaunches; st.graphReplays++;
     } else if (specBlock) enqueueBatch(p, 1u, outDev);
+    else if (specFade) enqueueSpecBlock(p, outDev);
     else enqueueBlock(p, outDev);
     if (nOut > 0 && !outDev) HIP_OK(hipMemcpyAsync(hOut, dOutRing, nOut * (size_t)blockSize * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
@@ -1801,8 +1804,12 @@ int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, siz
 // every island shape of the sequence has its kernel loaded on this device (stateless islands stay with the interpreter kernel)
 bool Engine::specReady(const Plan& p) const {
     if (specialize == 0 || p.shapes.empty()) return false;
-    for (const Plan::SpecShape& sh : p.shapes) if (!sh.entry->function(device)) return false;
-    return true;
+    bool any = false;
+    for (const Plan::SpecShape& sh : p.shapes) {
+        if (sh.entry->function(device)) any = true;
+        else if (!sh.optional) return false;
+    }
+    return any;
 }
 
 bool Engine::anyRootRuns(const std::vector<int32_t>& rootIds, size_t nOut) const {
@@ -2000,6 +2007,18 @@ void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
     if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)L); profSets++; profBlocks += batch; }
 }
 
+bool Engine::specBlockOk(const Plan& p) const { return specBlocks && p.convs.empty() && p.hosts.empty() && specReady(p); }
+
+void Engine::enqueueSpecBlock(const Plan& p, float* outRing) {
+    if (!outRing) outRing = dOutRing;
+    const uint32_t arenaFloats = p.numHbmBuffers * (uint32_t)blockSize;
+    const size_t L = p.levelOffsets.size() - 1;
+    for (size_t l = 0; l < L; ++l) (void)launchLevelBatch(p, l, 1u, arenaFloats);
+    launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, outRing);
+    debugSync("block: specialised levels + epilogue");
+    st.specFadeBlocks++;
+}
+
 int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime) {
     std::lock_guard<std::mutex> lock(mu);
     if (dry) return kNoDevice;
@@ -2066,6 +2085,29 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             done += chunk;
             st.blocksRendered += chunk;
             st.batchLaunches++;
+            continue;
+        }
+        if (specBlockOk(p)) {
+            // ---- one block through the specialised kernels (root fades running, or a call of one block) ----
+            rc = ensureHbm(arenaBuffers(p, 1));
+            if (rc != kOk) return rc;
+            if (hGlobals.ringSlots != 1u || hGlobals.blockSlot != 0u) {
+                hGlobals.ringSlots = 1u; hGlobals.blockSlot = 0u;
+                patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, ringSlots) / 4), 1u, 0u});
+                patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, blockSlot) / 4), 0u, 0u});
+            }
+            setInRing(nullptr, 0);
+            if (haveIn) HIP_OK(hipMemcpyAsync(dHbm, inDev + done * nIn * bs, nIn * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            rc = flushPending();
+            if (rc != kOk) return rc;
+            curBlockTime = hGlobals.sampleTime;
+            if (batchEligible(p, nOut, true)) enqueueBatch(p, 1u); else enqueueSpecBlock(p);
+            if (outDev && nOut > 0)
+                HIP_OK(hipMemcpyAsync(outDev + done * nOut * bs, dOutRing, nOut * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            mirrorRootFades(p, (uint32_t)bs, (uint32_t)nOut, (uint32_t)nIn);
+            hGlobals.sampleTime += (int64_t)bs;
+            done += 1;
+            st.blocksRendered += 1;
             continue;
         }
         const size_t chunk = std::min(G, numBlocks - done);

@@ -140,6 +140,7 @@ struct Stats {
     double   lastPlanBuildMs = 0.0;
     uint32_t numIslands = 0, numLevels = 0, numTasks = 0, numNodesInPlan = 0, maxLdsBytes = 0, numHbmBuffers = 0;
     uint64_t graphReplays = 0, graphCaptures = 0, batchLaunches = 0;
+    uint64_t specFadeBlocks = 0;         // blocks rendered by the specialised kernels while root fades were running (per-block epilogue)
     uint64_t idleLaunchesSkipped = 0;    // launches left out because no root of their islands ran
     uint64_t fusedEpilogues = 0;         // launch sets of one whose last level kernel ran the epilogue
     uint64_t progHeaps = 0;              // program heaps started (1 = the first still serves)
@@ -345,6 +346,10 @@ private:
     void enqueueBlock(const Plan& p, float* outRing = nullptr);
     int  renderHostNodes(const Plan& p, size_t level);   // call-out nodes of one launch level (synchronises the stream)
     void enqueueBatch(const Plan& p, uint32_t batch, float* outRing = nullptr);
+    // one block of a fully compiled plan whose root fades are still running: the specialised level launches of a set of one, then
+    // the PER-BLOCK epilogue (fades advance, taps promoted) — the two blocks after every commit of a live graph
+    void enqueueSpecBlock(const Plan& p, float* outRing = nullptr);
+    bool specBlockOk(const Plan& p) const;
     void launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32_t arenaFloats);
     // specialised kernels when ready, else the interpreter. `epiOut` non-null: if the level is one specialised launch, let its last
     // workgroup run the epilogue into `epiOut` (island_spec.inc spec_epilogue_tail); returns whether it will
@@ -425,6 +430,8 @@ struct Plan {
         uint32_t level = 0;
         uint32_t listBegin = 0, count = 0;     // its workgroups: specLists[listBegin, listBegin + count) (island | split part << 24)
         bool stateless = false;                // no block pipeline: the launch spreads the blocks of a set over gridDim.y
+        bool optional = false;                 // a one-island shape of a background-mode plan: while it compiles its island renders through
+                                               // the interpreter kernel and the plan still counts as ready (Engine::specReady)
         std::vector<int32_t> roots;            // the roots that own its islands: when none of them runs the launch is skipped
     };
     std::vector<SpecShape> shapes;

@@ -49,6 +49,7 @@ struct Jit::Impl {
     std::deque<std::shared_ptr<SpecEntry>> queue;
     std::unordered_map<uint32_t, std::pair<uint64_t, uint64_t>> prefixHash;   // LDS words -> key hash state behind the fixed part of the source
     std::string prefixDefs;                                                 // ... under this ELEMHIP_JIT_DEFINES
+    std::unordered_map<std::string, uint32_t> sightings;                    // one-island shapes a background-mode plan left to the interpreter
     std::unordered_set<std::string> notOnDisk;                             // keys the disk cache was asked about in vain
     std::vector<std::thread> workers;
     bool stop = false;
@@ -223,6 +224,11 @@ bool Jit::knownKey(const std::string& key) {
     const bool there = ::stat((impl->cacheDir + "/" + key + ".hsaco").c_str(), &st) == 0;
     if (!there) { std::lock_guard<std::mutex> l(impl->mu); if (impl->notOnDisk.size() > 4096) impl->notOnDisk.clear(); impl->notOnDisk.insert(key); }
     return there;
+}
+uint32_t Jit::sighting(const std::string& key) {
+    std::lock_guard<std::mutex> l(impl->mu);
+    if (impl->sightings.size() > 4096) impl->sightings.clear();
+    return ++impl->sightings[key];
 }
 bool Jit::known(const std::string& generated, uint32_t ldsWords) { return knownKey(keyFor(generated, ldsWords)); }
 

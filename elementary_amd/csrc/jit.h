@@ -36,6 +36,7 @@ public:
     // keep the key) and the two calls above by key; `request` builds the program text only for a key it has not seen
     std::string keyFor(const std::string& generated, uint32_t ldsWords);
     bool knownKey(const std::string& key);
+    uint32_t sighting(const std::string& key);     // how many plans (this one included) have wanted this not-yet-compiled shape
     std::shared_ptr<SpecEntry> requestKey(const std::string& key, const std::string& generated, uint32_t ldsWords);
     static std::string fullSource(const std::string& generated, uint32_t ldsWords);
     void shutdownAtExit();

@@ -1675,8 +1675,12 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
                 // one-off graph) is not worth a compile of its own: it renders through the interpreter kernel
                 const uint32_t ldsW = p.islands[kv.second[0]].ldsWords;
                 SpecText& tx = *kv.first;
-                if (specialize == 1 && kv.second.size() < 2 && !Jit::get().knownKey(tx.key)) continue;
+                // ... unless it keeps coming back: a live graph that replaces a voice per commit meets the same one-off shape (the old
+                // voice fading out behind its own mixer and root) in every plan — the second plan that wants it has it compiled
+                const bool lonely = specialize == 1 && kv.second.size() < 2;
+                if (lonely && !Jit::get().knownKey(tx.key) && Jit::get().sighting(tx.key) < 2u) continue;
                 Plan::SpecShape sh;
+                sh.optional = lonely;
                 sh.entry = Jit::get().requestKey(tx.key, tx.text, ldsW);
                 sh.level = (uint32_t)l; sh.listBegin = (uint32_t)p.specLists.size();
                 sh.stateless = p.islands[kv.second[0]].stateless != 0u;
@@ -1766,7 +1770,7 @@ std::string Engine::describePlan() {
     auto kv = [&](const char* k, uint64_t v, bool comma = true) { s += "\"" + std::string(k) + "\":" + std::to_string(v) + (comma ? "," : ""); };
     kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.numTasks);
     kv("num_members", p.numMembers); kv("num_operands", p.numOperands); kv("num_nodes", p.nodeIds.size());
-    kv("plan_idle_launches_skipped", st.idleLaunchesSkipped); kv("plan_fused_epilogues", st.fusedEpilogues); kv("plan_prog_heaps", st.progHeaps); kv("plan_prog_heap_used_dwords", p.progHeap ? p.progHeap->usedDwords : 0);
+    kv("plan_spec_fade_blocks", st.specFadeBlocks); kv("plan_idle_launches_skipped", st.idleLaunchesSkipped); kv("plan_fused_epilogues", st.fusedEpilogues); kv("plan_prog_heaps", st.progHeaps); kv("plan_prog_heap_used_dwords", p.progHeap ? p.progHeap->usedDwords : 0);
     kv("plan_islands_reused", st.planIslandsReused); kv("plan_islands_scheduled", st.planIslandsScheduled); kv("plan_cache_mismatches", st.planCacheMismatches);
     kv("num_hbm_buffers", p.numHbmBuffers); kv("num_stream_buffers", p.numStreamBuffers); kv("pack_k", p.packK);
     kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());

@@ -228,4 +228,6 @@ def test_idle_launches_of_a_replaced_root_are_left_out(gpu_required, path):
             got = np.stack([a.process(None, n_out, 512) for _ in range(nb)]) if path == "process" else _blocks(a, nb, n_out)
             worst = max(worst, float(np.abs(got - ref).max()))
             assert worst <= TOL, (batch, k, worst)
-    assert a.describe_plan()["plan_idle_launches_skipped"] > 0
+    info = a.describe_plan()
+    assert info["plan_idle_launches_skipped"] > 0
+    assert info["plan_spec_fade_blocks"] >= 5          # the blocks right after a commit: specialised level launches + the per-block epilogue

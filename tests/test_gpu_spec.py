@@ -248,3 +248,29 @@ def test_fused_epilogue_of_a_single_block_call(gpu_required, name):
         ref.append(c.process(xin, n_out + (1 if 30 <= k < 34 else 0), 512)[:n_out])
     ref = np.stack(ref)
     assert float(np.abs(outs[1] - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
+
+
+def _phasors_only_roots():
+    ph = [el.phasor(f) for f in (1000.0, 700.0, 333.3)]
+    return [ph[0], el.mul(2.0, ph[1]), el.le(ph[2], 0.5), el.sample({"path": "/t/ramp", "mode": "trigger", "startOffset": 10}, el.le(ph[1], 0.5), 2.0)]
+
+
+@pytest.mark.parametrize("path", ["process", "sets_of_3"])
+def test_merged_phase_task_of_phasors_only(gpu_required, path):
+    """Constant-frequency phasors share one lane-per-node task (OP_PHASE) whose spare lanes repeat the last member. With no
+    oscillator behind the phasors those lanes once ran the oscillator's arithmetic (inc = f / sr, not f * (1 / sr)) and raced
+    their final phase into the phasor's record: every launch started 512 x ulp(inc) off (r04; 1000 Hz drifted 4e-4 in five
+    blocks through elemhip_process, and a 700 Hz train — period exactly 63 frames — moved its edges). A phasor with a constant
+    frequency is exact arithmetic: bit-identical to the reference engine once the root fades have settled, over many launches."""
+    a, c = _spec_runtime(44100.0, 512, batch=3), _checker(44100.0, 512)
+    roots = _phasors_only_roots()
+    for rt in (a, c):
+        for rname, data in node_case_resources().items():
+            assert rt.add_shared_resource(rname, data)
+        assert rt.render(*roots)["result"] == 0
+    nb = 30
+    ref = np.stack([c.process(None, 4, 512) for _ in range(nb)])
+    got = np.stack([a.process(None, 4, 512) for _ in range(nb)]) if path == "process" else np.concatenate([_render_blocks(a, 3, 4) for _ in range(nb // 3)])
+    assert a.stats()["spec_launches"] > 0
+    assert np.array_equal(got[3:, :3], ref[3:, :3])                       # the phasors, their scaled copy and the train
+    assert float(np.abs(got - ref).max()) <= TOL

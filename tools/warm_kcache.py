@@ -66,6 +66,7 @@ def main():
         for name, (sr, mk, _n_in) in sorted(test_gpu_spec._fuse_graphs().items()):
             jobs.append((f"fuse_{name}", sr, 512, mk(), None, None))
             jobs.append((f"fuse_{name}_swapped", sr, 512, mk()[::-1], None, None))
+        jobs.append(("phasors_only", 44100.0, 512, test_gpu_spec._phasors_only_roots(), node_case_resources(), None))
         for copies in (1, 3, 6):
             jobs.append((f"stateful_d{copies}", 48000.0, 512, every_stateful_roots(), None, copies))
     if len(sys.argv) > 2:      # "i/n": this process takes every n-th job (several processes warm the cache in parallel)
