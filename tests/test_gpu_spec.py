@@ -274,3 +274,52 @@ def test_merged_phase_task_of_phasors_only(gpu_required, path):
     assert a.stats()["spec_launches"] > 0
     assert np.array_equal(got[3:, :3], ref[3:, :3])                       # the phasors, their scaled copy and the train
     assert float(np.abs(got - ref).max()) <= TOL
+
+
+@pytest.mark.parametrize("name", sorted(NODE_CASES))
+def test_spec_node_case_call_by_call(gpu_required, name):
+    """Every node case through elemhip_process, one synchronous call per block (the reference hosts' protocol): the two blocks
+    of the root fade-in go through the specialised level launches + the per-block epilogue, the rest as launch sets of one — node
+    state crosses a launch boundary after every block (records written back and staged again), which the multi-block test above
+    does three times in 17 blocks. Against the reference engine and, bit for bit where no libm call is involved, the interpreter."""
+    from elementary_amd.runtime import Runtime
+    roots_fn, n_in = NODE_CASES[name]
+    if name in REF_ONLY:
+        import oracle
+        if not oracle.have_ref():
+            pytest.skip("needs oracle/_ref")
+    nb = 12
+    a, c = Runtime(44100.0, 512, device=0), _checker(44100.0, 512)
+    a.set_option("specialize", 2)
+    for rt in (a, c):
+        for rname, data in node_case_resources().items():
+            assert rt.add_shared_resource(rname, data)
+    roots = roots_fn()
+    n_out = len(roots)
+    for rt in (a, c):
+        assert rt.render(*roots)["result"] == 0
+    for k in range(nb):
+        x = np.stack([lcg_noise(512, 1 + ch + 97 * k, 0.5) for ch in range(max(n_in, 1))])
+        got, ref = a.process(x if n_in else None, n_out, 512), c.process(x if n_in else None, n_out, 512)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(got - ref).max()) <= TOL * scale, f"{name}: block {k}: {np.abs(got - ref).max():.3e}"
+    info = a.describe_plan()
+    if any(i["tasks"] > 0 for i in info["islands"]):
+        assert a.stats()["spec_launches"] > 0 and info["plan_spec_fade_blocks"] >= 1, (a.stats(), info["plan_spec_fade_blocks"])
+
+
+@pytest.mark.parametrize("seed", range(0, 48, 3))
+def test_spec_random_graph_call_by_call(gpu_required, seed):
+    from elementary_amd.runtime import Runtime
+    from test_gpu_fuzz import random_graph
+    nb, n_out = 14, min(3, 1 + seed % 5)
+    a, c = Runtime(48000.0, 512, device=0), _checker(48000.0, 512)
+    a.set_option("specialize", 2)
+    for rt in (a, c):
+        assert rt.render(*random_graph(seed, n_nodes=24 + 22 * (seed % 4), n_roots=1 + seed % 5)[:n_out])["result"] == 0
+    for k in range(nb):
+        x = np.stack([lcg_noise(512, 11 + 7 * k + ch, 0.5) for ch in range(2)])
+        got, ref = a.process(x, n_out, 512), c.process(x, n_out, 512)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(got - ref).max()) <= TOL * scale, f"seed {seed}: block {k}: {np.abs(got - ref).max():.3e}"
+    assert a.stats()["spec_launches"] > 0

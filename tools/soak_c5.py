@@ -10,6 +10,7 @@ from elementary_amd import el, graphs
 from elementary_amd.runtime import Runtime
 
 n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+heap_dwords = int(sys.argv[2]) if len(sys.argv) > 2 else 0        # > 0: a program heap that keeps running out (plan.cpp ProgHeap)
 
 
 def voices_graph(ids):
@@ -22,6 +23,8 @@ def voices_graph(ids):
 
 a = Runtime(graphs.C2_SAMPLE_RATE, 512, device=0)
 a.set_option("specialize", 1)
+if heap_dwords:
+    a.set_option("prog_heap_dwords", heap_dwords)
 c = oracle.RefRuntime(graphs.C2_SAMPLE_RATE, 512)
 rng = np.random.RandomState(3)
 ids, nxt, worst, blocks, pruned_total = list(range(128)), 128, 0.0, 0, 0
@@ -53,4 +56,5 @@ for batch in range(n_batches):
     if batch % 50 == 49:
         st = a.stats()
         print(f"batch {batch + 1}: {blocks} blocks, worst {worst:.2e}, spec launches {st['spec_launches']}, plans {st['plans_built']}, pruned {pruned_total}, {time.time() - t0:.0f} s", flush=True)
-print("done: worst abs err", worst)
+info = a.describe_plan()
+print("done: worst abs err", worst, {k: info[k] for k in info if k.startswith("plan_")})
