@@ -8,6 +8,7 @@
 
 #include "../../include/elemhip.h"
 #include "engine.h"
+#include "launch.h"
 
 using elemhip::Engine;
 using elemhip::Value;
@@ -202,6 +203,13 @@ int elemhip_spec_info(elemhip_t* h, size_t k, char* src, size_t srcCap, char* lo
 int elemhip_set_stream(elemhip_t* h, void* stream) {
     if (!h) return elemhip::kInvalidInstructionFormat;
     h->engine.setStream(static_cast<hipStream_t>(stream));
+    return elemhip::kOk;
+}
+
+int elemhip_sum_buses(int deviceOrdinal, void* stream, float* dst, const float* const* partials, size_t nPartials, size_t nFloats) {
+    if (!dst || !partials || nPartials == 0 || nPartials > 64) return elemhip::kInvalidInstructionFormat;
+    if (hipSetDevice(deviceOrdinal) != hipSuccess) return elemhip::kHipError;
+    if (elemhip::launch_bus_sum(static_cast<hipStream_t>(stream), dst, partials, (uint32_t)nPartials, nFloats) != hipSuccess) return elemhip::kHipError;
     return elemhip::kOk;
 }
 

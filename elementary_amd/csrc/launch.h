@@ -28,5 +28,6 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
 uint32_t convolve_mfma_max_partitions();   // IRs of up to this many 512-tap partitions take the matrix-core MAC
 hipError_t upload_convolve_tables(const float* twiddleReIm);
 void launch_patches(hipStream_t s, const Patch* patches, uint32_t count, uint32_t* recs, uint32_t* globals);
+hipError_t launch_bus_sum(hipStream_t s, float* dst, const float* const* partials, uint32_t count, size_t n);   // dst = ((p0 + p1) + p2) + ... (rank order)
 
 } // namespace elemhip

@@ -21,6 +21,16 @@ class ElemHipError(RuntimeError):
     pass
 
 
+def sum_buses(dst_ptr: int, partial_ptrs, num_floats: int, device: int = 0, hip_stream: int = 0) -> None:
+    """``elemhip_sum_buses``: dst = ((partials[0] + partials[1]) + ...) in the order given — the rank-ordered, bit-reproducible
+    sum of the ranks' output buses once they sit on one device (raw device pointers, ``num_floats`` float32 each)."""
+    lib = load_library()
+    arr = (C.c_void_p * len(partial_ptrs))(*[C.c_void_p(p) for p in partial_ptrs])
+    rc = lib.elemhip_sum_buses(int(device), C.c_void_p(hip_stream or None), C.c_void_p(dst_ptr), arr, len(partial_ptrs), int(num_floats))
+    if rc != 0:
+        raise ElemHipError(f"elemhip_sum_buses failed: {describe(rc)} (code {rc})")
+
+
 def load_library() -> C.CDLL:
     """Load the in-tree HIP engine. Raises (never falls back) when it has not been built."""
     global _lib
@@ -47,6 +57,8 @@ def load_library() -> C.CDLL:
         lib.elemhip_time_launches.restype = C.c_int
         lib.elemhip_describe_plan.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         lib.elemhip_describe_plan.restype = C.c_size_t
+        lib.elemhip_sum_buses.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t]
+        lib.elemhip_sum_buses.restype = C.c_int
         _lib = lib
     return _lib
 

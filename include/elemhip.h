@@ -164,6 +164,13 @@ size_t elemhip_describe_plan(elemhip_t*, char* buf, size_t cap);
 int  elemhip_spec_info(elemhip_t*, size_t k, char* src, size_t srcCap, char* log, size_t logCap, int* state, uint32_t* islands);
 /* Run the launches on a caller-owned hipStream_t (e.g. torch's current stream). */
 int  elemhip_set_stream(elemhip_t*, void* hipStream);
+/* Multi-GPU hosts: the path shards over independent units (voices, render jobs: SURVEY 8(e)) and its one exchange step is the sum
+ * of the ranks' output buses. The reference has no counterpart (one thread, one bus: GraphRenderSequence.h:286-290 zeroes it,
+ * every root adds into it). Once the ranks' buses sit on one device (hipMemcpyPeer, or ncclSend / ncclRecv — INTEGRATION.md
+ * section 6) this adds them in the order given: dst = ((partials[0] + partials[1]) + partials[2]) + ... — the same bits on every
+ * run, unlike a ring all-reduce. Device pointers, `nFloats` each; at most 64 partials; asynchronous on `hipStream` (NULL: the
+ * null stream); no engine handle needed. */
+int  elemhip_sum_buses(int deviceOrdinal, void* hipStream, float* dst, const float* const* partials, size_t nPartials, size_t nFloats);
 /* Tunables (the full table with defaults: INTEGRATION.md section 5): "batch_blocks" (blocks per multi-block launch, 1 ... 1024),
  * "specialize" (0 interpreter kernels only, 1 per-island-shape kernels compiled in the background and used once ready, 2 commit
  * waits for them), "spec_blocks" / "host_out_direct" (elemhip_process through the specialised kernels / output written straight

@@ -8,6 +8,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -66,3 +67,41 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                          timeout=120, cwd=ROOT, env=env)
     assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_sum_buses_is_the_rank_ordered_sum(gpu_required):
+    """elemhip_sum_buses (the C-ABI's multi-GPU helper): the partial buses of voice shards rendered by separate engines, added in
+    rank order on the device — the bits of a sequential float32 sum in that order (and of sharded.ordered_bus_sum), for 2, 5 and 64
+    partials, a length that is not a multiple of the workgroup size, and through the error paths."""
+    import torch
+    from elementary_amd import graphs
+    from elementary_amd.runtime import Runtime, sum_buses, ElemHipError
+    shards = []
+    for r in range(5):                      # five "ranks": 8 voices each of a 40-voice graph
+        rt = Runtime(graphs.C2_SAMPLE_RATE, 512, device=0)
+        assert rt.render(*graphs.c2_graph(voices=8, channels=2, first_voice=8 * r))["result"] == 0
+        out = torch.zeros((16, 2, 512), dtype=torch.float32, device="cuda")
+        rt.process_blocks(16, 2, out_ptr=out.data_ptr())
+        shards.append(out)
+    torch.cuda.synchronize()
+    n = shards[0].numel()
+    dst = torch.empty_like(shards[0])
+    for count in (2, 5):
+        sum_buses(dst.data_ptr(), [s.data_ptr() for s in shards[:count]], n)
+        torch.cuda.synchronize()
+        ref = shards[0].cpu().numpy().copy()
+        for s in shards[1:count]:
+            ref = ref + s.cpu().numpy()                       # float32, rank order
+        assert np.array_equal(dst.cpu().numpy(), ref)
+    many = [torch.randn(1000 + 37, device="cuda") for _ in range(64)]
+    d2 = torch.empty(1037, device="cuda")
+    sum_buses(d2.data_ptr(), [m.data_ptr() for m in many], 1037)
+    torch.cuda.synchronize()
+    ref = many[0].cpu().numpy().copy()
+    for m in many[1:]:
+        ref = ref + m.cpu().numpy()
+    assert np.array_equal(d2.cpu().numpy(), ref)
+    with pytest.raises(ElemHipError):
+        sum_buses(d2.data_ptr(), [m.data_ptr() for m in many] + [many[0].data_ptr()], 1037)      # 65 partials
+    with pytest.raises(ElemHipError):
+        sum_buses(d2.data_ptr(), [], 1037)
