@@ -120,6 +120,11 @@ TablePool::~TablePool() { for (DevBuf& b : free) (void)hipFree(b.ptr); }
 // ---------------------------------------------------------------------------------------------
 Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), device(dev) {
     auto fail = [&](int code) { initErr = code; };
+    // A block's buffers are LDS slots of kMaxBlock frames. A host block that is a multiple of that is rendered as slices of
+    // kMaxBlock frames (the sample-rate nodes cannot tell; taps, whose delay IS the block, are refused at commit): the engine's
+    // own block size is the slice, the host's the limit of a process() call.
+    hostBlockSize = bs;
+    if (bs > (int)kMaxBlock && bs % (int)kMaxBlock == 0 && bs <= 64 * (int)kMaxBlock) { bs = (int)kMaxBlock; blockSize = bs; }
     if (const char* e = std::getenv("ELEMHIP_SPECIALIZE")) specialize = std::max(0, std::min(2, std::atoi(e)));
     if (const char* e = std::getenv("ELEMHIP_PLAN_CACHE")) planCache = std::max(0, std::min(2, std::atoi(e)));   // 2: verify mode (tests)
     if (bs <= 0 || bs > (int)kMaxBlock) { fail(kBlockTooLarge); return; }
@@ -993,6 +998,12 @@ int Engine::commit(std::unique_lock<std::mutex>& renderLock) {   // Runtime.h:20
         // (not a reference code path: its buildRenderSequence cannot fail. The roots stay swapped as in the reference;
         // the rebuild stays owed so that the next commit retries instead of rendering the old sequence forever.)
         if (!p) { rebuildOwed = true; return kUnsupportedGraph; }
+        if (hostBlockSize != blockSize && (!p->taps.empty() || !p->tapPairs.empty())) {
+            // tapIn / tapOut delay their signal by one BLOCK of the host (Feedback.h:90-126): slices of 512 frames would shorten the loop
+            std::fprintf(stderr, "[elemhip] tapIn / tapOut need blockSize <= %u (this runtime was created with %d)\n", (unsigned)kMaxBlock, hostBlockSize);
+            rebuildOwed = true;
+            return kUnsupportedGraph;
+        }
         rebuildOwed = false;
         // mc.capture: the reference (re)creates the node's multi-channel ring whenever a render sequence that holds it is pushed
         // (GraphRenderSequence.h:165-169 sets `_internal:numChildren`, mc/Capture.h:21-31 allocates children - 1 channels of
@@ -1592,6 +1603,22 @@ void Engine::mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t 
 }
 
 int Engine::process(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime) {
+    if (n <= (size_t)blockSize || hostBlockSize == blockSize) return processSlice(in, nIn, out, nOut, n, sampleTime);
+    if (n > (size_t)hostBlockSize) return kBlockTooLarge;
+    if (nIn > kMaxHostIn || nOut > kMaxOutBus) return kTooManyChannels;
+    // a host block longer than the engine's: slice by slice (each slice is a block of its own to the kernels)
+    std::vector<const float*> ip(nIn);
+    std::vector<float*> op(nOut);
+    for (size_t off = 0; off < n; off += (size_t)blockSize) {
+        for (size_t c = 0; c < nIn; ++c) ip[c] = in[c] + off;
+        for (size_t c = 0; c < nOut; ++c) op[c] = out[c] + off;
+        const int rc = processSlice(ip.data(), nIn, op.data(), nOut, std::min((size_t)blockSize, n - off), sampleTime + (int64_t)off);
+        if (rc != kOk) return rc;
+    }
+    return kOk;
+}
+
+int Engine::processSlice(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime) {
     std::lock_guard<std::mutex> lock(mu);
     if (dry) return kNoDevice;
     if (hipSetDevice(device) != hipSuccess) return kHipError;
@@ -2022,6 +2049,7 @@ void Engine::enqueueSpecBlock(const Plan& p, float* outRing) {
 int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime) {
     std::lock_guard<std::mutex> lock(mu);
     if (dry) return kNoDevice;
+    if (hostBlockSize != blockSize) return kBlockTooLarge;     // (the device-resident layout is [block][channel][blockSize <= 512])
     if (hipSetDevice(device) != hipSuccess) return kHipError;
     int rc = enqueueBlocks(inDev, nIn, outDev, nOut, numBlocks, sampleTime);
     if (rc != kOk) return rc;
@@ -2201,7 +2229,9 @@ int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* 
     if (nIn > kMaxHostIn || nOut > kMaxOutBus) return kTooManyChannels;
     if ((nIn && !in) || (nOut && !out)) return kInvalidInstructionFormat;
     const size_t bs = (size_t)blockSize;
-    const size_t numBlocks = (numFrames + bs - 1) / bs;
+    // whole HOST blocks, like the reference's block loop (a host block = hostBlockSize / blockSize engine blocks)
+    const size_t hb = (size_t)hostBlockSize;
+    const size_t numBlocks = ((numFrames + hb - 1) / hb) * (hb / bs);
     if (numBlocks == 0) return kOk;
     size_t setBlocks;
     {
@@ -2220,6 +2250,7 @@ int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* 
         auto part = [&](size_t bBegin, size_t bEnd) {
             for (size_t b = bBegin; b < bEnd; ++b) {
                 const size_t f0 = (b0 + b) * bs;
+                if (f0 >= numFrames) break;                     // (the engine blocks that only fill up the last host block)
                 const size_t n = std::min(bs, numFrames - f0);
                 for (size_t c = 0; c < nOut; ++c) std::memcpy(out[c] + f0, src + (b * nOut + c) * bs, n * sizeof(float));
             }

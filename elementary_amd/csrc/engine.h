@@ -166,6 +166,7 @@ public:
 
     // one block, host buffers (Runtime::process)
     int process(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime);
+    int processSlice(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime);   // n <= blockSize
     // numBlocks consecutive full blocks, device-resident output `outDev[block][nOut][blockSize]`
     // (may be null: render only) and optional device-resident input `inDev[block][nIn][blockSize]`
     int processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime);
@@ -208,7 +209,8 @@ private:
     int initErr = 0;
     bool dry = false;                      // device == -1: host logic only, cannot render
     double sampleRate;
-    int blockSize;
+    int blockSize;                         // the engine's block: <= kMaxBlock frames (one LDS slot per buffer)
+    int hostBlockSize = 0;                 // what the host created the runtime with: blockSize, or a multiple of kMaxBlock rendered in slices
     int device;
     hipStream_t stream = nullptr;
     bool ownStream = false;

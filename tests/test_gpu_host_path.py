@@ -230,3 +230,41 @@ def test_cli_benchmark_host(gpu_required):
         c.process(None, 2, 512)
     ref = c.process(None, 2, 512)
     assert float(np.abs(got - ref).max()) <= TOL
+
+
+@pytest.mark.parametrize("bs", [1024, 2048])
+def test_host_blocks_longer_than_512_frames(gpu_required, bs):
+    """Runtime(sr, blockSize > 512) (the reference has no limit, Runtime.h:44): a block that is a multiple of 512 frames is rendered
+    as slices of 512. elemhip_process with full and short blocks and elemhip_process_blocks_host (whole HOST blocks: the state
+    after a ragged call is the reference's) against the reference engine created with the same block size, on the 16-voice synth
+    and on the every-stateful-node graph with a host input; the device-resident entry point answers 102."""
+    from elementary_amd.runtime import Runtime, ElemHipError
+    from cases import every_stateful_roots
+    for roots_fn, n_out, n_in in ((lambda: graphs.c2_graph(voices=16), 2, 0), (every_stateful_roots, 3, 1)):
+        a, c = Runtime(48000.0, bs, device=0), _checker(48000.0, bs)
+        a.set_option("specialize", 2)
+        assert a.render(*roots_fn())["result"] == 0 and c.render(*roots_fn())["result"] == 0
+        worst, k = 0.0, 0
+        for n in (bs, bs, 1500 if bs == 2048 else 700, bs, 512, bs):          # process(): full, short and one-slice calls
+            x = np.stack([lcg_noise(n, 7 + k, 0.5)]) if n_in else None
+            got, ref = a.process(x, n_out, n), c.process(x, n_out, n)
+            assert got.shape == ref.shape == (n_out, n)
+            worst = max(worst, float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max())))
+            k += 1
+        assert worst <= TOL, worst
+        # the offline block loop over host arrays: 5 host blocks and a ragged sixth, then process() again (same state as the reference's)
+        frames = 5 * bs + 333
+        x = np.stack([lcg_noise(frames, 99, 0.5)]) if n_in else None
+        got = a.process_blocks_host(x, n_out, frames)
+        nb = (frames + bs - 1) // bs
+        xp = np.zeros((1, nb * bs), dtype=np.float32)
+        if n_in:
+            xp[0, :frames] = x[0]
+        ref = np.concatenate([c.process(xp[:, b * bs:(b + 1) * bs] if n_in else None, n_out, bs) for b in range(nb)], axis=1)[:, :frames]
+        assert float(np.abs(got - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
+        x = np.stack([lcg_noise(bs, 5, 0.5)]) if n_in else None
+        got, ref = a.process(x, n_out, bs), c.process(x, n_out, bs)
+        assert float(np.abs(got - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
+        with pytest.raises(ElemHipError):
+            a.process_blocks(2, n_out)
+        assert a.stats()["spec_launches"] > 0

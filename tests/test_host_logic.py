@@ -298,3 +298,22 @@ def test_island_program_cache_reuses_unchanged_islands():
         assert rt.render(*roots[:1])["result"] == 0
         assert rt.render(*roots)["result"] == 0
     assert rt.describe_plan()["plan_cache_mismatches"] == 0
+
+
+def test_block_sizes_above_one_lds_slot():
+    """Runtime(sr, blockSize) (Runtime.h:44): up to 512 frames as given; a multiple of 512 is accepted (rendered in slices of 512),
+    a graph with taps — whose loop delay is the host's block — is then refused at commit; any other size above 512 fails at creation."""
+    from elementary_amd.runtime import ElemHipError
+    for bs in (1024, 2048, 32768):
+        rt = dry(48000.0, bs)
+        assert rt.block_size == bs
+        assert rt.render(el.mul(0.5, el.cycle(220.0)))["result"] == 0
+        loop = el.tapOut({"name": "fb"}, el.add(el.in_({"channel": 0}), el.mul(0.5, el.tapIn({"name": "fb"}))))
+        assert rt.render(loop)["result"] == 104                      # UnsupportedGraph
+        assert rt.render(el.mul(0.25, el.cycle(330.0)))["result"] == 0  # and the runtime goes on
+    for bs in (513, 700, 1000, 512 * 65):
+        with pytest.raises(ElemHipError):
+            dry(48000.0, bs)
+    ok = dry(48000.0, 512)
+    loop = el.tapOut({"name": "fb"}, el.add(el.in_({"channel": 0}), el.mul(0.5, el.tapIn({"name": "fb"}))))
+    assert ok.render(loop)["result"] == 0
