@@ -1396,7 +1396,8 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "spec_blocks") { specBlocks = value != 0; return kOk; }      // elemhip_process through the specialised kernels when it can
     if (key == "batch_blocks") { batchBlocks = std::max(1, std::min(1024, (int)value)); return kOk; }      // blocks per multi-block launch (1 = off)
     if (key == "debug_build_delay_ms") { debugBuildDelayMs = std::max(0, (int)value); return kOk; }   // tests: stretches the unlocked part of a plan build
-    if (key == "plan_cache") { planCache = std::max(0, std::min(2, (int)value)); islandCache.clear(); return kOk; }
+    if (key == "plan_cache") { planCache = std::max(0, std::min(2, (int)value)); islandCache.clear(); islandShapeCache.clear(); return kOk; }
+    if (key == "plan_relocate") { relocatePrograms = value != 0; islandShapeCache.clear(); return kOk; }   // programs of structural twins renamed instead of scheduled again
     if (key == "fuse_svf_coef") { fuseSvfCoef = (uint32_t)std::max(0, std::min(2, (int)value)); planStale = true; return kOk; }
     if (key == "solo_waves") { soloWaves = (uint32_t)std::max(0, std::min(3, (int)value)); planStale = true; return kOk; }
     if (key == "mixer_split") { const int v = (int)value; mixerSplit = (v == 2 || v == 4 || v == 8) ? (uint32_t)v : 1u; planStale = true; return kOk; }

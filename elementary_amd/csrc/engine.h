@@ -128,6 +128,13 @@ struct IslandProgram {
     Island I;                            // progBegin / rootRec are re-made per plan
     std::vector<uint32_t> blob;          // host copy of the program (16-byte padded): describePlan, plan_cache = 2
     std::vector<uint32_t> members;       // (node id, opcode, record, arena buffer) of every member in render order: checked on a cache hit (the key is a hash)
+    // relocation (plan.cpp, "same island, other nodes"): the records and arena buffers the program names, in the order a canonical
+    // walk of the island meets them, and the first stream buffer it was given — an island of the same STRUCTURE (another voice of
+    // the patch) takes this program with the i-th record / buffer replaced by its own i-th
+    std::vector<uint32_t> canonRecs, canonHbms;
+    uint32_t streamStart = 0;
+    uint32_t specHbmTab = 0;             // entries of the specialised variant's arena table (behind the record table; its operand table follows)
+    uint64_t shapeKey = 0;
     std::shared_ptr<ProgHeap> heap;      // where the device copy lives ...
     uint32_t heapBegin = 0;              // ... as a dword offset (= Island::progBegin of every plan that uses it)
     std::shared_ptr<SpecText> spec;      // specialised-kernel text of its shape (null: none)
@@ -145,6 +152,7 @@ struct Stats {
     uint64_t fusedEpilogues = 0;         // launch sets of one whose last level kernel ran the epilogue
     uint64_t progHeaps = 0;              // program heaps started (1 = the first still serves)
     uint64_t planIslandsReused = 0, planIslandsScheduled = 0, planCacheMismatches = 0;   // island program cache (plan.cpp)
+    uint64_t planIslandsRelocated = 0, planRelocationMismatches = 0;                      // ... programs taken from a structural twin
     uint64_t specLaunches = 0;             // launches of run-time specialised island kernels
     uint32_t specShapes = 0, specIslands = 0;
     double   lastJitWaitMs = 0.0;
@@ -224,6 +232,8 @@ private:
     std::unordered_map<int32_t, Node> nodes;
     std::shared_ptr<TablePool> tablePool = std::make_shared<TablePool>();
     std::shared_ptr<ProgHeap> progHeap;    // island programs on the device (plan.cpp); owned by the mutator side (`ctl`)
+    std::unordered_map<uint64_t, std::shared_ptr<IslandProgram>> islandShapeCache;   // structure -> a program of that structure (relocated for its peers)
+    bool relocatePrograms = true;          // option "plan_relocate"
     size_t lastPlanProgDwords = 0, progHeapCap = 0;
     std::set<int32_t> currentRoots;
     std::unordered_map<std::string, ResourcePtr> resources;

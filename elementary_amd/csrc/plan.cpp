@@ -611,6 +611,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     p.islandProg.assign(ib.size(), nullptr);
     p.islandRoot.assign(ib.size(), 0);
     std::vector<uint32_t> scheduled;         // islands whose program this build made (p.prog holds them, progBegin relative to it)
+    std::vector<uint32_t> canonRecs, canonHbms;   // the island's records / arena buffers in the order its canonical walk meets them
+    std::vector<uint32_t> relocated;         // plan_cache = 2: the twin's renamed program, to be compared with the fresh schedule
     std::vector<int> convLevel;              // launch level of p.convs[i]
     for (size_t ii = 0; ii < ib.size(); ++ii) {
         IslandBuild& B = ib[ii];
@@ -668,8 +670,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         // `plan_cache` = 2 schedules anyway and compares (tests).
         const uint32_t streamStart = p.numStreamBuffers;
         const auto tIsl0 = std::chrono::steady_clock::now();
-        uint64_t ikey = 0;
-        std::shared_ptr<IslandProgram> cached;
+        uint64_t ikey = 0, skey = 0;
+        std::shared_ptr<IslandProgram> cached, twin;     // exact hit (program on the device already) / structural twin (its program, renamed)
         if (e.planCache != 0) {
             uint64_t h = 1469598103934665603ull;
             auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ull; h ^= h >> 29; };
@@ -691,6 +693,48 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 }
             }
             ikey = h;
+            // the same walk with every record / arena buffer replaced by the ordinal of its first appearance: the island's STRUCTURE
+            if (e.relocatePrograms) {
+                uint64_t g = 1469598103934665603ull;
+                auto smix = [&](uint64_t v) { g ^= v; g *= 1099511628211ull; g ^= g >> 29; };
+                canonRecs.clear(); canonHbms.clear();
+                auto recOrd = [&](uint32_t r) -> uint32_t {
+                    if (r == kNone) return kNone;
+                    for (size_t q = 0; q < canonRecs.size(); ++q) if (canonRecs[q] == r) return (uint32_t)q;
+                    canonRecs.push_back(r); return (uint32_t)canonRecs.size() - 1u;
+                };
+                auto hbmOrd = [&](uint32_t b) -> uint32_t {
+                    if (b == kNone) return kNone;
+                    if (b < kMaxHostIn) return 0x40000000u | b;             // host input slots are the same for everybody
+                    for (size_t q = 0; q < canonHbms.size(); ++q) if (canonHbms[q] == b) return (uint32_t)q;
+                    canonHbms.push_back(b); return (uint32_t)canonHbms.size() - 1u;
+                };
+                auto posIn = [&](int niIndex) -> uint32_t {          // position of an island member (B.nodes is sorted)
+                    auto f = std::lower_bound(B.nodes.begin(), B.nodes.end(), niIndex);
+                    return (f != B.nodes.end() && *f == niIndex) ? (uint32_t)(f - B.nodes.begin()) : 0xFFFFu;
+                };
+                smix(bs); smix(maxCopies); smix(splitCoefStage); smix(wantSpec); smix(e.fuseSvfCoef); smix(e.mergePhases); smix(e.soloWaves);
+                smix(e.mixerSplit); smix(e.chainLdsOut); smix(packCount[ii]); smix((uint32_t)islandPairsTaps[ii]);
+                smix(B.nodes.size());
+                for (int k : B.nodes) {
+                    const NI& x = ni[k];
+                    smix(x.n->op); smix(recOrd(x.rec)); smix(x.ch); smix((uint32_t)x.kind); smix(x.exported); smix(hbmOrd(x.hbm)); smix(x.elided);
+                    smix(x.fusedRoot >= 0 ? recOrd(ni[(size_t)x.fusedRoot].n->rec) : kNone); smix(x.needLds);
+                    const int tw = tapWriter[(size_t)k];
+                    smix(tw >= 0 ? (posIn(tw) != 0xFFFFu ? posIn(tw) : 0x10000u | recOrd(ni[(size_t)tw].rec)) : 0xFFFFFFu);
+                    smix(x.n->inlets.size());
+                    for (auto& in : x.n->inlets) {
+                        smix(in.channel);
+                        auto it2 = idx.find(K(in.source, in.channel));
+                        if (it2 == idx.end()) { smix(0xDEADu); continue; }
+                        const NI& sn = ni[it2->second];
+                        const bool inside = sn.island == x.island;
+                        smix((uint32_t)sn.kind); smix(inside); smix(inside ? posIn(it2->second) : 0xFFFFu);
+                        smix(hbmOrd(sn.hbm)); smix(recOrd(sn.rec)); smix(sn.elided); smix(sn.n->op);
+                    }
+                }
+                skey = g;
+            }
             auto it = e.islandCache.find(ikey);
             if (it != e.islandCache.end() && it->second->heap == e.progHeap) {
                 // the key is 64 bits of hash: a hit is only taken when the members it was built from are the members in front of us
@@ -716,6 +760,77 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 p.numTasks += I.numTasks; p.numMembers += cached->numMembers; p.numOperands += cached->numOperands;
                 e.st.planIslandsReused++;
                 continue;
+            }
+            // ---- same structure, other nodes (another voice of the patch; the voice that replaces one): the twin's program with the
+            // i-th record / arena buffer it names replaced by this island's i-th, stream buffers moved to this island's first. Any
+            // reference the canonical walk did not meet makes the attempt fail and the island is scheduled as usual.
+            if (skey != 0 && !cached) {
+                auto ts = e.islandShapeCache.find(skey);
+                if (ts != e.islandShapeCache.end() && ts->second->canonRecs.size() == canonRecs.size() && ts->second->canonHbms.size() == canonHbms.size() &&
+                    ts->second->members.size() == 4 * B.nodes.size())
+                    twin = ts->second;
+            }
+            if (twin) {
+                std::vector<uint32_t> blob(twin->blob);
+                const Island& T = twin->I;
+                bool ok = true;
+                auto mapRec = [&](uint32_t r) -> uint32_t {
+                    for (size_t q = 0; q < twin->canonRecs.size(); ++q) if (twin->canonRecs[q] == r) return canonRecs[q];
+                    ok = false; return r;
+                };
+                auto mapHbm = [&](uint32_t b) -> uint32_t {          // an arena index as stored in outHbm fields / operand values (kNone handled by callers)
+                    if (b & kOpStream) return kOpStream | ((b & ~kOpStream) - twin->streamStart + streamStart);
+                    if (b < kMaxHostIn) return b;
+                    for (size_t q = 0; q < twin->canonHbms.size(); ++q) if (twin->canonHbms[q] == b) return canonHbms[q];
+                    ok = false; return b;
+                };
+                auto mapOpnd = [&](uint32_t o) -> uint32_t { return (o & kOpKindMask) == kOpHbm ? (kOpHbm | mapHbm(o & kOpValMask)) : o; };
+                const uint32_t numMembers = twin->numMembers, numOperands = twin->numOperands;
+                for (uint32_t d = 0; d < T.copies && ok; ++d) {
+                    uint32_t* c0 = blob.data() + (size_t)d * T.copyDwords;
+                    for (uint32_t t = 0; t < T.numTasks; ++t) {
+                        Task* tk = reinterpret_cast<Task*>(c0 + t * 8u);
+                        tk->o0 = mapOpnd(tk->o0); tk->o1 = mapOpnd(tk->o1);
+                        if (tk->outHbm != kNone) tk->outHbm = mapHbm(tk->outHbm);
+                    }
+                    for (uint32_t m = 0; m < numMembers; ++m) {
+                        Member* mb = reinterpret_cast<Member*>(c0 + T.memOff + m * 8u);
+                        if (mb->outHbm != kNone) mb->outHbm = mapHbm(mb->outHbm);
+                    }
+                    for (uint32_t o = 0; o < numOperands; ++o) c0[T.opndOff + o] = mapOpnd(c0[T.opndOff + o]);
+                }
+                for (uint32_t q = 0; q < T.numCells && ok; ++q) blob[T.cellOff + 2u * q + 1u] = mapRec(blob[T.cellOff + 2u * q + 1u]);
+                for (uint32_t q = 0; q < T.numRecs && ok; ++q) blob[T.recOff + q] = mapRec(blob[T.recOff + q]);
+                // behind the record table: the specialised variant's arena table, then its operand table (to the end of the program)
+                const uint32_t tail0 = T.recOff + T.numRecs, tailN = T.progDwords - tail0;
+                if (ok && tailN < twin->specHbmTab) ok = false;
+                for (uint32_t q = 0; q < twin->specHbmTab && ok; ++q) blob[tail0 + q] = mapHbm(blob[tail0 + q]);
+                for (uint32_t q = twin->specHbmTab; q < tailN && ok; ++q) blob[tail0 + q] = mapOpnd(blob[tail0 + q]);
+                if (!ok) { twin.reset(); e.st.planRelocationMismatches++; }
+                else if (e.planCache == 1) {
+                    I = T;
+                    I.progBegin = (uint32_t)p.prog.size();      // (local to this build's staging; moved into the heap below)
+                    I.rootRec = seqRoots[B.seq]->rec;
+                    p.prog.insert(p.prog.end(), blob.begin(), blob.end());
+                    auto ent = std::make_shared<IslandProgram>();
+                    ent->I = I; ent->blob.swap(blob); ent->spec = twin->spec;
+                    ent->numMembers = twin->numMembers; ent->numOperands = twin->numOperands; ent->streamDelta = twin->streamDelta;
+                    ent->specHbmTab = twin->specHbmTab;
+                    ent->canonRecs = canonRecs; ent->canonHbms = canonHbms; ent->streamStart = streamStart; ent->shapeKey = skey;
+                    ent->members.reserve(4 * B.nodes.size());
+                    for (int k : B.nodes) { const NI& x = ni[k]; ent->members.insert(ent->members.end(), {(uint32_t)x.n->id, (uint32_t)x.n->op | (x.ch << 16), x.rec, x.hbm}); }
+                    p.islandProg[ii] = ent; scheduled.push_back((uint32_t)ii);
+                    p.progDwordsTotal += ent->blob.size();
+                    p.numStreamBuffers += ent->streamDelta;
+                    if (packCount[ii] > 1u) minPackedCopies = minPackedCopies ? std::min(minPackedCopies, I.copies) : I.copies;
+                    p.maxCopies = std::max(p.maxCopies, I.copies);
+                    p.maxLdsBytes = std::max(p.maxLdsBytes, I.ldsWords * 4u);
+                    if (ent->spec) { if (p.specText.size() < ib.size()) p.specText.resize(ib.size()); p.specText[ii] = ent->spec; }
+                    p.numTasks += I.numTasks; p.numMembers += ent->numMembers; p.numOperands += ent->numOperands;
+                    e.islandCache[ikey] = ent;
+                    e.st.planIslandsRelocated++;
+                    continue;
+                } else relocated.swap(blob);                    // plan_cache = 2: schedule anyway, then compare with this
             }
         }
         // imports needed in LDS: external producers (or host inputs) feeding chain members
@@ -1500,6 +1615,16 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             for (int k : B.nodes) { const NI& x = ni[k]; ent->members.insert(ent->members.end(), {(uint32_t)x.n->id, (uint32_t)x.n->op | (x.ch << 16), x.rec, x.hbm}); }
             p.islandProg[ii] = ent; scheduled.push_back((uint32_t)ii);
             p.progDwordsTotal += ent->blob.size();
+            ent->specHbmTab = (uint32_t)sp.hbmTab.size();
+            if (skey != 0) {
+                ent->canonRecs = canonRecs; ent->canonHbms = canonHbms; ent->streamStart = streamStart; ent->shapeKey = skey;
+                if (e.planCache != 0 && !e.islandShapeCache.count(skey)) e.islandShapeCache[skey] = ent;
+            }
+            if (!relocated.empty()) {       // plan_cache = 2: the twin's renamed program must be what was just scheduled
+                if (relocated != ent->blob) { e.st.planRelocationMismatches++; std::fprintf(stderr, "[elemhip] plan cache: island %zu: the relocated program of its twin differs from its own schedule\n", ii); }
+                else e.st.planIslandsRelocated++;
+                relocated.clear();
+            }
             if (ii < p.specText.size()) ent->spec = p.specText[ii];
             ent->numMembers = (uint32_t)members.size(); ent->numOperands = (uint32_t)operands.size();
             ent->streamDelta = p.numStreamBuffers - streamStart;
@@ -1582,6 +1707,7 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     // the text cache is only ever trimmed BETWEEN builds (texts in use stay alive through the shared objects the plan holds)
     if (specTextCache.size() > 4096) specTextCache.clear();
     if (islandCache.size() > 2048) islandCache.clear();      // (entries of replaced islands are never looked up again: ~8 KB each)
+    if (islandShapeCache.size() > 512) islandShapeCache.clear();
     // Lane-packing (option "pack_islands": 0 auto, 1 off, K): the first attempt packs as the option says; a packed island
     // that does not fit in LDS, or fits with a single buffer set (no blocks in flight: the stages of a block would run back
     // to back), sends the build back with one island fewer per pack.
@@ -1770,7 +1896,8 @@ std::string Engine::describePlan() {
     auto kv = [&](const char* k, uint64_t v, bool comma = true) { s += "\"" + std::string(k) + "\":" + std::to_string(v) + (comma ? "," : ""); };
     kv("num_islands", p.islands.size()); kv("num_levels", p.levelOffsets.size() - 1); kv("num_tasks", p.numTasks);
     kv("num_members", p.numMembers); kv("num_operands", p.numOperands); kv("num_nodes", p.nodeIds.size());
-    kv("plan_spec_fade_blocks", st.specFadeBlocks); kv("plan_idle_launches_skipped", st.idleLaunchesSkipped); kv("plan_fused_epilogues", st.fusedEpilogues); kv("plan_prog_heaps", st.progHeaps); kv("plan_prog_heap_used_dwords", p.progHeap ? p.progHeap->usedDwords : 0);
+    kv("plan_islands_relocated", st.planIslandsRelocated); kv("plan_relocation_mismatches", st.planRelocationMismatches);
+    kv("plan_spec_texts", specTextCache.size()); kv("plan_spec_fade_blocks", st.specFadeBlocks); kv("plan_idle_launches_skipped", st.idleLaunchesSkipped); kv("plan_fused_epilogues", st.fusedEpilogues); kv("plan_prog_heaps", st.progHeaps); kv("plan_prog_heap_used_dwords", p.progHeap ? p.progHeap->usedDwords : 0);
     kv("plan_islands_reused", st.planIslandsReused); kv("plan_islands_scheduled", st.planIslandsScheduled); kv("plan_cache_mismatches", st.planCacheMismatches);
     kv("num_hbm_buffers", p.numHbmBuffers); kv("num_stream_buffers", p.numStreamBuffers); kv("pack_k", p.packK);
     kv("max_lds_bytes", p.maxLdsBytes); kv("num_roots", p.roots.size());

@@ -271,6 +271,10 @@ def test_island_program_cache_reuses_unchanged_islands():
                 rt.gc()
         plans[mode] = rt.describe_plan()
     assert plans[2]["plan_cache_mismatches"] == 0 and plans[2]["plan_islands_scheduled"] > 24 * 128
+    # an island with the STRUCTURE of one scheduled before (another voice of the patch, the voice that replaces one) takes that
+    # program with its records / arena buffers renamed; verify mode schedules it anyway and compares the two, bit for bit
+    assert plans[2]["plan_relocation_mismatches"] == 0 and plans[2]["plan_islands_relocated"] >= 127 + 24
+    assert plans[1]["plan_islands_relocated"] >= 127 + 24 and plans[1]["plan_islands_scheduled"] <= 8
     assert plans[1]["plan_islands_reused"] > 20 * 120                 # ~126 of 130 islands per re-plan
     strip = lambda p: {k: v for k, v in p.items() if not k.startswith("plan_") and k != "build_us"}      # noqa: E731
     assert strip(plans[1]) == strip(plans[0]) == strip(plans[2])
