@@ -694,7 +694,9 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             }
             ikey = h;
             // the same walk with every record / arena buffer replaced by the ordinal of its first appearance: the island's STRUCTURE
-            if (e.relocatePrograms) {
+            // (only for islands the exact key does not find: an unchanged island of a live graph pays for one walk, not two)
+            const bool exactKnown = e.planCache == 1 && e.islandCache.count(ikey) != 0;
+            if (e.relocatePrograms && !exactKnown) {
                 uint64_t g = 1469598103934665603ull;
                 auto smix = [&](uint64_t v) { g ^= v; g *= 1099511628211ull; g ^= g >> 29; };
                 canonRecs.clear(); canonHbms.clear();
