@@ -1271,6 +1271,7 @@ size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
         }
         nodes.erase(id);
     }
+    if (!pruned.empty()) { if (++nodesEpoch == 0u) nodesEpoch = 1u; }      // (Inlet::src memos name erased nodes now)
     std::sort(pruned.begin(), pruned.end());
     size_t k = 0;
     for (int32_t id : pruned) { if (out && k < cap) out[k] = id; ++k; }

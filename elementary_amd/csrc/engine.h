@@ -64,12 +64,17 @@ struct Resource {
 };
 using ResourcePtr = std::shared_ptr<Resource>;
 
-struct Inlet  { int32_t source; uint32_t channel; };
+struct Node;
+// (`src` / `srcEpoch`: the planner's memo of nodes.find(source) — valid while Engine::nodesEpoch, which every erase from the node
+//  table bumps, equals srcEpoch; node addresses are stable under insertion)
+struct Inlet  { int32_t source; uint32_t channel; mutable Node* src = nullptr; mutable uint32_t srcEpoch = 0; };
 struct Outlet { int32_t dest; uint32_t channel; };
 
 struct Node {
     int32_t id = 0;
     uint32_t planVisited = 0, planOnStack = 0;   // plan-build scratch (PlanBuilder::traverse): epoch marks instead of hash sets
+    int32_t planIdx = -1;                        // ... planner entry of output channel 0 in the build whose epoch is planVisited
+    uint32_t planChans = 0;                      // ... and how many channel entries follow it
     uint16_t op = OP_INVALID;
     uint32_t rec = kNone;
     std::vector<Inlet> inlets;
@@ -230,6 +235,7 @@ private:
     Stats st;
 
     std::unordered_map<int32_t, Node> nodes;
+    uint32_t nodesEpoch = 1;               // bumped whenever a node leaves `nodes` (Inlet::src memos of the planner)
     std::shared_ptr<TablePool> tablePool = std::make_shared<TablePool>();
     std::shared_ptr<ProgHeap> progHeap;    // island programs on the device (plan.cpp); owned by the mutator side (`ctl`)
     std::unordered_map<uint64_t, std::shared_ptr<IslandProgram>> islandShapeCache;   // structure -> a program of that structure (relocated for its peers)

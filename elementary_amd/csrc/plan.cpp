@@ -189,6 +189,25 @@ struct PlanBuilder {
     std::vector<std::vector<int>> seqNodes; // per root sequence
     std::vector<Node*> seqRoots;
 
+    // (node, channel) of an inlet -> planner entry, through the memo the render-order walk left in the inlet (no hashing): what
+    // srcOf(in) answers, for the ~20 questions per inlet the phases ask
+    struct Hit {
+        int second; bool ok;
+        const Hit* operator->() const { return this; }
+        bool operator==(const FlatIdx::Slot* p) const { return p == nullptr && !ok; }
+        bool operator!=(const FlatIdx::Slot* p) const { return !(*this == p); }
+    };
+    uint32_t buildEpoch = 0;
+    Hit srcOf(const Inlet& in) const {
+        const Node* c = in.srcEpoch == e.nodesEpoch ? in.src : nullptr;
+        if (c) {
+            if (c->planVisited != buildEpoch || in.channel >= c->planChans) return Hit{-1, false};
+            return Hit{c->planIdx + (int)in.channel, true};
+        }
+        const FlatIdx::Slot* s = idx.find(K(in.source, in.channel));      // (an inlet of a node the walk did not reach, a missing source)
+        return s ? Hit{s->second, true} : Hit{-1, false};
+    }
+
     void traverse(uint32_t epoch, std::vector<Node*>& order, Node* root) {
         // iterative DFS post-order, children in inlet order (Runtime.h:502-518); visited / on-stack are epoch marks in the nodes
         struct Frame { Node* n; size_t next; };
@@ -200,11 +219,16 @@ struct PlanBuilder {
             Frame& f = st.back();
             Node& n = *f.n;
             if (f.next < n.inlets.size()) {
-                const int32_t c = n.inlets[f.next++].source;
-                auto it = e.nodes.find(c);
-                if (it == e.nodes.end() || it->second.planVisited == epoch || it->second.planOnStack == epoch) continue;
-                it->second.planOnStack = epoch;
-                st.push_back({&it->second, 0});
+                const Inlet& in = n.inlets[f.next++];
+                Node* c = in.srcEpoch == e.nodesEpoch ? in.src : nullptr;
+                if (!c) {                                    // (misses are not remembered: the node may be created later)
+                    auto it = e.nodes.find(in.source);
+                    if (it == e.nodes.end()) continue;
+                    c = &it->second; in.src = c; in.srcEpoch = e.nodesEpoch;
+                }
+                if (c->planVisited == epoch || c->planOnStack == epoch) continue;
+                c->planOnStack = epoch;
+                st.push_back({c, 0});
             } else {
                 order.push_back(f.n);
                 n.planVisited = epoch;
@@ -257,6 +281,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
     }
     if (++e.planEpoch == 0u) { for (auto& kv : e.nodes) kv.second.planVisited = kv.second.planOnStack = 0u; e.planEpoch = 1u; }
     const uint32_t epoch = e.planEpoch;
+    buildEpoch = epoch;
     idx.reserve(2 * e.nodes.size() + 64);   // (one entry per node and output channel; the table doubles that again)
     ni.reserve(e.nodes.size() + 16);
     std::vector<int32_t> planNodeIds;
@@ -271,6 +296,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             const int32_t id = node.id;
             uint32_t numOuts = 1;                       // getRequiredOutputChannels (GraphRenderSequence.h:15-24)
             if (node.mc) for (auto& o : node.outlets) numOuts = std::max(numOuts, std::min<uint32_t>(o.channel + 1u, 16u));
+            node.planIdx = (int32_t)ni.size(); node.planChans = numOuts;
             for (uint32_t ch = 0; ch < numOuts; ++ch) {
                 NI x;
                 x.n = &node;
@@ -361,7 +387,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         const uint32_t w = 1 + scratchSlots(x.n->op);
         deps.clear(); foreign.clear();
         for (auto& in : x.n->inlets) {
-            auto it = idx.find(K(in.source, in.channel));
+            auto it = srcOf(in);
             if (it == idx.end()) continue;
             NI& s = ni[it->second];
             if (s.kind == K_CONST) continue;
@@ -449,7 +475,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         NI& x = ni[k];
         if (x.kind == K_CONST) continue;
         for (auto& in : x.n->inlets) {
-            auto it = idx.find(K(in.source, in.channel));
+            auto it = srcOf(in);
             if (it == idx.end()) continue;
             NI& s = ni[it->second];
             if (s.kind == K_CONST) continue;
@@ -628,7 +654,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             if (x.n->inlets.empty()) d.inKind = 3;                                      // leaf: host input 0
             else {
                 const Inlet& in = x.n->inlets[0];
-                auto it = idx.find(K(in.source, in.channel));
+                auto it = srcOf(in);
                 if (it == idx.end()) d.inKind = 4;
                 else if (ni[it->second].elided) { d.inKind = 5; d.inIdx = ni[it->second].n->rec; }   // host channel named by the `in` record
                 else if (ni[it->second].kind == K_CONST) { d.inKind = 2; d.inIdx = ni[it->second].n->rec; }
@@ -651,7 +677,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             }
             d.leaf = x.n->inlets.empty();
             for (auto& in : x.n->inlets) {
-                auto it = idx.find(K(in.source, in.channel));
+                auto it = srcOf(in);
                 if (it == idx.end()) d.inputs.push_back({0, 0u, 0.0f});
                 else if (ni[it->second].kind == K_CONST && !ni[it->second].elided) d.inputs.push_back({2, ni[it->second].n->rec, 0.0f});
                 else if (ni[it->second].elided && ni[it->second].n->op == OP_IN) d.inputs.push_back({3, ni[it->second].n->rec, 0.0f});
@@ -686,7 +712,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 mix(x.n->inlets.size());
                 for (auto& in : x.n->inlets) {
                     mix((uint32_t)in.source); mix(in.channel);
-                    auto it = idx.find(K(in.source, in.channel));
+                    auto it = srcOf(in);
                     if (it == idx.end()) { mix(0xDEADu); continue; }
                     const NI& sn = ni[it->second];
                     mix((uint32_t)sn.kind); mix(sn.island == x.island); mix(sn.hbm); mix(sn.rec); mix(sn.elided); mix(sn.n->op);
@@ -727,7 +753,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                     smix(x.n->inlets.size());
                     for (auto& in : x.n->inlets) {
                         smix(in.channel);
-                        auto it2 = idx.find(K(in.source, in.channel));
+                        auto it2 = srcOf(in);
                         if (it2 == idx.end()) { smix(0xDEADu); continue; }
                         const NI& sn = ni[it2->second];
                         const bool inside = sn.island == x.island;
@@ -850,7 +876,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             if (x.kind != K_CHAIN) continue;
             if (x.n->inlets.empty()) { if (leafArity(x.n->op) > 0) anyImport = true; continue; }
             for (auto& in : x.n->inlets) {
-                auto it = idx.find(K(in.source, in.channel));
+                auto it = srcOf(in);
                 if (it == idx.end()) continue;
                 NI& s = ni[it->second];
                 if (s.kind != K_CONST && s.island != x.island) anyImport = true;
@@ -865,7 +891,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             NI& x = ni[k];
             int lv = base, sub = 0;
             for (auto& in : x.n->inlets) {
-                auto it = idx.find(K(in.source, in.channel));
+                auto it = srcOf(in);
                 if (it == idx.end()) continue;
                 NI& s = ni[it->second];
                 if (s.kind == K_CONST || s.island != x.island) continue;
@@ -898,7 +924,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         for (int k : B.nodes) {
             NI& x = ni[k];
             for (auto& in : x.n->inlets) {
-                auto it = idx.find(K(in.source, in.channel));
+                auto it = srcOf(in);
                 if (it == idx.end()) continue;
                 NI& s = ni[it->second];
                 if (s.kind == K_CONST) continue;
@@ -1026,7 +1052,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             }
             m.nin = (uint32_t)x.n->inlets.size();
             for (auto& in : x.n->inlets) {
-                auto it = idx.find(K(in.source, in.channel));
+                auto it = srcOf(in);
                 if (it == idx.end()) { operandSrc.push_back(-1); operands.push_back(kOpZero); continue; }
                 NI& s = ni[it->second];
                 if (s.kind == K_CONST) { operandSrc.push_back(-1); operands.push_back(kOpConst | cellFor(s.n)); }
@@ -1045,7 +1071,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             size_t direct = 0;
             for (int k : B.nodes)
                 for (auto& in : ni[k].n->inlets) {
-                    auto it = idx.find(K(in.source, in.channel));
+                    auto it = srcOf(in);
                     if (it != idx.end() && ni[it->second].kind != K_CONST && ni[it->second].island != ni[k].island) direct++;
                 }
             mixerLike = direct >= 8;
@@ -1092,7 +1118,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
         auto constMaskOf = [&](const NI& x) -> uint32_t {
             uint32_t mask = 0;
             for (size_t q = 0; q < x.n->inlets.size() && q < 8; ++q) {
-                auto it = idx.find(K(x.n->inlets[q].source, x.n->inlets[q].channel));
+                auto it = srcOf(x.n->inlets[q]);
                 if (it == idx.end()) { mask |= 1u << q; continue; }   // zero operand
                 if (ni[it->second].kind == K_CONST) mask |= 1u << q;
             }
