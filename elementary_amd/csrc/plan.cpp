@@ -453,14 +453,13 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
 
     // canonical island list
     std::vector<IslandBuild> ib;
-    std::unordered_map<int, int> islandOf;   // uf representative -> dense index
+    std::vector<int> islandOf(uf.p.size(), -1);   // uf representative -> dense index (in order of first appearance)
     for (size_t k = 0; k < ni.size(); ++k) {
         NI& x = ni[k];
         if (x.kind == K_CONST) continue;
         const int r = rep(x.island);
-        auto it = islandOf.find(r);
-        if (it == islandOf.end()) { it = islandOf.emplace(r, (int)ib.size()).first; ib.emplace_back(); ib.back().seq = x.seq; }
-        x.island = it->second;
+        if (islandOf[(size_t)r] < 0) { islandOf[(size_t)r] = (int)ib.size(); ib.emplace_back(); ib.back().seq = x.seq; }
+        x.island = islandOf[(size_t)r];
         ib[x.island].nodes.push_back((int)k);
     }
 
@@ -721,7 +720,8 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             ikey = h;
             // the same walk with every record / arena buffer replaced by the ordinal of its first appearance: the island's STRUCTURE
             // (only for islands the exact key does not find: an unchanged island of a live graph pays for one walk, not two)
-            const bool exactKnown = e.planCache == 1 && e.islandCache.count(ikey) != 0;
+            auto it = e.islandCache.find(ikey);
+            const bool exactKnown = e.planCache == 1 && it != e.islandCache.end();
             if (e.relocatePrograms && !exactKnown) {
                 uint64_t g = 1469598103934665603ull;
                 auto smix = [&](uint64_t v) { g ^= v; g *= 1099511628211ull; g ^= g >> 29; };
@@ -763,7 +763,6 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
                 }
                 skey = g;
             }
-            auto it = e.islandCache.find(ikey);
             if (it != e.islandCache.end() && it->second->heap == e.progHeap) {
                 // the key is 64 bits of hash: a hit is only taken when the members it was built from are the members in front of us
                 const std::vector<uint32_t>& m = it->second->members;
