@@ -321,3 +321,35 @@ def test_block_sizes_above_one_lds_slot():
     ok = dry(48000.0, 512)
     loop = el.tapOut({"name": "fb"}, el.add(el.in_({"channel": 0}), el.mul(0.5, el.tapIn({"name": "fb"}))))
     assert ok.render(loop)["result"] == 0
+
+
+def _verify_mode(sr, renders, opts=()):
+    rt = dry(sr)
+    rt.set_option("specialize", 2)
+    rt.set_option("plan_cache", 2)
+    for k, v in opts:
+        rt.set_option(k, v)
+    from cases import node_case_resources
+    for name, data in node_case_resources().items():
+        rt.add_shared_resource(name, data)
+    for roots in renders:
+        assert rt.render(*roots)["result"] == 0
+    d = rt.describe_plan()
+    return d["plan_islands_relocated"], d["plan_relocation_mismatches"] + d["plan_cache_mismatches"]
+
+
+def test_relocated_programs_in_verify_mode():
+    """plan_cache = 2 over graph families with structural twins: an island that takes the renamed program of a twin (plan.cpp,
+    "same structure, other nodes") is scheduled anyway and the two blobs compared. Every node case in ONE engine (twins across
+    cases), 16 / 48 / 300 voices (unpacked and lane-packed), render jobs packed across roots, tap loops: no mismatch, and the path
+    is really taken."""
+    from cases import NODE_CASES
+    total = 0
+    for sr, renders, opts in ((44100.0, [NODE_CASES[n][0]() for n in sorted(NODE_CASES)], ()),
+                              (graphs.C2_SAMPLE_RATE, [graphs.c2_graph(voices=v) for v in (16, 48)], ()),
+                              (graphs.C2_SAMPLE_RATE, [graphs.c2_graph(voices=300)], (("cu_count", 150),)),
+                              (graphs.C4_SAMPLE_RATE, [[graphs.c4_instance(k) for k in range(96)]], (("pack_roots", 1), ("cu_count", 32)))):
+        relocated, bad = _verify_mode(sr, renders, opts)
+        assert bad == 0, (sr, relocated, bad)
+        total += relocated
+    assert total >= 16 + 48 + 100
