@@ -169,7 +169,7 @@ def c4_cpu_baseline(inst: int, first: int = 0, target_seconds: float = 12.0):
     if not oracle.have_ref():
         return None
     avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
-    P = max(1, min(32, len(avail), inst))
+    P = max(1, min(len(avail), inst))            # every host core this process may use, up to one per job (no 32-core cap)
     ctx = mp.get_context("spawn")       # the parent holds a HIP context: never fork it
     with ctx.Pool(P) as pool:
         cal = pool.map(_c4_worker, [([first], 400, 0, avail[0])])[0][0] / 400.0          # seconds per job-block on one core
@@ -210,6 +210,38 @@ def c4_parity(timed_host, inst: int, first: int, total_blocks: int, tail: int = 
     return {"ok": bool(worst <= tol), "max_abs_err": worst, "tolerance": tol, "jobs_checked": [first + k for k in picks], "blocks_checked_per_job": tail,
             "reference_advanced_blocks": total_blocks, "max_abs_ref": peak,
             "what": f"last {tail} blocks of the timed region of {len(picks)} render jobs vs reference engines advanced from time zero through all {total_blocks} blocks"}
+
+
+def run_configs(names, timeout_s: float):
+    """The other configurations of BASELINE.json, driver-run (VERDICT r04 "next" #1): each in a process of its own AFTER the headline's
+    timed region (this process's engine is idle meanwhile), each record with its own value / ms_per_step x steps / roofline /
+    cpu_baseline / parity on the samples it timed (benchmarks/driver_configs.py; C4 is this script's own `--workload c4`). A
+    configuration that fails or runs out of time costs its own sub-record, never the headline line."""
+    import subprocess
+    recs = {}
+    t_all = time.perf_counter()
+    for name in names:
+        if name == "c4":
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c4", "--steps", "16", "--warmup", "4"]
+        else:
+            cmd = [sys.executable, os.path.join(ROOT, "benchmarks", "driver_configs.py"), name]
+        t0 = time.perf_counter()
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+            lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+            if res.returncode == 0 and lines:
+                rec = json.loads(lines[-1])
+            else:
+                rec = {"error": f"exit code {res.returncode}", "stderr_tail": res.stderr[-600:]}
+        except subprocess.TimeoutExpired:
+            rec = {"error": f"no result within {timeout_s:.0f} s"}
+        except Exception as e:      # noqa: BLE001
+            rec = {"error": repr(e)[:300]}
+        rec["wall_s"] = time.perf_counter() - t0
+        recs[name] = rec
+    recs["total_wall_s"] = time.perf_counter() - t_all
+    recs["all_parity_ok"] = all(bool((recs[n].get("parity") or {}).get("ok")) for n in names)
+    return recs
 
 
 def main_c4(args) -> None:
@@ -331,6 +363,7 @@ def main_c4(args) -> None:
                          "note": "bound by the float recurrences (biquad, delay feedback) of the instances, not by bytes; `traffic` = PMC HBM "
                                  "bytes of one launch set (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md)"},
             "cpu_baseline": base, "speedup_vs_cpu_baseline": (world * inst * BLOCK * blocks / dt) / base["value"] if base else None,
+            "speedup_vs_cpu_baseline_note": (f"GPU rate / the reference engine on ALL {base['cores']} host cores this process may use" if base else None),
             "parity": parity,
         }))
     if world > 1:
@@ -350,6 +383,9 @@ def main() -> None:
     ap.add_argument("--graph-blocks", type=int, default=8, help="blocks per captured hipGraph (per-block launch path)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the sub-records of the other configurations (C1, C3, C4, C5, C5 shape churn, taps)")
+    ap.add_argument("--configs", default="c1,c3,c4,c5,c5_churn,taps", help="which sub-records to append (comma separated)")
+    ap.add_argument("--config-timeout", type=float, default=240.0, help="seconds a sub-record's process may take before it is given up")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N > 1 ('nccl' = RCCL; 'gloo' lets a test run two ranks on ONE GPU)")
     ap.add_argument("--shared-gpu", action="store_true", help="testing: every rank uses cuda:0 (needs --backend gloo)")
@@ -535,6 +571,12 @@ def main() -> None:
                 import bench_configs as _bc
                 sync_native = _bc._native_host(graphs.c2_graph(voices=my_voices, channels=2, first_voice=first), graphs.C2_SAMPLE_RATE, blocks=2000,
                                                env={"ELEMHIP_SPECIALIZE": "2"})
+                # ... and at the PRODUCT default (background compilation: the kernel cache on disk is warm here, so the specialised kernels
+                # are there from the first blocks; a cold cache renders through the interpreter kernels until the compiles finish)
+                if isinstance(sync_native, dict) and "error" not in sync_native:
+                    sync_native["specialize"] = 2
+                    sync_native["product_default_specialize_1"] = _bc._native_host(
+                        graphs.c2_graph(voices=my_voices, channels=2, first_voice=first), graphs.C2_SAMPLE_RATE, blocks=2000, env={"ELEMHIP_SPECIALIZE": "1"})
             except Exception as e:      # noqa: BLE001  (a missing binary is reported, not fatal)
                 sync_native = {"error": str(e)[:200]}
 
@@ -658,6 +700,8 @@ def main() -> None:
             out["parity_max_abs_err"] = err
             out["parity"] = {"tolerance": 1e-6, "ok": err <= 1e-6 * scale, "scale": scale,
                              "what": f"last {nb} blocks of the rank-0 reduced bus vs the reference engine rendering all {total_voices} voices"}
+        if world == 1 and not args.no_configs and my_voices == 256 and not args.device_resident:
+            out["configs"] = run_configs([c for c in args.configs.split(",") if c], args.config_timeout)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

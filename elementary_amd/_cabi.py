@@ -144,14 +144,21 @@ class CRuntime:
     def reset(self) -> None:
         self._fn("reset")(self._h)
 
-    def process_queued_events(self) -> List[tuple]:
-        """Runtime::processQueuedEvents (Runtime.h:64, 437-446): [(type, payload dict), ...] in relay order."""
+    def process_queued_events(self, blockwise: bool = False) -> List[tuple]:
+        """Runtime::processQueuedEvents (Runtime.h:64, 437-446): [(type, payload dict), ...] in relay order.
+        ``blockwise`` (HIP engine only): every block's events since the last relay, in block order — what a caller that relayed
+        after every block (offline-renderer/index.ts:112-120) would have collected."""
         import json
         got: List[tuple] = []
 
         def cb(kind, payload, _user):
             got.append((kind.decode(), json.loads(payload.decode())))
-        rc = self._fn("process_queued_events")(self._h, _EVENT_CB(cb), None)
+        name = "process_queued_events_blockwise" if blockwise else "process_queued_events"
+        if blockwise:
+            f = self._fn(name)
+            f.argtypes = [C.c_void_p, _EVENT_CB, C.c_void_p]
+            f.restype = C.c_int
+        rc = self._fn(name)(self._h, _EVENT_CB(cb), None)
         if rc != 0:
             raise RuntimeError(f"process_queued_events failed with code {rc}")
         return got

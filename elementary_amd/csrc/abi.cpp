@@ -153,6 +153,12 @@ int elemhip_process_queued_events(elemhip_t* h, elemhip_event_cb cb, void* user)
     return h->engine.processQueuedEvents(cb, user);
 }
 
+int elemhip_process_queued_events_blockwise(elemhip_t* h, elemhip_event_cb cb, void* user) {
+    if (!h) return elemhip::kInvalidInstructionFormat;
+    return h->engine.processQueuedEvents(cb, user, true);
+}
+uint32_t elemhip_event_window_blocks(elemhip_t* h) { return h ? h->engine.eventWindowBlocks() : 0u; }
+
 int elemhip_get_stats(elemhip_t* h, elemhip_stats* out) {
     if (!h || !out) return elemhip::kInvalidInstructionFormat;
     const elemhip::Stats& s = h->engine.stats();

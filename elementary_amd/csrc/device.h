@@ -277,6 +277,11 @@ enum : uint32_t {
     CAP_CH = P4,         // mc.capture: the output channel this record renders (channel 0's record carries the recording state)
     // meter: S0 min, S1 max, S2 readout count; snapshot: S0 previous trigger sample, S1 captured value, S2 capture count
     EVT_A = 8, EVT_B = 9, EVT_COUNT = 10,
+    // ... and a per-BLOCK readout log (r05): ring of 4-dword entries {block number of this node, a, b, -} behind EVT_LOG with EVT_LOGMASK + 1
+    // entries — meter: one entry per block (min, max), entry index = block number; snapshot: one entry per block that latched (value of the
+    // block's last latch, latches in the block), EVT_LOGN entries so far, EVT_BLK blocks so far. The reference's offline caller relays events
+    // after EVERY block (offline-renderer/index.ts:112-120); the log lets a host that rendered a whole launch set do the same afterwards.
+    EVT_LOG = P0, EVT_LOGMASK = P2, EVT_BLK = 11, EVT_LOGN = 12,
     // scope: device ring [4 channels][8192] (MultiChannelRingBuffer.h), write / read positions shared with the host relay
     SCP_RING = P0, SCP_WRITE = 8, SCP_READ = 9,
     // sample (Sample.h:22-231): buffer, length, new-buffer flag, mode (0 trigger, 1 gate, 2 loop), offsets, gain smoothing alpha;

@@ -223,6 +223,10 @@ Engine::~Engine() {
         if (evOut[k]) (void)hipEventDestroy(evOut[k]);
     }
     if (ioStream) (void)hipStreamDestroy(ioStream);
+    if (relayStream) { (void)hipStreamSynchronize(relayStream); (void)hipStreamDestroy(relayStream); }
+    if (evRelay) (void)hipEventDestroy(evRelay);
+    if (dRelay) (void)hipFree(dRelay);
+    if (hRelay) (void)hipHostFree(hRelay);
     if (ownStream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -364,7 +368,10 @@ uint32_t Engine::channelRec(Node& n, uint32_t ch) {
         else writeChannelBuffer(n, (uint32_t)n.chanRecs.size(), r);
         // channel 0 has been on the device already (it may be mid-playback): the new channel continues from channel 0's
         // LIVE reader state and consumed flags — the reference keeps one state for all channels (mc/Sample.h, mc/SampleSeq.h)
-        if (!freshFlag[n.rec]) recClones.push_back({n.rec, r});
+        // (mc.capture channels > 0 only pass an input through: they have no state to take over, and the clone — dwords P3.. of
+        //  channel 0's LIVE record — would overwrite the CAP_CH just set with channel 0's: the new channel would pass input 1 through
+        //  and record every block into the shared ring a second time)
+        if (!freshFlag[n.rec] && n.op != OP_CAPTURE) recClones.push_back({n.rec, r});
     }
     return n.chanRecs[ch - 1];
 }
@@ -560,6 +567,9 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
     } else if (nn.op == OP_TAPOUT) {                                              // Feedback.h:66-67
         rc = allocRing(nn, (size_t)blockSize);
         if (rc == kOk) writeParamPtr(nn, rec::TAP_PRIVATE, nn.ring.ptr);
+    } else if (nn.op == OP_METER || nn.op == OP_SNAPSHOT) {                       // per-block readout log (device.h EVT_LOG): 1024 entries of 4 dwords
+        rc = allocRing(nn, (size_t)kEventLogEntries * 4u);
+        if (rc == kOk) { writeParamPtr(nn, rec::EVT_LOG, nn.ring.ptr); writeParam(nn, rec::EVT_LOGMASK, kEventLogEntries - 1u); }
     } else if (nn.op == OP_SCOPE) {                                               // Analyzers.h:145: MultiChannelRingBuffer(4) x 8192
         rc = allocRing(nn, 4u * 8192u);
         if (rc == kOk) writeParamPtr(nn, rec::SCP_RING, nn.ring.ptr);
@@ -1096,138 +1106,233 @@ int Engine::apply(const Value& batch) {   // Runtime.h:170-218
 }
 
 // ---- event relay ------------------------------------------------------------------------------------
-int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), void* user) {   // Runtime.h:437-446
+// ---- the event relay (Runtime.h:437-446, GraphRenderSequence.h:189-198, builtins/Analyzers.h, Capture.h, mc/Capture.h) -------------
+//
+// The reference drains lock-free queues: its audio thread never notices a relay. Here the readouts live in device memory, so
+// the relay (a) takes the render lock only to ENQUEUE a device-side snapshot of the event nodes' records behind the blocks
+// already queued (stream order makes it consistent) and, at the end, to queue the read-position updates as parameter patches;
+// (b) waits for that snapshot, fetches the ring ranges it names and calls the host back WITHOUT the render lock — a render
+// thread that calls process() meanwhile is not held up by a synchronise or a copy (r04 held `mu` across both).
+// What a ring range holds cannot change under the copy: kernels only write ahead of the write position the snapshot shows,
+// the relay is the only reader, and the rings themselves are freed under `ctl`, which the relay holds throughout.
+//
+// blockwise = false: the reference's processQueuedEvents — per node the NEWEST readout since the last relay.
+// blockwise = true:  what the reference's offline caller produces by relaying after EVERY block (offline-renderer/index.ts:112-120),
+//   reconstructed after a whole launch set from the per-block readout logs the kernels keep (device.h EVT_LOG): every block's
+//   events in block order, nodes in render order inside a block. Exact while a relay window stays within eventWindowBlocks().
+int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), void* user, bool blockwise) {
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
-    if (dry || !current || !cb) return kOk;
-    if (hipSetDevice(device) != hipSuccess) return kHipError;
-    HIP_OK(hipStreamSynchronize(stream));
+    if (dry || !cb) return kOk;
+    struct Item { Node* n; size_t recOff; uint32_t order; };
+    std::vector<Item> items;
+    std::shared_ptr<Plan> plan;
+    uint64_t windowBlocks = 0, blocksNow = 0;
+    {   // ---- (a) under the render lock: snapshot of the records, stream-ordered behind everything rendered so far ----
+        std::lock_guard<std::mutex> lock(mu);
+        if (!current) return kOk;
+        if (hipSetDevice(device) != hipSuccess) return kHipError;
+        plan = current;
+        uint32_t order = 0;
+        for (auto& en : plan->eventNodes) {
+            auto nit = nodes.find(en.first), rit = nodes.find(en.second);
+            if (nit == nodes.end() || rit == nodes.end()) continue;
+            auto a = rit->second.props.find("active");                       // GraphRenderSequence.h:192
+            if (a == rit->second.props.end() || !a->second.isBool() || !a->second.b) continue;
+            items.push_back({&nit->second, items.size() * kRecDwords * 4, order++});
+        }
+        blocksNow = st.blocksRendered;
+        windowBlocks = blocksNow - relayBlocksMark;
+        if (items.empty()) { relayBlocksMark = blocksNow; return kOk; }
+        const size_t need = items.size() * kRecDwords * 4;
+        if (need > relayBytes) {
+            const size_t cap = std::max<size_t>(need * 2, 16384);
+            uint8_t* d = nullptr; uint8_t* h = nullptr;
+            HIP_OK(hipMalloc(reinterpret_cast<void**>(&d), cap));
+            HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&h), cap, hipHostMallocDefault));
+            if (dRelay) deferredFree.push_back(dRelay);
+            if (hRelay) (void)hipHostFree(hRelay);
+            dRelay = d; hRelay = h; relayBytes = cap;
+        }
+        if (!relayStream) {
+            HIP_OK(hipStreamCreateWithFlags(&relayStream, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&evRelay, hipEventDisableTiming));
+        }
+        // (parameter patches still waiting for the next block — a read position written by the previous relay — go first)
+        int rc = flushPending();
+        if (rc != kOk) return rc;
+        for (const Item& it : items)
+            HIP_OK(hipMemcpyAsync(dRelay + it.recOff, dRecs + (size_t)it.n->rec * kRecDwords, kRecDwords * 4, hipMemcpyDeviceToDevice, stream));
+        HIP_OK(hipEventRecord(evRelay, stream));
+    }
+    // ---- (b) without the render lock: wait for the snapshot, fetch what it names ----
+    HIP_OK(hipStreamWaitEvent(relayStream, evRelay, 0));
+    HIP_OK(hipMemcpyAsync(hRelay, dRelay, items.size() * kRecDwords * 4, hipMemcpyDeviceToHost, relayStream));
+    HIP_OK(hipStreamSynchronize(relayStream));
     auto numStr = [](float v) { char b[64]; std::snprintf(b, sizeof b, "%.17g", (double)v); return std::string(b); };
-    for (auto& en : current->eventNodes) {
-        auto nit = nodes.find(en.first), rit = nodes.find(en.second);
-        if (nit == nodes.end() || rit == nodes.end()) continue;
-        auto a = rit->second.props.find("active");                       // GraphRenderSequence.h:192
-        if (a == rit->second.props.end() || !a->second.isBool() || !a->second.b) continue;
-        Node& n = nit->second;
-        if (n.op == OP_SCOPE) {                                           // Analyzers.h:192-245, MultiChannelRingBuffer.h:61-86
-            auto numOr = [&](const char* k, double dflt) { auto q = n.props.find(k); return (q != n.props.end() && q->second.isNumber()) ? q->second.num : dflt; };
-            const size_t size = (size_t)numOr("size", 512.0), channels = (size_t)numOr("channels", 1.0);
-            const uint32_t cap = 8192u, mask = cap - 1u;
-            uint32_t pos[2] = {0, 0};                                     // write, read
-            HIP_OK(hipMemcpy(pos, dRecs + (size_t)n.rec * kRecDwords + rec::SCP_WRITE, sizeof pos, hipMemcpyDeviceToHost));
-            const uint32_t w = pos[0], r = pos[1];
-            const uint32_t full = w > r ? w - r : ((cap - (r - w)) & mask);
-            if (!(full > size) || !n.ring.ptr) continue;
-            std::vector<float> host(4u * cap);
-            HIP_OK(hipMemcpy(host.data(), n.ring.ptr, host.size() * 4, hipMemcpyDeviceToHost));
-            std::string src = "null";
-            auto nm = n.props.find("name");
-            if (nm != n.props.end() && nm->second.isString()) { src = "\""; for (char ch : nm->second.str) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; } src += "\""; }
-            std::string j = "{\"source\": " + src + ", \"data\": [";
-            for (size_t ch = 0; ch < channels; ++ch) {
-                j += ch ? ", [" : "[";
-                for (size_t i = 0; i < size; ++i) { if (i) j += ", "; j += numStr(host[ch * cap + ((r + i) & mask)]); }
-                j += "]";
-            }
-            j += "]}";
-            const uint32_t nr = (uint32_t)((r + size) & mask);
-            HIP_OK(hipMemcpy(dRecs + (size_t)n.rec * kRecDwords + rec::SCP_READ, &nr, 4, hipMemcpyHostToDevice));
-            shadow[(size_t)n.rec * kRecDwords + rec::SCP_READ] = nr;
-            cb("scope", j.c_str(), user);
-            continue;
-        }
-        if (n.op == OP_CAPTURE && n.mc) {                                 // mc/Capture.h:107-146: drain every channel's ring, emit once the gate fell
-            uint32_t cs[5] = {0, 0, 0, 0, 0};                             // write, read, (scratch), change, ready
-            HIP_OK(hipMemcpy(cs, dRecs + (size_t)n.rec * kRecDwords + rec::CAP_WRITE, sizeof cs, hipMemcpyDeviceToHost));
-            const uint32_t mask = shadow[(size_t)n.rec * kRecDwords + rec::CAP_MASK], cap = mask + 1u, chans = shadow[(size_t)n.rec * kRecDwords + rec::CAP_CHANS];
-            const uint32_t w = cs[0], r = cs[1];
-            const uint32_t avail = w > r ? w - r : ((cap - (r - w)) & mask);
-            if (avail > 0 && n.ring.ptr && chans > 0) {
-                if (n.relayCh.size() != chans) n.relayCh.resize(chans);       // (pendingEventData.resize(numChansToRead))
-                const uint32_t first = std::min(avail, cap - r);
-                for (uint32_t k = 0; k < chans; ++k) {
-                    std::vector<float>& dst = n.relayCh[k];
-                    const size_t at = dst.size();
-                    dst.resize(at + avail);
-                    const float* base = (const float*)n.ring.ptr + (size_t)k * cap;
-                    HIP_OK(hipMemcpy(dst.data() + at, base + r, (size_t)first * 4, hipMemcpyDeviceToHost));
-                    if (avail > first) HIP_OK(hipMemcpy(dst.data() + at + first, base, (size_t)(avail - first) * 4, hipMemcpyDeviceToHost));
-                }
-                const uint32_t nr = (r + avail) & mask;
-                HIP_OK(hipMemcpy(dRecs + (size_t)n.rec * kRecDwords + rec::CAP_READ, &nr, 4, hipMemcpyHostToDevice));
-                shadow[(size_t)n.rec * kRecDwords + rec::CAP_READ] = nr;
-            }
-            if (cs[4]) {
-                const uint32_t zero = 0u;
-                HIP_OK(hipMemcpy(dRecs + (size_t)n.rec * kRecDwords + rec::CAP_READY, &zero, 4, hipMemcpyHostToDevice));
-                shadow[(size_t)n.rec * kRecDwords + rec::CAP_READY] = 0u;
-                std::string src = "null";
-                auto nm = n.props.find("name");
-                if (nm != n.props.end() && nm->second.isString()) { src = "\""; for (char ch : nm->second.str) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; } src += "\""; }
-                std::string j = "{\"source\": " + src + ", \"data\": [";
-                for (size_t k = 0; k < n.relayCh.size(); ++k) {
-                    j += k ? ", [" : "[";
-                    for (size_t i = 0; i < n.relayCh[k].size(); ++i) { if (i) j += ", "; j += numStr(n.relayCh[k][i]); }
-                    j += "]";
-                    n.relayCh[k].clear();
-                }
-                j += "]}";
-                cb("mc.capture", j.c_str(), user);
-            }
-            continue;
-        }
-        if (n.op == OP_CAPTURE) {                                         // Capture.h:60-95: drain the ring into the relay, emit once the gate fell
-            uint32_t cs[5] = {0, 0, 0, 0, 0};                             // write, read, scratch, change, ready
-            HIP_OK(hipMemcpy(cs, dRecs + (size_t)n.rec * kRecDwords + rec::CAP_WRITE, sizeof cs, hipMemcpyDeviceToHost));
-            const uint32_t mask = shadow[(size_t)n.rec * kRecDwords + rec::CAP_MASK], cap = mask + 1u;
-            const uint32_t w = cs[0], r = cs[1];
-            const uint32_t avail = w > r ? w - r : ((cap - (r - w)) & mask);
-            if (avail > 0 && n.ring.ptr) {
-                const size_t at = n.relay.size();
-                n.relay.resize(at + avail);
-                const uint32_t first = std::min(avail, cap - r);
-                HIP_OK(hipMemcpy(n.relay.data() + at, (const float*)n.ring.ptr + r, (size_t)first * 4, hipMemcpyDeviceToHost));
-                if (avail > first) HIP_OK(hipMemcpy(n.relay.data() + at + first, n.ring.ptr, (size_t)(avail - first) * 4, hipMemcpyDeviceToHost));
-                const uint32_t nr = (r + avail) & mask;
-                HIP_OK(hipMemcpy(dRecs + (size_t)n.rec * kRecDwords + rec::CAP_READ, &nr, 4, hipMemcpyHostToDevice));
-                shadow[(size_t)n.rec * kRecDwords + rec::CAP_READ] = nr;
-            }
-            if (cs[4]) {
-                const uint32_t zero = 0u;
-                HIP_OK(hipMemcpy(dRecs + (size_t)n.rec * kRecDwords + rec::CAP_READY, &zero, 4, hipMemcpyHostToDevice));
-                shadow[(size_t)n.rec * kRecDwords + rec::CAP_READY] = 0u;
-                std::string src = "null";
-                auto nm = n.props.find("name");
-                if (nm != n.props.end() && nm->second.isString()) { src = "\""; for (char ch : nm->second.str) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; } src += "\""; }
-                std::string j = "{\"source\": " + src + ", \"data\": [";
-                for (size_t i = 0; i < n.relay.size(); ++i) { if (i) j += ", "; j += numStr(n.relay[i]); }
-                j += "]}";
-                n.relay.clear();
-                cb("capture", j.c_str(), user);
-            }
-            continue;
-        }
-        uint32_t st[3] = {0, 0, 0};
-        HIP_OK(hipMemcpy(st, dRecs + (size_t)n.rec * kRecDwords + rec::EVT_A, sizeof st, hipMemcpyDeviceToHost));
-        if (st[2] == n.eventCount) continue;                             // nothing new since the last relay
-        n.eventCount = st[2];
+    auto srcOf = [](const Node& n) {
         std::string src = "null";
         auto nm = n.props.find("name");
-        if (nm != n.props.end() && nm->second.isString()) {
-            src = "\"";
-            for (char ch : nm->second.str) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; }
-            src += "\"";
+        if (nm != n.props.end() && nm->second.isString()) { src = "\""; for (char ch : nm->second.str) { if (ch == '"' || ch == '\\') src += '\\'; src += ch; } src += "\""; }
+        return src;
+    };
+    // a stretch [from, from + count) of a device ring of `cap` entries of `entryFloats` floats each, wrapped, into `dst`
+    auto fetchRing = [&](const float* base, uint32_t cap, uint32_t from, uint32_t count, uint32_t entryFloats, float* dst) -> bool {
+        if (!count) return true;
+        from %= cap;
+        const uint32_t first = std::min(count, cap - from);
+        if (hipMemcpyAsync(dst, base + (size_t)from * entryFloats, (size_t)first * entryFloats * 4, hipMemcpyDeviceToHost, relayStream) != hipSuccess) return false;
+        if (count > first && hipMemcpyAsync(dst + (size_t)first * entryFloats, base, (size_t)(count - first) * entryFloats * 4, hipMemcpyDeviceToHost, relayStream) != hipSuccess) return false;
+        return hipStreamSynchronize(relayStream) == hipSuccess;
+    };
+    struct Ev { uint64_t block; uint32_t order; const char* type; std::string json; };
+    std::vector<Ev> evs;
+    struct Wb { Node* n; uint32_t dword; uint32_t value; };
+    std::vector<Wb> writeBack;
+    const uint64_t lastBlock = windowBlocks ? windowBlocks - 1 : 0;
+    auto blockOf = [&](uint64_t fromEnd) -> uint64_t { return fromEnd > lastBlock ? 0 : lastBlock - fromEnd; };
+    for (const Item& it : items) {
+        Node& n = *it.n;
+        const uint32_t* rc_ = reinterpret_cast<const uint32_t*>(hRelay + it.recOff);
+        if (n.op == OP_SCOPE) {                                           // Analyzers.h:192-245, MultiChannelRingBuffer.h:61-86
+            auto numOr = [&](const char* k, double dflt) { auto q = n.props.find(k); return (q != n.props.end() && q->second.isNumber()) ? q->second.num : dflt; };
+            const size_t size = (size_t)numOr("size", 512.0), channels = std::min<size_t>(4, (size_t)numOr("channels", 1.0));
+            const uint32_t cap = 8192u, mask = cap - 1u;
+            const uint32_t wEnd = rc_[rec::SCP_WRITE];
+            uint32_t r = rc_[rec::SCP_READ];
+            if (!n.ring.ptr || size == 0 || size >= cap) continue;
+            // blockwise: the write position after each block of the window (whole blocks of blockSize frames), oldest first
+            const uint64_t steps = blockwise ? std::max<uint64_t>(1, std::min<uint64_t>(windowBlocks, (cap - 1) / (uint32_t)blockSize)) : 1;
+            std::vector<std::pair<uint64_t, uint32_t>> emits;            // (block, read position of the emitted frame)
+            for (uint64_t s_ = 0; s_ < steps; ++s_) {
+                const uint32_t w = (wEnd - (uint32_t)((steps - 1 - s_) * (uint64_t)blockSize)) & mask;
+                const uint32_t full = w > r ? w - r : ((cap - (r - w)) & mask);
+                if (!(full > size)) continue;
+                emits.emplace_back(blockOf(steps - 1 - s_), r);
+                r = (uint32_t)((r + size) & mask);
+            }
+            if (emits.empty()) continue;
+            const uint32_t r0 = emits.front().second, span = (uint32_t)(emits.size() * size);
+            std::vector<float> host((size_t)channels * span);
+            bool ok = true;
+            for (size_t ch = 0; ch < channels && ok; ++ch) ok = fetchRing((const float*)n.ring.ptr + ch * cap, cap, r0, span, 1, host.data() + ch * span);
+            if (!ok) return kHipError;
+            const std::string src = srcOf(n);
+            for (size_t e = 0; e < emits.size(); ++e) {
+                std::string j = "{\"source\": " + src + ", \"data\": [";
+                for (size_t ch = 0; ch < channels; ++ch) {
+                    j += ch ? ", [" : "[";
+                    for (size_t i = 0; i < size; ++i) { if (i) j += ", "; j += numStr(host[ch * span + e * size + i]); }
+                    j += "]";
+                }
+                j += "]}";
+                evs.push_back({emits[e].first, it.order, "scope", std::move(j)});
+            }
+            writeBack.push_back({&n, rec::SCP_READ, r});
+            continue;
         }
-        float fa, fb; std::memcpy(&fa, &st[0], 4); std::memcpy(&fb, &st[1], 4);
-        if (n.op == OP_METER) {                                           // Analyzers.h:43-62
-            const std::string j = "{\"min\": " + numStr(fa) + ", \"max\": " + numStr(fb) + ", \"source\": " + src + "}";
-            cb("meter", j.c_str(), user);
-        } else {                                                          // Analyzers.h:112-131
-            const std::string j = "{\"source\": " + src + ", \"data\": " + numStr(fb) + "}";
-            cb("snapshot", j.c_str(), user);
+        if (n.op == OP_CAPTURE) {                                         // Capture.h:60-95 / mc/Capture.h:107-146: drain the ring(s) into the relay, emit once the gate fell
+            const uint32_t mask = shadow[(size_t)n.rec * kRecDwords + rec::CAP_MASK], cap = mask + 1u;
+            const uint32_t chans = n.mc ? shadow[(size_t)n.rec * kRecDwords + rec::CAP_CHANS] : 1u;
+            const uint32_t w = rc_[rec::CAP_WRITE], r = rc_[rec::CAP_READ], ready = rc_[rec::CAP_READY];
+            const uint32_t avail = w > r ? w - r : ((cap - (r - w)) & mask);
+            if (avail > 0 && n.ring.ptr && chans > 0) {
+                if (n.mc) { if (n.relayCh.size() != chans) n.relayCh.resize(chans); }      // (pendingEventData.resize(numChansToRead))
+                for (uint32_t k = 0; k < chans; ++k) {
+                    std::vector<float>& dst = n.mc ? n.relayCh[k] : n.relay;
+                    const size_t at = dst.size();
+                    dst.resize(at + avail);
+                    if (!fetchRing((const float*)n.ring.ptr + (size_t)k * cap, cap, r, avail, 1, dst.data() + at)) return kHipError;
+                }
+                writeBack.push_back({&n, rec::CAP_READ, (r + avail) & mask});
+            }
+            if (ready) {
+                writeBack.push_back({&n, rec::CAP_READY, 0u});
+                std::string j = "{\"source\": " + srcOf(n) + ", \"data\": [";
+                if (n.mc) {
+                    for (size_t k = 0; k < n.relayCh.size(); ++k) {
+                        j += k ? ", [" : "[";
+                        for (size_t i = 0; i < n.relayCh[k].size(); ++i) { if (i) j += ", "; j += numStr(n.relayCh[k][i]); }
+                        j += "]";
+                        n.relayCh[k].clear();
+                    }
+                } else {
+                    for (size_t i = 0; i < n.relay.size(); ++i) { if (i) j += ", "; j += numStr(n.relay[i]); }
+                    n.relay.clear();
+                }
+                j += "]}";
+                evs.push_back({lastBlock, it.order, n.mc ? "mc.capture" : "capture", std::move(j)});
+            }
+            continue;
+        }
+        // meter / snapshot
+        const uint32_t count = rc_[rec::EVT_COUNT];
+        float fa, fb; std::memcpy(&fa, &rc_[rec::EVT_A], 4); std::memcpy(&fb, &rc_[rec::EVT_B], 4);
+        const uint32_t lmask = shadow[(size_t)n.rec * kRecDwords + rec::EVT_LOGMASK], lcap = lmask + 1u;
+        if (n.op == OP_METER) {                                           // Analyzers.h:23-62
+            const uint32_t fresh = count - n.eventCount;
+            if (!fresh) continue;
+            if (blockwise && n.ring.ptr && fresh > 1u) {
+                const uint32_t take = std::min(fresh, lcap);
+                std::vector<uint32_t> e((size_t)take * 4);
+                if (!fetchRing((const float*)n.ring.ptr, lcap, count - take, take, 4, reinterpret_cast<float*>(e.data()))) return kHipError;
+                const std::string src = srcOf(n);
+                for (uint32_t k = 0; k < take; ++k) {
+                    float mn, mx; std::memcpy(&mn, &e[4 * k + 1], 4); std::memcpy(&mx, &e[4 * k + 2], 4);
+                    evs.push_back({blockOf(take - 1 - k), it.order, "meter", "{\"min\": " + numStr(mn) + ", \"max\": " + numStr(mx) + ", \"source\": " + src + "}"});
+                }
+            } else evs.push_back({lastBlock, it.order, "meter", "{\"min\": " + numStr(fa) + ", \"max\": " + numStr(fb) + ", \"source\": " + srcOf(n) + "}"});
+            n.eventCount = count;
+        } else {                                                          // Analyzers.h:83-131
+            const uint32_t blk = rc_[rec::EVT_BLK], logn = rc_[rec::EVT_LOGN];
+            if (count == n.eventCount) { n.logRelayed = logn; continue; }
+            const uint32_t fresh = logn - n.logRelayed;
+            if (blockwise && n.ring.ptr && fresh >= 1u) {
+                const uint32_t take = std::min(fresh, lcap);
+                std::vector<uint32_t> e((size_t)take * 4);
+                if (!fetchRing((const float*)n.ring.ptr, lcap, logn - take, take, 4, reinterpret_cast<float*>(e.data()))) return kHipError;
+                const std::string src = srcOf(n);
+                for (uint32_t k = 0; k < take; ++k) {
+                    float v; std::memcpy(&v, &e[4 * k + 1], 4);
+                    evs.push_back({blockOf((uint64_t)(blk - 1u - e[4 * k])), it.order, "snapshot", "{\"source\": " + src + ", \"data\": " + numStr(v) + "}"});
+                }
+            } else evs.push_back({lastBlock, it.order, "snapshot", "{\"source\": " + srcOf(n) + ", \"data\": " + numStr(fb) + "}"});
+            n.eventCount = count; n.logRelayed = logn;
         }
     }
+    {   // ---- (c) read positions back to the device: parameter patches, applied in stream order at once (no synchronise) ----
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Wb& w : writeBack) writeParam(*w.n, w.dword, w.value);
+        relayBlocksMark = blocksNow;
+        if (!writeBack.empty()) { const int rc = flushPending(); if (rc != kOk) return rc; }
+    }
+    // ---- (d) the host's callbacks, in block order (stable: nodes stay in render order inside a block) ----
+    if (blockwise) std::stable_sort(evs.begin(), evs.end(), [](const Ev& a, const Ev& b) { return a.block != b.block ? a.block < b.block : a.order < b.order; });
+    for (const Ev& e : evs) cb(e.type, e.json.c_str(), user);
     return kOk;
+}
+
+// How many blocks may pass between two blockwise relays for their result to be exactly the per-block relay's: the per-block
+// readout logs hold 1024 blocks; a scope ring (8192 frames, `size` of them per event) must not overrun inside a window; a
+// capture node's take is placed by the relay that sees its gate fall, so it wants a relay per block.
+uint32_t Engine::eventWindowBlocks() {
+    std::lock_guard<std::mutex> control(ctl);
+    std::lock_guard<std::mutex> lock(mu);
+    const std::shared_ptr<Plan> pl = pending ? pending : current;
+    uint32_t w = kEventLogEntries;
+    if (!pl) return w;
+    for (auto& en : pl->eventNodes) {
+        auto nit = nodes.find(en.first);
+        if (nit == nodes.end()) continue;
+        const Node& n = nit->second;
+        if (n.op == OP_CAPTURE) return 1u;
+        if (n.op == OP_SCOPE) {
+            auto q = n.props.find("size");
+            const double size = (q != n.props.end() && q->second.isNumber()) ? q->second.num : 512.0;
+            const double room = 8192.0 - 1.0 - std::max(1.0, size);
+            w = std::min<uint32_t>(w, (uint32_t)std::max(1.0, std::floor(room / (double)blockSize)));
+        }
+    }
+    return w;
 }
 
 // ---- gc / resources -------------------------------------------------------------------------------
@@ -1390,7 +1495,7 @@ int Engine::setOption(const std::string& key, double value) {
     std::lock_guard<std::mutex> lock(mu);
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
     if (key == "host_out_direct") { hostOutDirect = value != 0; return kOk; }   // elemhip_process: epilogue writes the pinned host block itself
-    if (key == "conv_mfma") { convMfma = std::max(0, std::min(2, (int)value)); return kOk; }   // partition MAC of launch sets: 1 matrix cores (default), 0 packed vector FMAs
+    if (key == "conv_mfma") { convMfma = std::max(0, std::min(1, (int)value)); return kOk; }   // partition MAC of launch sets: 1 matrix cores (default), 0 packed vector FMAs
     if (key == "skip_idle_launches") { skipIdleLaunches = value != 0; dropGraphs(); return kOk; }
     if (key == "fuse_epilogue") { fuseEpilogue = value != 0; dropGraphs(); return kOk; }
     if (key == "spec_block_graph") { specBlockGraph = value != 0; dropGraphs(); return kOk; }   // elemhip_process: replay the launch set of one from a hipGraph
@@ -1404,7 +1509,11 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "mixer_split") { const int v = (int)value; mixerSplit = (v == 2 || v == 4 || v == 8) ? (uint32_t)v : 1u; planStale = true; return kOk; }
     if (key == "stateless_rows") { statelessRows = (uint32_t)std::max(1, std::min(64, (int)value)); return kOk; }   // gridDim.y of a multi-block launch: blocks that stateless islands render side by side
     if (key == "pipeline_copies") { pipelineCopies = std::max(1, std::min(6, (int)value)); planStale = true; return kOk; }   // next commit re-plans
+#ifdef ELEMHIP_EXPERIMENTAL
     if (key == "stream_ring") { streamRing = value != 0.0; return kOk; }   // 0: measurement only, needs kernels built with ELEMHIP_STREAM_PER_BLOCK
+#else
+    if (key == "stream_ring") return value != 0.0 ? kOk : kInvalidPropertyValue;   // (the per-block stream slices exist in EXPERIMENTAL builds only)
+#endif
     if (key == "pack_islands") { packIslands = std::max(0, std::min(16, (int)value)); planStale = true; return kOk; }   // next commit re-plans
     if (key == "prog_heap_dwords") { progHeapCap = (size_t)std::max(0.0, value); progHeap.reset(); islandCache.clear(); planStale = true; return kOk; }   // 0: sized by the engine
     if (key == "pack_roots") { packRoots = value != 0; planStale = true; return kOk; }   // islands of different active roots may share a workgroup (C4: a root per render job)
@@ -1418,6 +1527,9 @@ int Engine::setOption(const std::string& key, double value) {
         if (profileLaunches) { profMs.clear(); profSets = 0; profBlocks = 0; }
         return kOk;
     }
+    if (key == "spec_lonely_blocks") { lonelyBlocks = std::max(0, (int)value); return kOk; }   // background mode: a one-off shape is queued for compilation once its
+    if (key == "spec_lonely_ms") { lonelyMs = std::max(0, (int)value); return kOk; }           // plan has rendered this many blocks and been current this long
+    if (key == "jit_cache_entries") { Jit::get().setEntryCap((uint32_t)std::max(0.0, value)); return kOk; }   // PROCESS-wide: compiled shapes kept in memory (0: default 256)
     if (key == "time_batch") { timeBatch = std::max(1, std::min(256, (int)value)); return kOk; }
     if (key == "graph_blocks") { graphBlocks = std::max(1, (int)value); dropGraphs(); return kOk; }
     return kInvalidPropertyValue;
@@ -1516,6 +1628,8 @@ int Engine::swapInPending() {   // Runtime.h:277-285: newest sequence wins
         if (current && !dry) retiredPlans.push_back(std::move(current));   // its kernels may still be queued (host path): freed after the next synchronize
         current = pending;
         pending.reset();
+        current->blocksAtAdoption = st.blocksRendered;
+        current->adopted = std::chrono::steady_clock::now();
         st.numIslands = (uint32_t)current->islands.size();
         st.numLevels = (uint32_t)current->levelOffsets.size() - 1;
         st.numTasks = current->numTasks;
@@ -1538,7 +1652,7 @@ void Engine::enqueueBlock(const Plan& p, float* outRing) {
     const size_t L = p.levelOffsets.size() - 1;
     for (size_t l = 0; l < L; ++l) {
         const uint32_t b = p.levelOffsets[l], e = p.levelOffsets[l + 1];
-        if (e > b) launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l]);
+        if (e > b) { launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l]); islandBlocksInterp += e - b; }
         debugSync("block: interpreter level", (unsigned)l, e - b);
         const uint32_t cb = p.convLevelOffsets[l], ce = p.convLevelOffsets[l + 1];
         if (ce > cb) launch_convolve(stream, p.view, dRecs, dHbm, dGlobals, cb, ce - cb);
@@ -1608,13 +1722,16 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     if (n <= (size_t)blockSize || hostBlockSize == blockSize) return processSlice(in, nIn, out, nOut, n, sampleTime);
     if (n > (size_t)hostBlockSize) return kBlockTooLarge;
     if (nIn > kMaxHostIn || nOut > kMaxOutBus) return kTooManyChannels;
-    // a host block longer than the engine's: slice by slice (each slice is a block of its own to the kernels)
+    // a host block longer than the engine's: slice by slice (each slice is a block of its own to the kernels), the render lock held
+    // and the newest sequence adopted ONCE for the whole host block — a commit, gc or event relay from another thread lands between
+    // two host blocks, never inside one
     std::vector<const float*> ip(nIn);
     std::vector<float*> op(nOut);
+    std::lock_guard<std::mutex> lock(mu);
     for (size_t off = 0; off < n; off += (size_t)blockSize) {
         for (size_t c = 0; c < nIn; ++c) ip[c] = in[c] + off;
         for (size_t c = 0; c < nOut; ++c) op[c] = out[c] + off;
-        const int rc = processSlice(ip.data(), nIn, op.data(), nOut, std::min((size_t)blockSize, n - off), sampleTime + (int64_t)off);
+        const int rc = processSliceLocked(ip.data(), nIn, op.data(), nOut, std::min((size_t)blockSize, n - off), sampleTime + (int64_t)off, off == 0);
         if (rc != kOk) return rc;
     }
     return kOk;
@@ -1622,12 +1739,18 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
 
 int Engine::processSlice(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime) {
     std::lock_guard<std::mutex> lock(mu);
+    return processSliceLocked(in, nIn, out, nOut, n, sampleTime, true);
+}
+
+// (`mu` held.) `adopt`: take the newest render sequence — once per HOST block (Runtime.h:277-285): the later slices of a host block
+// longer than the engine's render the sequence its first slice adopted, under the same hold of the lock.
+int Engine::processSliceLocked(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime, bool adopt) {
     if (dry) return kNoDevice;
     if (hipSetDevice(device) != hipSuccess) return kHipError;
     if (n > (size_t)blockSize) return kBlockTooLarge;
     if (nIn > kMaxHostIn || nOut > kMaxOutBus) return kTooManyChannels;
     if (n != conv::kBlock) convAligned = false;   // a convolver's input block may now be partly filled at a call boundary
-    int rc = swapInPending();
+    int rc = adopt ? swapInPending() : kOk;
     if (rc != kOk) return rc;
     if (!current) return kOk;   // no render sequence yet: outputs untouched (Runtime.h:287-289)
     Plan& p = *current;
@@ -1713,6 +1836,7 @@ int Engine::processSlice(const float* const* in, size_t nIn, float* const* out, 
     mirrorRootFades(p, (uint32_t)n, (uint32_t)nOut, (uint32_t)nIn);
     hGlobals.sampleTime += (int64_t)n;
     st.blocksRendered++;
+    promoteDeferredShapes();
     freeDeferred();
     return kOk;
 }
@@ -1841,6 +1965,16 @@ bool Engine::specReady(const Plan& p) const {
     return any;
 }
 
+void Engine::promoteDeferredShapes() {
+    Plan* p = current.get();
+    if (!p || !p->deferredShapes) return;
+    if (st.blocksRendered - p->blocksAtAdoption < (uint64_t)std::max(0, lonelyBlocks)) return;
+    if (std::chrono::steady_clock::now() - p->adopted < std::chrono::milliseconds(std::max(0, lonelyMs))) return;
+    for (Plan::SpecShape& sh : p->shapes)
+        if (sh.deferred) { Jit::get().promote(sh.entry); sh.deferred = false; }
+    p->deferredShapes = 0;
+}
+
 bool Engine::anyRootRuns(const std::vector<int32_t>& rootIds, size_t nOut) const {
     for (int32_t id : rootIds) {
         auto it = nodes.find(id);
@@ -1895,7 +2029,7 @@ int Engine::specInfo(size_t k, std::string* source, std::string* log, int* state
     const std::shared_ptr<Plan> pl = pending ? pending : current;
     if (!pl || k >= pl->shapes.size()) return -1;
     const Plan::SpecShape& sh = pl->shapes[k];
-    if (source) *source = sh.entry->source;
+    if (source) *source = sh.entry->fullText();
     if (log) *log = sh.entry->log;
     if (state) *state = sh.entry->state.load();
     if (islands) *islands = sh.count;
@@ -1934,7 +2068,7 @@ bool Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         }
         if (!any) spec = false;
     }
-    if (!spec) { launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats, statelessRows); debugSync("set: interpreter level", (unsigned)l, batch); return false; }
+    if (!spec) { launch_level(stream, p.view, dRecs, dHbm, dGlobals, dLcg, b, e - b, p.levelLdsBytes[l], batch, arenaFloats, statelessRows); islandBlocksInterp += (uint64_t)(e - b) * batch; debugSync("set: interpreter level", (unsigned)l, batch); return false; }
     // The launches of one level are independent of each other (different islands): with more than one they go to side
     // streams forked from / joined to the engine's stream, so two shapes of 64 islands each fill 128 CUs at once
     // instead of 64 CUs twice.
@@ -1974,6 +2108,7 @@ bool Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
             PlanView pv = p.view;
             pv.levelIslands = p.dSpecLists;
             launch_level(st_, pv, dRecs, dHbm, dGlobals, dLcg, f.second->listBegin, f.second->count, p.levelLdsBytes[l], batch, arenaFloats, statelessRows);
+            islandBlocksInterp += (uint64_t)f.second->count * batch;
             continue;
         }
         PlanView pv = p.view;
@@ -1987,12 +2122,14 @@ bool Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         const uint32_t gy = f.second->stateless ? std::max(1u, std::min(batch, statelessRows)) : 1u;
         HIP_WARN(hipModuleLaunchKernel(f.first, f.second->count, gy, 1, kThreads, 1, 1, 0, st_, args, nullptr));
         st.specLaunches++;
+        islandBlocksSpec += (uint64_t)f.second->count * batch;
         debugSync("set: specialised shape", f.second->count, batch);
     }
     if (re > rb) {
         PlanView pv = p.view;
         pv.levelIslands = p.dRestIslands;
         launch_level(streamFor(k++), pv, dRecs, dHbm, dGlobals, dLcg, rb, re - rb, p.levelLdsBytes[l], batch, arenaFloats, statelessRows);
+        islandBlocksInterp += (uint64_t)(re - rb) * batch;
         debugSync("set: interpreter rest", re - rb, batch);
     }
     if (fork) {
@@ -2114,6 +2251,7 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             hGlobals.sampleTime += (int64_t)(chunk * bs);
             done += chunk;
             st.blocksRendered += chunk;
+            promoteDeferredShapes();
             st.batchLaunches++;
             continue;
         }
@@ -2138,6 +2276,7 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             hGlobals.sampleTime += (int64_t)bs;
             done += 1;
             st.blocksRendered += 1;
+            promoteDeferredShapes();
             continue;
         }
         const size_t chunk = std::min(G, numBlocks - done);
@@ -2160,9 +2299,11 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
                 hipGraph_t graph = nullptr;
                 HIP_OK(hipStreamSynchronize(stream));
                 const auto tc0 = std::chrono::steady_clock::now();
+                const uint64_t ibi = islandBlocksInterp;
                 HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
                 for (size_t b = 0; b < G; ++b) enqueueBlock(p);
                 HIP_OK(hipStreamEndCapture(stream, &graph));
+                islandBlocksInterp = ibi;                                   // (counted per replay below)
                 HIP_OK(hipGraphInstantiate(&p.graphExec, graph, nullptr, nullptr, 0));
                 (void)hipGraphDestroy(graph);
                 p.graphBlocks = (int)G;
@@ -2171,6 +2312,7 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             }
             HIP_OK(hipGraphLaunch(p.graphExec, stream));
             st.graphReplays++;
+            islandBlocksInterp += (uint64_t)G * p.levelIslands.size();
         } else {
             for (size_t b = 0; b < chunk; ++b) { curBlockTime = hGlobals.sampleTime + (int64_t)(b * bs); enqueueBlock(p); }
         }
@@ -2182,6 +2324,7 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
         hGlobals.blockSlot = (uint32_t)((hGlobals.blockSlot + chunk) % G);
         done += chunk;
         st.blocksRendered += chunk;
+        promoteDeferredShapes();
     }
     return kOk;
 }
@@ -2242,6 +2385,9 @@ int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* 
         setBlocks = (size_t)std::max(1, batchBlocks);
         if (setBlocks < 8) setBlocks = std::min<size_t>(64, numBlocks);     // per-block launch path: still stage whole chunks
         setBlocks = std::min(setBlocks, numBlocks);
+        // launch sets hold whole HOST blocks: a newer render sequence is adopted at a set boundary (enqueueBlocks), and the reference
+        // swaps sequences at host-block boundaries only (Runtime.h:277-285)
+        if (hb > bs) setBlocks = std::min(numBlocks, std::max(hb / bs, setBlocks / (hb / bs) * (hb / bs)));
         int rc = ensureHostStaging(setBlocks * std::max<size_t>(nOut, 1) * bs, setBlocks * std::max<size_t>(nIn, 1) * bs);
         if (rc != kOk) return rc;
     }

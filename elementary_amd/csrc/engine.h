@@ -87,6 +87,7 @@ struct Node {
     DevBuf ring;                // delay / sdelay ring, tapOut private buffer, seq data
     ResourcePtr res;            // tap buffer / sample data held by the node
     uint32_t eventCount = 0;    // meter / snapshot: readouts already relayed by processQueuedEvents
+    uint32_t logRelayed = 0;    // snapshot: entries of the per-block readout log already relayed
     uint32_t convSlices = 1;    // convolve: helper slices its current impulse response wants (conv.hip)
     bool mc = false;            // multi-output node (mc.*): one record per output channel, planned as one entry per channel
     std::vector<uint32_t> chanRecs;   // records of output channels 1, 2, ... (allocated when a plan first needs them)
@@ -179,7 +180,8 @@ public:
 
     // one block, host buffers (Runtime::process)
     int process(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime);
-    int processSlice(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime);   // n <= blockSize
+    int processSlice(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime);
+    int processSliceLocked(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime, bool adopt);   // n <= blockSize
     // numBlocks consecutive full blocks, device-resident output `outDev[block][nOut][blockSize]`
     // (may be null: render only) and optional device-resident input `inDev[block][nIn][blockSize]`
     int processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime);
@@ -202,7 +204,10 @@ public:
     void reset();
     // Runtime::processQueuedEvents (Runtime.h:64, 437-446): relays the newest meter / snapshot readout of every such node
     // of the current render sequence whose root is active. cb(type, json payload, user).
-    int processQueuedEvents(void (*cb)(const char*, const char*, void*), void* user);
+    // `blockwise`: every block's events since the last relay in block order, as a host that relayed after each block would have
+    // got them (offline-renderer/index.ts:112-120), from the kernels' per-block readout logs
+    int processQueuedEvents(void (*cb)(const char*, const char*, void*), void* user, bool blockwise = false);
+    uint32_t eventWindowBlocks();          // blocks a blockwise relay window may span and still be exact for the newest plan's event nodes
     void setStream(hipStream_t s);
     const Stats& stats() const { return st; }
     // dry-engine introspection for host-logic tests: adopt the pending plan and describe it as JSON
@@ -284,6 +289,10 @@ private:
     float* hOutDev = nullptr;                          // hOut as the device sees it (mapped)
     float* hIn = nullptr; size_t hInFloats = 0;       // pinned
     std::vector<void*> deferredFree;
+    // the event relay's snapshot (processQueuedEvents): records copied device-side in stream order, fetched on a stream of its own
+    hipStream_t relayStream = nullptr; hipEvent_t evRelay = nullptr;
+    uint8_t* dRelay = nullptr; uint8_t* hRelay = nullptr; size_t relayBytes = 0;
+    uint64_t relayBlocksMark = 0;          // Stats::blocksRendered at the last relay: a blockwise relay's window starts here
     std::vector<std::shared_ptr<Plan>> retiredPlans;   // replaced plans whose launches may still be in flight; released by freeDeferred()
 
     // host-buffer launch sets (processBlocksHost): copy stream, pinned + device staging halves, hand-over events
@@ -374,6 +383,12 @@ private:
     bool launchLevelBatch(const Plan& p, size_t level, uint32_t batch, uint32_t arenaFloats, float* epiOut = nullptr);
     bool batchEligible(const Plan& p, size_t nOut, bool oneBlock = false) const;
     bool specReady(const Plan& p) const;
+    // background mode: the one-off shapes of the current plan are queued for compilation (behind everything else) once the plan
+    // has rendered `lonelyBlocks` blocks and has been current for `lonelyMs` — a plan a live graph replaces 30 ms later never
+    // gets there, a static patch does within its first second (plan.cpp "deferred")
+    void promoteDeferredShapes();
+    int lonelyBlocks = 64, lonelyMs = 30;  // options "spec_lonely_blocks", "spec_lonely_ms"
+    uint64_t islandBlocksSpec = 0, islandBlocksInterp = 0;   // island x block units rendered by specialised / interpreter kernels (describe_plan)
     bool anyRootRuns(const std::vector<int32_t>& rootIds, size_t nOut) const;   // host mirror of spec_root_running (Core.h:28-31, GraphRenderSequence.h:214-219)
     void mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn);
     int  setGlobalsFor(size_t nIn, size_t nOut, size_t n, int64_t sampleTime);
@@ -450,9 +465,14 @@ struct Plan {
         bool stateless = false;                // no block pipeline: the launch spreads the blocks of a set over gridDim.y
         bool optional = false;                 // a one-island shape of a background-mode plan: while it compiles its island renders through
                                                // the interpreter kernel and the plan still counts as ready (Engine::specReady)
+        bool deferred = false;                 // ... and its compile has not even been queued: Engine::promoteDeferredShapes does that once
+                                               // the plan has rendered for a while
         std::vector<int32_t> roots;            // the roots that own its islands: when none of them runs the launch is skipped
     };
     std::vector<SpecShape> shapes;
+    uint32_t deferredShapes = 0;               // shapes whose compile waits for this plan to prove that it stays (0 again once promoted)
+    uint64_t blocksAtAdoption = 0;             // Engine stats' blocksRendered when this plan became the current one
+    std::chrono::steady_clock::time_point adopted{};   // when it became the current plan
     std::vector<uint32_t> specLists;           // island indices, shape-major
     std::vector<uint32_t> restIslands;         // per level: the levelIslands entries no shape covers (interpreter launch)
     std::vector<uint32_t> restOffsets;         // numLevels + 1

@@ -6,14 +6,27 @@
 // engine keeps rendering through the interpreter kernel until a shape's code object is ready. Code objects are cached
 // in memory (per process) and on disk (kcache/ next to the library, or $ELEMHIP_KCACHE), keyed by a hash of the whole
 // program text and the compiler version, so a shape is compiled once per machine.
+//
+// Everything here is BOUNDED (r05; a live-coding session keeps producing shapes it never meets again):
+//   * an entry keeps its code object and the few KB of generated text, not the 300 KB translation unit (dropped after the compile);
+//   * the in-memory table is capped (`jit_cache_entries`, default 256): entries no plan references any more are evicted oldest
+//     first and their modules unloaded (hipModuleUnload) — plans hold their shapes' entries, and a plan dies only after the
+//     synchronise that follows its last launch, so an unreferenced entry has no kernel in flight;
+//   * the on-disk cache is capped ($ELEMHIP_KCACHE_MAX_MB, default 512): oldest files (mtime; a disk hit refreshes it) go first;
+//   * the compile queue drops requests nobody waits for any more (the voice was replaced before a worker got to its shape) and
+//     serves the newest request first when it is backed up; one-off shapes of background-mode plans enter it only once their plan
+//     has rendered for a while (Jit::promote), behind everything else.
 #include "jit.h"
 
+#include <dirent.h>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hiprtc.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -42,13 +55,25 @@ static std::string libraryDir() {
     return ".";
 }
 
+// tuning experiments ("NAME=VALUE NAME2=VALUE2" -> #define lines in front of the node library, part of the cache key) exist only
+// in a `make EXPERIMENTAL=1` build: several of the hooks they reach render wrong samples by design (measurement only)
+static std::string experimentalDefines() {
+#ifdef ELEMHIP_EXPERIMENTAL
+    const char* d = std::getenv("ELEMHIP_JIT_DEFINES");
+    return d ? d : "";
+#else
+    return "";
+#endif
+}
+
 struct Jit::Impl {
     std::mutex mu;
     std::condition_variable cv;
     std::unordered_map<std::string, std::shared_ptr<SpecEntry>> entries;   // key -> entry
-    std::deque<std::shared_ptr<SpecEntry>> queue;
-    std::unordered_map<uint32_t, std::pair<uint64_t, uint64_t>> prefixHash;   // LDS words -> key hash state behind the fixed part of the source
-    std::string prefixDefs;                                                 // ... under this ELEMHIP_JIT_DEFINES
+    std::deque<std::shared_ptr<SpecEntry>> queue;                          // wanted by a plan now (newest served first when backed up)
+    std::deque<std::shared_ptr<SpecEntry>> lowQueue;                       // promoted one-off shapes
+    std::unordered_map<uint64_t, std::pair<uint64_t, uint64_t>> prefixHash; // (LDS words, block) -> key hash state behind the fixed part of the source
+    std::string prefixDefs;                                                 // ... under these experimental defines
     std::unordered_map<std::string, uint32_t> sightings;                    // one-island shapes a background-mode plan left to the interpreter
     std::unordered_set<std::string> notOnDisk;                             // keys the disk cache was asked about in vain
     std::vector<std::thread> workers;
@@ -57,14 +82,27 @@ struct Jit::Impl {
     bool joined = false;
     std::string cacheDir;
     std::string versionTag;
+    bool keepSource = false;
+    uint32_t entryCap = 256;
+    uint64_t diskCapBytes = 512ull << 20;
+    int64_t diskBytes = -1;                 // -1: not scanned yet
+    std::atomic<uint64_t> tick{1};
+    JitStats st;
+    std::atomic<int64_t> modulesLoaded{0};
 
     Impl() {
         exitHookTarget = this;
         const char* env = std::getenv("ELEMHIP_KCACHE");
         cacheDir = env && env[0] ? env : libraryDir() + "/kcache";
+        if (const char* k = std::getenv("ELEMHIP_JIT_KEEP_SOURCE")) keepSource = std::atoi(k) != 0;
+        if (const char* k = std::getenv("ELEMHIP_JIT_CACHE_ENTRIES")) entryCap = (uint32_t)std::max(4, std::atoi(k));
+        if (const char* k = std::getenv("ELEMHIP_KCACHE_MAX_MB")) diskCapBytes = (uint64_t)std::max(1, std::atoi(k)) << 20;
         int maj = 0, min = 0;
         (void)hiprtcVersion(&maj, &min);
-        versionTag = "hiprtc" + std::to_string(maj) + "." + std::to_string(min) + ";gfx950;-O3;-ffp-contract=off;v1";
+        versionTag = "hiprtc" + std::to_string(maj) + "." + std::to_string(min) + ";gfx950;-O3;-ffp-contract=off;v2";
+#ifdef ELEMHIP_EXPERIMENTAL
+        versionTag += ";experimental";
+#endif
         unsigned n = std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 4u));   // a plan of a new graph brings several shapes at once
         if (const char* t = std::getenv("ELEMHIP_JIT_THREADS")) n = (unsigned)std::max(1, std::atoi(t));
         // The compiler library (comgr) is loaded lazily by the first hiprtc compile and registers its static destructors
@@ -82,7 +120,7 @@ struct Jit::Impl {
         {
             std::lock_guard<std::mutex> l(mu);
             if (joined) return;
-            joined = true; stop = true; queue.clear();
+            joined = true; stop = true; queue.clear(); lowQueue.clear();
         }
         cv.notify_all();
         for (auto& t : workers) if (t.joinable()) t.join();
@@ -98,17 +136,51 @@ struct Jit::Impl {
         std::atexit([] { if (Impl* i = exitHookTarget) i->shutdown(); });
     }
 
+    // (mu held) the next piece of work. The plan queue goes first, newest request first once it is backed up (under a stream of
+    // ever-new shapes the newest voice is the one that will live longest after its compile); requests whose plans are all gone are
+    // dropped instead of compiled while others wait.
+    std::shared_ptr<SpecEntry> take() {
+        for (;;) {
+            std::shared_ptr<SpecEntry> e;
+            bool others;
+            if (!queue.empty()) {
+                if (queue.size() > workers.size()) { e = std::move(queue.back()); queue.pop_back(); }
+                else { e = std::move(queue.front()); queue.pop_front(); }
+                others = !queue.empty();
+            } else if (!lowQueue.empty()) {
+                e = std::move(lowQueue.front()); lowQueue.pop_front();
+                others = !lowQueue.empty();
+            } else return nullptr;
+            // references: the table's and this one; anything above that is a plan (or a waiting commit)
+            if (others && e.use_count() <= 2) {
+                e->state.store(-2, std::memory_order_release);
+                auto it = entries.find(e->key);
+                if (it != entries.end() && it->second == e) entries.erase(it);
+                st.abandoned++;
+                continue;
+            }
+            return e;
+        }
+    }
+
     void run() {
         for (;;) {
             std::shared_ptr<SpecEntry> e;
             {
                 std::unique_lock<std::mutex> l(mu);
-                cv.wait(l, [&] { return stop || !queue.empty(); });
+                cv.wait(l, [&] { return stop || !queue.empty() || !lowQueue.empty(); });
                 if (stop) return;
-                e = queue.front(); queue.pop_front();
+                e = take();
+                if (!e) continue;
             }
             compile(*e);
-            { std::lock_guard<std::mutex> l(mu); }
+            {
+                std::lock_guard<std::mutex> l(mu);
+                const int s = e->state.load(std::memory_order_acquire);
+                if (s == 1 && e->fromDisk) st.diskHits++;
+                else if (s == 1) { st.compiles++; st.compileMsTotal += e->compileMs; st.compileMsLast = e->compileMs; st.compileMsMax = std::max(st.compileMsMax, e->compileMs); }
+                else st.failed++;
+            }
             cv.notify_all();
         }
     }
@@ -119,11 +191,20 @@ struct Jit::Impl {
             std::ifstream f(path, std::ios::binary);
             if (f) {
                 std::vector<char> code((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-                if (code.size() > 64) { e.code.swap(code); e.fromDisk = true; e.state.store(1, std::memory_order_release); return; }
+                if (code.size() > 64) {
+                    e.code.swap(code); e.fromDisk = true;
+                    (void)utimensat(AT_FDCWD, path.c_str(), nullptr, 0);      // a hit keeps the file young (the cap removes oldest first)
+                    e.state.store(1, std::memory_order_release);
+                    return;
+                }
             }
         }
+        const auto t0 = std::chrono::steady_clock::now();
+        // the 300 KB translation unit lives for the duration of the compile only (ELEMHIP_JIT_KEEP_SOURCE=1: it stays in the entry)
+        const std::string src = Jit::fullSource(e.generated, e.ldsWords, e.block);
+        if (keepSource) { std::lock_guard<std::mutex> l(e.mu); e.source = src; }
         hiprtcProgram prog = nullptr;
-        if (hiprtcCreateProgram(&prog, e.source.c_str(), "elemhip_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        if (hiprtcCreateProgram(&prog, src.c_str(), "elemhip_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
             e.log = "hiprtcCreateProgram failed"; e.state.store(-1, std::memory_order_release); return;
         }
         const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-Wno-pragma-once-outside-header"};
@@ -142,14 +223,70 @@ struct Jit::Impl {
         e.code.resize(sz);
         (void)hiprtcGetCode(prog, e.code.data());
         (void)hiprtcDestroyProgram(&prog);
+        e.compileMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         // disk cache: best effort, atomic rename
         (void)mkdir(cacheDir.c_str(), 0755);
         const std::string tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
+        bool written = false;
         {
             std::ofstream f(tmp, std::ios::binary);
-            if (f) { f.write(e.code.data(), (std::streamsize)e.code.size()); f.close(); if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str()); }
+            if (f) {
+                f.write(e.code.data(), (std::streamsize)e.code.size()); f.close();
+                if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str()); else written = true;
+            }
         }
         e.state.store(1, std::memory_order_release);
+        if (written) trimDisk((int64_t)e.code.size());
+    }
+
+    // the on-disk cache stays under its cap: when a write takes it over, the oldest code objects (mtime) go until 3/4 are left
+    void trimDisk(int64_t added) {
+        struct F { std::string name; int64_t size; int64_t mtime; };
+        std::vector<F> files;
+        {
+            std::lock_guard<std::mutex> l(mu);
+            if (diskBytes >= 0) { diskBytes += added; st.diskBytes = (uint64_t)diskBytes; if ((uint64_t)diskBytes <= diskCapBytes) return; }
+        }
+        DIR* d = opendir(cacheDir.c_str());
+        if (!d) return;
+        int64_t total = 0;
+        while (struct dirent* en = readdir(d)) {
+            const std::string n = en->d_name;
+            if (n.size() < 7 || n.compare(n.size() - 6, 6, ".hsaco") != 0) continue;
+            struct stat sb;
+            if (::stat((cacheDir + "/" + n).c_str(), &sb) != 0) continue;
+            files.push_back({n, (int64_t)sb.st_size, (int64_t)sb.st_mtime});
+            total += (int64_t)sb.st_size;
+        }
+        closedir(d);
+        uint64_t removed = 0;
+        if ((uint64_t)total > diskCapBytes) {
+            std::sort(files.begin(), files.end(), [](const F& a, const F& b) { return a.mtime < b.mtime; });
+            for (const F& f : files) {
+                if ((uint64_t)total <= diskCapBytes / 4 * 3) break;
+                if (std::remove((cacheDir + "/" + f.name).c_str()) == 0) { total -= f.size; ++removed; }
+            }
+        }
+        std::lock_guard<std::mutex> l(mu);
+        diskBytes = total; st.diskBytes = (uint64_t)total; st.diskFilesRemoved += removed;
+        if (removed) notOnDisk.clear();
+    }
+
+    // (mu held) the table stays under its cap: entries nobody references (no plan, no queue) go, least recently used first
+    void evict() {
+        if (entries.size() <= entryCap) return;
+        std::vector<std::pair<uint64_t, std::string>> idle;
+        for (auto& kv : entries) {
+            const int s = kv.second->state.load(std::memory_order_acquire);
+            if (kv.second.use_count() == 1 && (s == 1 || s == -1 || s == 2)) idle.emplace_back(kv.second->lastUse.load(std::memory_order_relaxed), kv.first);
+        }
+        std::sort(idle.begin(), idle.end());
+        const size_t target = entryCap - entryCap / 4;
+        for (auto& p : idle) {
+            if (entries.size() <= target) break;
+            entries.erase(p.second);          // ~SpecEntry unloads the modules
+            st.evictions++;
+        }
     }
 };
 
@@ -159,19 +296,29 @@ Jit& Jit::get() { static Jit* j = new Jit; return *j; }   // never destroyed: th
 Jit::Jit() : impl(new Impl) {}
 Jit::~Jit() { delete impl; }
 void Jit::shutdownAtExit() { impl->shutdown(); }
+void Jit::noteModuleLoaded(int delta) { impl->modulesLoaded.fetch_add(delta, std::memory_order_relaxed); }
+void Jit::setEntryCap(uint32_t cap) {
+    std::lock_guard<std::mutex> l(impl->mu);
+    impl->entryCap = cap ? std::max(4u, cap) : 256u;
+    impl->evict();
+}
 
-// everything in front of the generated text (a function of the LDS size and of ELEMHIP_JIT_DEFINES)
-static std::string sourcePrefix(uint32_t ldsWords, size_t reserveExtra) {
+// everything in front of the generated text (a function of the LDS size, the engine's block size and the experimental defines)
+static std::string sourcePrefix(uint32_t ldsWords, uint32_t block, size_t reserveExtra) {
     std::string s;
     s.reserve(sizeof(kSpecDeviceH) + sizeof(kSpecOpsInc) + sizeof(kSpecInc) + reserveExtra + 256);
-    s += "#define ELEMHIP_SPEC 1\n#define ELEMHIP_SPEC_LDS_WORDS " + std::to_string(ldsWords) + "\n";
-    if (const char* d = std::getenv("ELEMHIP_JIT_DEFINES")) {   // tuning experiments: "NAME=VALUE NAME2=VALUE2" -> #define lines (part of the cache key)
-        std::string t = d, tok;
-        for (size_t i = 0; i <= t.size(); ++i) {
-            if (i == t.size() || t[i] == ' ') {
+    s += "#define ELEMHIP_SPEC 1\n#define ELEMHIP_SPEC_LDS_WORDS " + std::to_string(ldsWords) + "\n#define ELEMHIP_SPEC_BLOCK " + std::to_string(block) + "\n";
+#ifdef ELEMHIP_EXPERIMENTAL
+    s += "#define ELEMHIP_EXPERIMENTAL 1\n";
+#endif
+    const std::string defs = experimentalDefines();
+    if (!defs.empty()) {
+        std::string tok;
+        for (size_t i = 0; i <= defs.size(); ++i) {
+            if (i == defs.size() || defs[i] == ' ') {
                 if (!tok.empty()) { const size_t eq = tok.find('='); s += "#define " + (eq == std::string::npos ? tok + " 1" : tok.substr(0, eq) + " " + tok.substr(eq + 1)) + "\n"; }
                 tok.clear();
-            } else tok += t[i];
+            } else tok += defs[i];
         }
     }
     // hiprtc has no host headers: the fixed-width names the sources use (same underlying types as <stdint.h> on this target)
@@ -181,30 +328,31 @@ static std::string sourcePrefix(uint32_t ldsWords, size_t reserveExtra) {
     return s;
 }
 
-std::string Jit::fullSource(const std::string& generated, uint32_t ldsWords) {
-    std::string s = sourcePrefix(ldsWords, generated.size());
+std::string Jit::fullSource(const std::string& generated, uint32_t ldsWords, uint32_t block) {
+    std::string s = sourcePrefix(ldsWords, block, generated.size());
     s += generated;
     return s;
 }
 
 // The key is a hash of the whole translation unit; its first ~300 KB are the same for every shape of one LDS size, so the hash
 // state behind them is kept (FNV-1a runs front to back: same keys as hashing the full source, a tenth of the time).
-std::string Jit::keyFor(const std::string& generated, uint32_t ldsWords) {
-    const char* d = std::getenv("ELEMHIP_JIT_DEFINES");
-    const std::string defs = d ? d : "";
+std::string Jit::keyFor(const std::string& generated, uint32_t ldsWords, uint32_t block) {
+    const std::string defs = experimentalDefines();
+    const uint64_t pk = ((uint64_t)block << 32) | ldsWords;
     uint64_t h1 = 0, h2 = 0;
     bool have = false;
     {
         std::lock_guard<std::mutex> l(impl->mu);
-        if (impl->prefixDefs == defs) { auto it = impl->prefixHash.find(ldsWords); if (it != impl->prefixHash.end()) { h1 = it->second.first; h2 = it->second.second; have = true; } }
+        if (impl->prefixDefs == defs) { auto it = impl->prefixHash.find(pk); if (it != impl->prefixHash.end()) { h1 = it->second.first; h2 = it->second.second; have = true; } }
     }
     if (!have) {
-        const std::string pre = sourcePrefix(ldsWords, 0);
+        const std::string pre = sourcePrefix(ldsWords, block, 0);
         h1 = fnv1a(pre, fnv1a(impl->versionTag, 1469598103934665603ull));
         h2 = fnv1a(pre, fnv1a(impl->versionTag, 0x9E3779B97F4A7C15ull) ^ 0xA5A5A5A5ull);
         std::lock_guard<std::mutex> l(impl->mu);
         if (impl->prefixDefs != defs) { impl->prefixHash.clear(); impl->prefixDefs = defs; }
-        impl->prefixHash[ldsWords] = {h1, h2};
+        if (impl->prefixHash.size() > 256) impl->prefixHash.clear();
+        impl->prefixHash[pk] = {h1, h2};
     }
     h1 = fnv1a(generated, h1); h2 = fnv1a(generated, h2);
     char key[40];
@@ -215,7 +363,8 @@ std::string Jit::keyFor(const std::string& generated, uint32_t ldsWords) {
 bool Jit::knownKey(const std::string& key) {
     {
         std::lock_guard<std::mutex> l(impl->mu);
-        if (impl->entries.count(key)) return true;
+        auto it = impl->entries.find(key);
+        if (it != impl->entries.end() && it->second->state.load(std::memory_order_acquire) != 2) return true;   // (a deferred entry has not been asked for yet)
         if (impl->notOnDisk.count(key)) return false;
     }
     // (asked on every re-plan of a live graph for the one-island shapes of a voice that is fading out: the answer from the
@@ -230,31 +379,80 @@ uint32_t Jit::sighting(const std::string& key) {
     if (impl->sightings.size() > 4096) impl->sightings.clear();
     return ++impl->sightings[key];
 }
-bool Jit::known(const std::string& generated, uint32_t ldsWords) { return knownKey(keyFor(generated, ldsWords)); }
 
-std::shared_ptr<SpecEntry> Jit::requestKey(const std::string& key, const std::string& generated, uint32_t ldsWords) {
+std::shared_ptr<SpecEntry> Jit::requestKey(const std::string& key, const std::string& generated, uint32_t ldsWords, uint32_t block, bool deferred) {
+    std::shared_ptr<SpecEntry> found;
     {
         std::lock_guard<std::mutex> l(impl->mu);
         auto it = impl->entries.find(key);
-        if (it != impl->entries.end()) return it->second;
+        if (it != impl->entries.end()) found = it->second;
     }
-    std::string src = fullSource(generated, ldsWords);
-    std::lock_guard<std::mutex> l(impl->mu);
-    auto it = impl->entries.find(key);
-    if (it != impl->entries.end()) return it->second;
-    auto e = std::make_shared<SpecEntry>();
-    e->key = key; e->source.swap(src); e->ldsBytes = ldsWords * 4u;
-    impl->entries.emplace(e->key, e);
-    impl->queue.push_back(e);
-    impl->cv.notify_one();
-    return e;
+    if (!found) {
+        auto e = std::make_shared<SpecEntry>();
+        e->key = key; e->generated = generated; e->ldsWords = ldsWords; e->block = block; e->ldsBytes = ldsWords * 4u;
+        e->state.store(deferred ? 2 : 0, std::memory_order_release);
+        std::lock_guard<std::mutex> l(impl->mu);
+        auto it = impl->entries.find(key);
+        if (it != impl->entries.end()) found = it->second;
+        else {
+            e->lastUse.store(impl->tick.fetch_add(1), std::memory_order_relaxed);
+            impl->entries.emplace(key, e);
+            if (deferred) impl->st.deferred++;
+            else {
+                impl->queue.push_back(e); impl->st.queued++;
+                // a backed-up queue is swept for requests nobody waits for (they would only be dropped when their turn came)
+                if (impl->queue.size() > 64) {
+                    for (auto q = impl->queue.begin(); q != impl->queue.end();) {
+                        if (q->use_count() <= 2 && *q != e) {
+                            (*q)->state.store(-2, std::memory_order_release);
+                            auto m = impl->entries.find((*q)->key);
+                            if (m != impl->entries.end() && m->second == *q) impl->entries.erase(m);
+                            impl->st.abandoned++;
+                            q = impl->queue.erase(q);
+                        } else ++q;
+                    }
+                }
+                impl->cv.notify_one();
+            }
+            impl->evict();
+            return e;
+        }
+    }
+    found->lastUse.store(impl->tick.fetch_add(1), std::memory_order_relaxed);
+    if (!deferred && found->state.load(std::memory_order_acquire) == 2) promote(found, true);   // wanted in earnest now (second sighting, a waiting commit)
+    return found;
 }
-std::shared_ptr<SpecEntry> Jit::request(const std::string& generated, uint32_t ldsWords) { return requestKey(keyFor(generated, ldsWords), generated, ldsWords); }
+
+void Jit::promote(const std::shared_ptr<SpecEntry>& e, bool urgent) {
+    int expect = 2;
+    if (!e->state.compare_exchange_strong(expect, 0, std::memory_order_acq_rel)) return;
+    std::lock_guard<std::mutex> l(impl->mu);
+    if (urgent) { impl->queue.push_back(e); impl->st.queued++; }
+    else { impl->lowQueue.push_back(e); impl->st.promoted++; }
+    impl->cv.notify_one();
+}
 
 int Jit::wait(const std::shared_ptr<SpecEntry>& e) {
+    if (e->state.load(std::memory_order_acquire) == 2) promote(e, true);
     std::unique_lock<std::mutex> l(impl->mu);
-    impl->cv.wait(l, [&] { return impl->stop || e->state.load(std::memory_order_acquire) != 0; });
+    impl->cv.wait(l, [&] { const int s = e->state.load(std::memory_order_acquire); return impl->stop || (s != 0 && s != 2); });
     return e->state.load(std::memory_order_acquire);
+}
+
+JitStats Jit::stats() {
+    std::lock_guard<std::mutex> l(impl->mu);
+    JitStats s = impl->st;
+    s.entries = impl->entries.size();
+    s.modulesLoaded = (uint64_t)std::max<int64_t>(0, impl->modulesLoaded.load(std::memory_order_relaxed));
+    s.entryCap = impl->entryCap; s.workers = (uint32_t)impl->workers.size(); s.diskCapBytes = impl->diskCapBytes;
+    s.sourceBytesHeld = 0; s.codeBytesHeld = 0;
+    for (auto& kv : impl->entries) { s.sourceBytesHeld += kv.second->source.capacity() + kv.second->generated.capacity(); s.codeBytesHeld += kv.second->code.capacity(); }
+    return s;
+}
+
+std::string SpecEntry::fullText() {
+    { std::lock_guard<std::mutex> l(mu); if (!source.empty()) return source; }
+    return Jit::fullSource(generated, ldsWords, block);
 }
 
 // engine thread, device current: load the code object on this device (once)
@@ -266,11 +464,26 @@ hipFunction_t SpecEntry::function(int device) {
     hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "elemhip_spec_island") != hipSuccess) {
         std::fprintf(stderr, "[elemhip] jit: loading shape %s failed: %s\n", key.c_str(), hipGetErrorString(hipGetLastError()));
+        if (mod) { (void)hipModuleUnload(mod); mod = nullptr; }
         perDevice.emplace(device, std::make_pair(mod, (hipFunction_t) nullptr));
         return nullptr;
     }
     perDevice.emplace(device, std::make_pair(mod, fn));
+    Jit::get().noteModuleLoaded(+1);
     return fn;
+}
+
+// The last reference is gone (evicted from the table and no plan left that names it — a plan is destroyed only after the
+// synchronise that follows its last launch): the modules can be unloaded. Each on the device it was loaded on.
+SpecEntry::~SpecEntry() {
+    if (perDevice.empty()) return;
+    int cur = -1;
+    const bool haveCur = hipGetDevice(&cur) == hipSuccess;
+    for (auto& kv : perDevice) {
+        if (!kv.second.first) continue;
+        if (hipSetDevice(kv.first) == hipSuccess && hipModuleUnload(kv.second.first) == hipSuccess) Jit::get().noteModuleLoaded(-1);
+    }
+    if (haveCur && cur >= 0) (void)hipSetDevice(cur);
 }
 
 } // namespace elemhip

@@ -14,31 +14,49 @@ namespace elemhip {
 
 struct SpecEntry {
     std::string key;                 // hex hash of the whole program text + compiler tag
-    std::string source;
+    std::string generated;           // the shape's own part of the text (codegen.cpp): kept, a few KB — the node library in front of
+                                     // it is the same for every shape and is re-attached on demand (fullText)
+    std::string source;              // the whole translation unit: only between request and compile (ELEMHIP_JIT_KEEP_SOURCE=1 keeps it)
     std::string log;
     std::vector<char> code;          // gfx950 code object
-    uint32_t ldsBytes = 0;
+    uint32_t ldsBytes = 0, ldsWords = 0, block = 0;
     bool fromDisk = false;
-    std::atomic<int> state{0};       // 0 compiling, 1 ready, -1 failed
+    double compileMs = 0.0;          // hiprtc time of this shape (0: disk hit)
+    // 2 deferred (known to the cache, not queued: a one-off shape of a background-mode plan, Jit::promote queues it);
+    // 0 queued / compiling; 1 ready; -1 failed; -2 abandoned (nobody wanted it any more when a worker got to it)
+    std::atomic<int> state{0};
+    std::atomic<uint64_t> lastUse{0};   // Jit tick of the newest request / launch look-up (eviction order)
     std::mutex mu;
     std::unordered_map<int, std::pair<hipModule_t, hipFunction_t>> perDevice;
     hipFunction_t function(int device);   // nullptr until ready (or if loading failed)
+    std::string fullText();               // the translation unit hiprtc saw (debug / tests: elemhip_spec_info)
+    ~SpecEntry();                         // unloads its modules (each on its own device)
+};
+
+struct JitStats {
+    uint64_t entries = 0, modulesLoaded = 0, compiles = 0, diskHits = 0, failed = 0, evictions = 0, abandoned = 0, queued = 0,
+             deferred = 0, promoted = 0, diskBytes = 0, diskFilesRemoved = 0, sourceBytesHeld = 0, codeBytesHeld = 0;
+    double compileMsTotal = 0.0, compileMsMax = 0.0, compileMsLast = 0.0;
+    uint32_t entryCap = 0, workers = 0;
+    uint64_t diskCapBytes = 0;
 };
 
 class Jit {
 public:
     static Jit& get();
-    // queue `generated` (codegen.cpp text of one island shape) for compilation; identical text -> the same entry
-    std::shared_ptr<SpecEntry> request(const std::string& generated, uint32_t ldsWords);
-    int wait(const std::shared_ptr<SpecEntry>& e);   // blocks until compiled: 1 ready, -1 failed
-    bool known(const std::string& generated, uint32_t ldsWords);   // already requested in this process, or on disk
-    // the cache key of a shape (hashing the ~170 KB program text costs 0.3 ms: callers that see the same text object again
-    // keep the key) and the two calls above by key; `request` builds the program text only for a key it has not seen
-    std::string keyFor(const std::string& generated, uint32_t ldsWords);
-    bool knownKey(const std::string& key);
+    // the cache key of a shape (hashing the program text costs 0.3 ms: callers that see the same text object again keep the key)
+    std::string keyFor(const std::string& generated, uint32_t ldsWords, uint32_t block);
+    bool knownKey(const std::string& key);          // requested in this process (and not abandoned), or on disk
     uint32_t sighting(const std::string& key);     // how many plans (this one included) have wanted this not-yet-compiled shape
-    std::shared_ptr<SpecEntry> requestKey(const std::string& key, const std::string& generated, uint32_t ldsWords);
-    static std::string fullSource(const std::string& generated, uint32_t ldsWords);
+    // the entry of `key`, created and queued for compilation if new. `deferred`: create it WITHOUT queueing (a shape only one island
+    // of a background-mode plan has); promote() queues it at low priority once its plan has proved to stay
+    std::shared_ptr<SpecEntry> requestKey(const std::string& key, const std::string& generated, uint32_t ldsWords, uint32_t block, bool deferred = false);
+    void promote(const std::shared_ptr<SpecEntry>& e, bool urgent = false);
+    int wait(const std::shared_ptr<SpecEntry>& e);   // blocks until compiled: 1 ready, -1 failed
+    static std::string fullSource(const std::string& generated, uint32_t ldsWords, uint32_t block);
+    JitStats stats();
+    void setEntryCap(uint32_t cap);                  // option "jit_cache_entries": in-memory entries (code objects + loaded modules) kept; 0 = default
+    void noteModuleLoaded(int delta);
     void shutdownAtExit();
 private:
     Jit();

@@ -8,6 +8,7 @@ namespace elemhip {
 // Output bus channels per process call (the epilogue kernels' thread-per-channel tables; device.h's kMaxOut = 256 was the r01-r03
 // limit and is still what the JIT-compiled island kernels see — they never look at it)
 constexpr uint32_t kMaxOutBus = 1024;
+constexpr uint32_t kEventLogEntries = 1024;   // per-block readout log of a meter / snapshot node (device.h EVT_LOG), a power of two
 
 hipError_t configure_kernels(uint32_t maxLdsBytes);
 void launch_level(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, const uint32_t* lcg,

@@ -794,8 +794,16 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             if (skey != 0 && !cached) {
                 auto ts = e.islandShapeCache.find(skey);
                 if (ts != e.islandShapeCache.end() && ts->second->canonRecs.size() == canonRecs.size() && ts->second->canonHbms.size() == canonHbms.size() &&
-                    ts->second->members.size() == 4 * B.nodes.size())
-                    twin = ts->second;
+                    ts->second->members.size() == 4 * B.nodes.size()) {
+                    // the structural key is 64 bits of hash too: before another island's program is renamed into this one, the two
+                    // must at least agree member by member on opcode and output channel
+                    bool same = true;
+                    for (size_t q = 0; same && q < B.nodes.size(); ++q) {
+                        const NI& x = ni[B.nodes[q]];
+                        same = ts->second->members[4 * q + 1] == ((uint32_t)x.n->op | (x.ch << 16));
+                    }
+                    if (same) twin = ts->second; else e.st.planRelocationMismatches++;
+                }
             }
             if (twin) {
                 std::vector<uint32_t> blob(twin->blob);
@@ -1818,23 +1826,28 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
                 seen[isl] = 1;
                 SpecText& tx = *p.specText[isl];
                 const uint32_t ldsW = p.islands[isl].ldsWords;
-                if (tx.key.empty() || tx.keyLdsWords != ldsW) { tx.key = Jit::get().keyFor(tx.text, ldsW); tx.keyLdsWords = ldsW; }
+                if (tx.key.empty() || tx.keyLdsWords != ldsW) { tx.key = Jit::get().keyFor(tx.text, ldsW, (uint32_t)blockSize); tx.keyLdsWords = ldsW; }
                 auto& slot = byText[tx.key];
                 slot.first = &tx; slot.second.push_back(isl);
             }
             for (auto& kvk : byText) {
                 auto& kv = kvk.second;
                 // background mode: a shape only one island has (a voice that is fading out next to its replacement, a
-                // one-off graph) is not worth a compile of its own: it renders through the interpreter kernel
+                // one-off graph) is not worth a compile at commit time: its plan may be gone in 30 ms. It gets a DEFERRED entry —
+                // known to the kernel cache, not queued — and renders through the interpreter kernel; once this plan has rendered
+                // for a while (Engine::promoteDeferredShapes: `spec_lonely_blocks` blocks and `spec_lonely_ms` of wall clock) the
+                // shape is queued behind everything else, so a static single-patch graph leaves the interpreter too (r04: never)
                 const uint32_t ldsW = p.islands[kv.second[0]].ldsWords;
                 SpecText& tx = *kv.first;
-                // ... unless it keeps coming back: a live graph that replaces a voice per commit meets the same one-off shape (the old
-                // voice fading out behind its own mixer and root) in every plan — the second plan that wants it has it compiled
+                // ... and at once when it keeps coming back: a live graph that replaces a voice per commit meets the same one-off shape
+                // (the old voice fading out behind its own mixer and root) in every plan — the second plan that wants it has it compiled
                 const bool lonely = specialize == 1 && kv.second.size() < 2;
-                if (lonely && !Jit::get().knownKey(tx.key) && Jit::get().sighting(tx.key) < 2u) continue;
+                const bool defer = lonely && !Jit::get().knownKey(tx.key) && Jit::get().sighting(tx.key) < 2u;
                 Plan::SpecShape sh;
                 sh.optional = lonely;
-                sh.entry = Jit::get().requestKey(tx.key, tx.text, ldsW);
+                sh.deferred = defer;
+                sh.entry = Jit::get().requestKey(tx.key, tx.text, ldsW, (uint32_t)blockSize, defer);
+                if (defer) p.deferredShapes++;
                 sh.level = (uint32_t)l; sh.listBegin = (uint32_t)p.specLists.size();
                 sh.stateless = p.islands[kv.second[0]].stateless != 0u;
                 // (levelIslands entry format: island | split part << 24 — a split island is one workgroup per part)
@@ -1934,6 +1947,26 @@ std::string Engine::describePlan() {
         for (int k = 0; k < 6; ++k) { char b[64]; std::snprintf(b, sizeof b, "%s\"%s\":%.1f", k ? "," : "", names[k], p.buildUs[k]); s += b; }
     }
     s += "},";
+    {   // which kernels rendered (island x block units since the handle was made), this plan's shapes, the process-wide kernel cache
+        const JitStats js = Jit::get().stats();
+        const uint64_t tot = islandBlocksSpec + islandBlocksInterp;
+        char b[1024];
+        uint32_t ready = 0, waiting = 0, deferred = 0;
+        for (const Plan::SpecShape& sh : p.shapes) { const int stt = sh.entry->state.load(); if (stt == 1) ++ready; else if (stt == 2) ++deferred; else if (stt == 0) ++waiting; }
+        std::snprintf(b, sizeof b, "\"island_blocks_spec\":%llu,\"island_blocks_interp\":%llu,\"interp_block_fraction\":%.6f,"
+                      "\"shapes\":{\"total\":%zu,\"ready\":%u,\"compiling\":%u,\"deferred\":%u},"
+                      "\"jit\":{\"entries\":%llu,\"entry_cap\":%u,\"modules_loaded\":%llu,\"compiles\":%llu,\"disk_hits\":%llu,\"failed\":%llu,\"evictions\":%llu,"
+                      "\"abandoned\":%llu,\"queued\":%llu,\"deferred\":%llu,\"promoted\":%llu,\"compile_ms_mean\":%.1f,\"compile_ms_max\":%.1f,\"compile_ms_last\":%.1f,"
+                      "\"text_bytes_held\":%llu,\"code_bytes_held\":%llu,\"disk_bytes\":%llu,\"disk_cap_bytes\":%llu,\"disk_files_removed\":%llu,\"workers\":%u},",
+                      (unsigned long long)islandBlocksSpec, (unsigned long long)islandBlocksInterp, tot ? (double)islandBlocksInterp / (double)tot : 0.0,
+                      p.shapes.size(), ready, waiting, deferred,
+                      (unsigned long long)js.entries, js.entryCap, (unsigned long long)js.modulesLoaded, (unsigned long long)js.compiles, (unsigned long long)js.diskHits,
+                      (unsigned long long)js.failed, (unsigned long long)js.evictions, (unsigned long long)js.abandoned, (unsigned long long)js.queued,
+                      (unsigned long long)js.deferred, (unsigned long long)js.promoted, js.compiles ? js.compileMsTotal / (double)js.compiles : 0.0, js.compileMsMax, js.compileMsLast,
+                      (unsigned long long)js.sourceBytesHeld, (unsigned long long)js.codeBytesHeld, (unsigned long long)js.diskBytes, (unsigned long long)js.diskCapBytes,
+                      (unsigned long long)js.diskFilesRemoved, js.workers);
+        s += b;
+    }
     kv("num_taps", p.taps.size()); kv("taps_in_sets", p.tapsInSets ? 1 : 0); kv("num_tap_nodes", p.taps.size() + p.tapPairs.size()); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());
     s += "\"level_sizes\":[";
     for (size_t l = 0; l + 1 < p.levelOffsets.size(); ++l) { if (l) s += ","; s += std::to_string(p.levelOffsets[l + 1] - p.levelOffsets[l]); }

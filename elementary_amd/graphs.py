@@ -20,6 +20,12 @@ def c1_graph() -> List[NodeRepr]:
 C1_SAMPLE_RATE = 44100.0
 
 
+def c1_algorithmic_bytes(block: int = 512) -> int:
+    """4 shared consts x 1 + per channel [const 1 + phasor 2 + mul 3 + sin 2 + mul 3 + svf 4 + root 2] = 38
+    buffer touches x 2 KB + the 4 KB bus = 80 KB per block."""
+    return (4 + 2 * 17) * block * 4 + 2 * block * 4
+
+
 # ---- C2: 256-voice subtractive synth, 4107 nodes, sr 48 kHz -----------------------------------
 C2_SAMPLE_RATE = 48000.0
 C2_POLE = 0.9995

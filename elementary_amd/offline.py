@@ -57,6 +57,31 @@ class OfflineRenderer:
         bs = self.block_size
         total = len(outputs[0])
         host_batch = getattr(self._rt, "process_blocks_host", None)
+        window = getattr(self._rt, "event_window_blocks", None)
+        if host_batch is not None and window is not None and any(self._listeners.values()) and total > bs:
+            # listeners to serve: the reference relays events after EVERY block (index.ts:112-122). The engine keeps per-block readout
+            # logs, so the block loop still runs as launch sets — `event_window_blocks()` blocks per engine call (1024 with meters and
+            # snapshots only, fewer with a scope ring, one with a capture node) — and the BLOCKWISE relay after each call hands the
+            # listeners every block's events in block order, as the per-block loop would have
+            w = max(1, int(window())) * bs
+            for k in range(0, total, w):
+                m = min(w, total - k)
+                x = None
+                if self.num_in:
+                    x = np.zeros((self.num_in, m), dtype=np.float32)
+                    for i, buf in enumerate(inputs):
+                        seg = np.asarray(buf[k:k + m], dtype=np.float32)
+                        x[i, :len(seg)] = seg
+                y = host_batch(x, self.num_out, m, sample_time=self._time)
+                self._time += ((m + bs - 1) // bs) * bs
+                for kind, payload in self._rt.process_queued_events(blockwise=True):
+                    for cb in self._listeners.get(kind, []):
+                        cb(payload)
+                for i, buf in enumerate(outputs):
+                    mm = min(m, len(buf) - k)
+                    if mm > 0:
+                        buf[k:k + mm] = y[i, :mm]
+            return
         if host_batch is not None and not any(self._listeners.values()) and total > bs:
             # no event listeners to serve between blocks: the whole block loop in one engine call
             # (elemhip_process_blocks_host: launch sets staged through pinned double buffers); the event queues are drained

@@ -140,6 +140,13 @@ class Runtime(CRuntime):
             self.sample_time += nb * self.block_size
         return out
 
+    def event_window_blocks(self) -> int:
+        """Blocks a ``process_queued_events(blockwise=True)`` window may span and still equal a relay after every block."""
+        f = self._lib.elemhip_event_window_blocks
+        f.argtypes = [C.c_void_p]
+        f.restype = C.c_uint32
+        return int(f(self._h))
+
     def set_stream(self, hip_stream: int) -> None:
         self._lib.elemhip_set_stream(self._h, C.c_void_p(hip_stream))
 

@@ -156,6 +156,16 @@ int  elemhip_get_launch_profile(elemhip_t*, double* msOut, size_t cap, uint64_t*
  * render sequence whose root is active: cb(type, JSON payload, user), e.g. ("meter", {"min":..,"max":..,"source":name|null}). */
 typedef void (*elemhip_event_cb)(const char* type, const char* json_payload, void* user);
 int  elemhip_process_queued_events(elemhip_t*, elemhip_event_cb cb, void* user);
+/* The relay of a caller that renders many blocks per call and still wants what the reference's offline renderer delivers by
+ * calling processQueuedEvents after EVERY block (js/packages/offline-renderer/index.ts:112-120): every block's events since the
+ * last relay, in block order, nodes in render order inside a block — reconstructed from per-block readout logs the kernels keep
+ * (builtins/Analyzers.h:23-62, 83-131: `meter` queues one readout per block, `snapshot` one per latch; a per-block relay hands on the
+ * newest of each block). Exact while no more than elemhip_event_window_blocks() blocks pass between two relays (1024 for meter /
+ * snapshot; less with a `scope` — its 8192-frame ring must not overrun inside a window — and 1 with a `capture` node, whose take
+ * belongs to the block in which the gate fell). Neither relay holds up a render thread: the readouts are snapshotted in stream order
+ * and fetched on a stream of their own (runtime/elem/Runtime.h:437-446 drains lock-free queues). */
+int  elemhip_process_queued_events_blockwise(elemhip_t*, elemhip_event_cb cb, void* user);
+uint32_t elemhip_event_window_blocks(elemhip_t*);
 
 int  elemhip_trace_level(elemhip_t*, size_t nOut, uint32_t level, unsigned long long* out, size_t cap);
 /* Debug/test hook: JSON description of the current render plan (islands, launch levels, LDS).

@@ -22,7 +22,9 @@ assert os.environ.get("ELEMHIP_SPECIALIZE") == "1" and os.environ.get("ELEMHIP_K
 # Background mode compiles a shape only when at least two islands of the plan have it (a one-off island renders through the
 # interpreter kernel for good, plan.cpp), so the cases here are graphs of repeated islands: synth voices + their two mixers,
 # independent render jobs (two shapes), feedback loops through taps (one block in flight).
-CASES = ["c2x16", "c4x8", "four_tap_loops"]
+# r05: a shape only ONE island has is compiled too — once its plan has rendered 64 blocks and lived 30 ms (Engine::promoteDeferredShapes):
+# `one_off_chain` is a mono effects chain, a single island.
+CASES = ["c2x16", "c4x8", "four_tap_loops", "one_off_chain"]
 
 
 def make(name):
@@ -31,6 +33,10 @@ def make(name):
         roots, sr = graphs.c2_graph(voices=16), graphs.C2_SAMPLE_RATE
     elif name == "c4x8":
         roots, sr = [graphs.c4_instance(k) for k in range(8)], graphs.C4_SAMPLE_RATE
+    elif name == "one_off_chain":
+        from elementary_amd import el
+        x = el.in_({"channel": 0})
+        roots, sr, n_in = [el.tanh(el.lowpass(700.0, 1.2, el.add(el.mul(0.3, el.cycle(330.0)), el.sdelay({"size": 300}, x))))], 44100.0, 1
     else:
         from elementary_amd import el     # four roots, a filtered feedback loop through a tap each: four islands of one shape
 
@@ -81,7 +87,7 @@ while time.time() < deadline and any(e["after"] < 3 for e in engines):
 # may still be in the compiler: wait for them (so that the count below does not depend on timing) and render one more set with
 # every kernel loaded
 def _all_compiled(e):
-    return all(e["a"].spec_info(k)["state"] != 0 for k in range(e["a"].stats()["spec_shapes"]))
+    return all(e["a"].spec_info(k)["state"] not in (0, 2) for k in range(e["a"].stats()["spec_shapes"]))   # (2: deferred, not queued yet)
 
 
 while time.time() < deadline and not all(_all_compiled(e) for e in engines):

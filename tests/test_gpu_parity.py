@@ -276,6 +276,43 @@ def test_mc_capture_events(gpu_required):
     assert n_events >= 10
 
 
+def test_mc_capture_gains_a_channel(gpu_required):
+    """a LIVE mc.capture node whose second output channel is consumed only by a later render. The new
+    channel's record used to be cloned from channel 0's device record, CAP_CH included: it passed input 1 through instead of
+    input 2 and recorded every block a second time into the shared ring (duplicated takes)."""
+    import oracle
+    if not oracle.have_ref():
+        pytest.skip("needs oracle/_ref")
+    from elementary_amd.runtime import Runtime
+    logs, outs = [], []
+    for mk in (lambda sr, bs: Runtime(sr, bs, device=0), lambda sr, bs: oracle.RefRuntime(sr, bs)):
+        rt = mk(44100.0, 512)
+        x0, x1 = el.in_({"channel": 0}), el.in_({"channel": 1})
+        cap = el.mc.capture({"name": "take", "channels": 2}, el.train(9.0), x0, el.mul(0.5, x1))
+        assert rt.render(cap[0])["result"] == 0
+        log, out = [], []
+        for k in range(36):
+            x = np.stack([lcg_noise(512, 7 + k, 0.5), lcg_noise(512, 207 + k, 0.5)])
+            y = rt.process(x, 2, 512)
+            out.append(y)
+            if k == 11:
+                assert rt.render(cap[0], cap[1])["result"] == 0     # the same node, one more consumed channel
+            log.append(rt.process_queued_events())
+        logs.append(log); outs.append(np.stack(out))
+    assert float(np.abs(outs[0] - outs[1]).max()) <= TOL
+    assert float(np.abs(outs[1][20:, 1]).max()) > 0.01                  # channel 1 really renders input 2 after the second render
+    n_events = 0
+    for a, b in zip(*logs):
+        assert [(t, p.get("source")) for t, p in a] == [(t, p.get("source")) for t, p in b], (a, b)
+        for (_, pa), (_, pb) in zip(a, b):
+            assert [len(c) for c in pa["data"]] == [len(c) for c in pb["data"]]
+            for ca, cb in zip(pa["data"], pb["data"]):
+                if len(cb):
+                    assert float(np.abs(np.asarray(ca, np.float64) - np.asarray(cb, np.float64)).max()) <= TOL
+            n_events += 1
+    assert n_events >= 4
+
+
 def test_stranger_things_example(gpu_required):
     """cli/examples/02_StrangerThings.js:10-31 (the reference's own example patch, also the 69-node voice of
     hashing.test.js) rendered on both engines, two channels, 3 s of audio at the cli's sample rate."""
