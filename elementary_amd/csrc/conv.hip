@@ -87,6 +87,11 @@ __device__ __forceinline__ State state_of(gup base) {
     return st;
 }
 
+// which kernel family renders this node's share of a launch set of `batch` blocks (conv_long.inc; the same answer in every kernel)
+__device__ __forceinline__ bool conv_use_long(const State& st, uint32_t batch, uint32_t longMode) {
+    return longMode != 0u && st.hdr[conv::H_Q] != 0u && batch >= 8u && (batch & 7u) == 0u;
+}
+
 // sum_{p=2}^{P-1} H_p[k] X_{b-p}[k] restricted to partitions p = 2 + q, q = q0, q0 + dq, ...
 __device__ __forceinline__ c2 older_sum(const State& st, uint32_t b, uint32_t k, uint32_t q0, uint32_t dq) {
     const uint32_t P = st.P, bm = b % P;
@@ -215,6 +220,11 @@ __device__ void conv_main(const ConvDesc d, gup recs, gfp hbm, const Globals* g,
                 st.overlap[j] = B[512u + j].x;
                 st.X[(size_t)(blk % st.P) * 512u + j] = Xk[j];
             }
+            // the node's last input blocks in the time domain: the history a long-partition launch set starts from (conv_long.inc)
+            if (const uint32_t R = st.hdr[conv::H_HISTBLKS]) {
+                gfp hist = st.overlap + 512u + (size_t)(blk % R) * 512u;
+                for (uint32_t j = tid; j < 512u; j += 256u) hist[j] = st.inbuf[j];
+            }
             fill = 0u; blk += 1u;
         }
         processed += chunk;
@@ -283,7 +293,7 @@ constexpr uint32_t kMacParts = 2;       // workgroups the partitions of one (nod
 // set's first block + kTileHist) and of IR rows [kTileHist][16] — a workgroup's whole window is one contiguous stream, where the
 // natural [row][512] layout hands out 128-byte pieces 4 KB apart
 constexpr uint32_t kTileHist = 192;     // history rows (= the longest IR, in partitions, the matrix-core kernel takes)
-__host__ __device__ __forceinline__ size_t batch_scratch_floats(uint32_t maxBatch) {
+__host__ __device__ __forceinline__ size_t batch_scratch_floats_512(uint32_t maxBatch) {
     return kBatchHdr + (size_t)maxBatch * 1024u + (size_t)(maxBatch + 1u) * 512u + (size_t)kMacParts * maxBatch * 1024u
          + (size_t)(kTileHist + maxBatch) * 1024u + (size_t)kTileHist * 1024u;
 }
@@ -294,7 +304,7 @@ struct BatchCtx {
 };
 
 // decode shared by the three kernels; live == false: the node writes zeros (Convolve.h:70-71) or does nothing
-__device__ __forceinline__ bool batch_ctx(const ConvDesc& d, gup recs, const Globals* g, float* scratchAll, uint32_t convIdx, uint32_t maxBatch, BatchCtx& c) {
+__device__ __forceinline__ bool batch_ctx(const ConvDesc& d, gup recs, const Globals* g, float* scratchAll, uint32_t convIdx, uint32_t maxBatch, BatchCtx& c, size_t perNode) {
     gcup r = (gcup)(recs + d.rec * kRecDwords);
     const uint64_t sp = (uint64_t)r[rec::CONV_STATE] | ((uint64_t)r[rec::CONV_STATE + 1] << 32);
     c.inKind = d.inKind; c.inBuf = d.inIdx;
@@ -306,7 +316,7 @@ __device__ __forceinline__ bool batch_ctx(const ConvDesc& d, gup recs, const Glo
     c.cval = c.inKind == 2u ? __uint_as_float(((gcup)recs)[d.inIdx * kRecDwords + rec::P0]) : 0.0f;
     c.gain = 1.0f;
     if (d.fuseRootRec != kNone) c.gain = __uint_as_float(((gcup)recs)[d.fuseRootRec * kRecDwords + rec::ROOT_TARGET]);   // settled fades only (Engine::batchEligible)
-    c.scratch = (gfp)(scratchAll + (size_t)convIdx * batch_scratch_floats(maxBatch));
+    c.scratch = (gfp)(scratchAll + (size_t)convIdx * perNode);      // per node: the 512-partition area, then the long-partition area (conv_long.inc)
     c.xnew = (gf2p)(c.scratch + kBatchHdr);
     c.tails = c.scratch + kBatchHdr + (size_t)maxBatch * 1024u;
     c.ysum = (gf2p)(c.tails + (size_t)(maxBatch + 1u) * 512u);
@@ -325,13 +335,14 @@ __device__ __forceinline__ bool batch_ctx(const ConvDesc& d, gup recs, const Glo
 
 __global__ __launch_bounds__(256)
 void elemhip_convolve_batch_fft(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t macMode) {
+                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t macMode, uint32_t longMode, size_t perNode) {
     __shared__ c2 A[conv::kFft], B[conv::kFft], W[conv::kFft];
     const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, j = blockIdx.y, tid = threadIdx.x;
     const ConvDesc d = pv.convs[convIdx];
     if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
     BatchCtx c;
-    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) return;
+    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c, perNode)) return;
+    if (conv_use_long(c.st, gridDim.y, longMode)) return;           // this node's share of the set goes through the long-partition kernels
     const uint32_t stride = g->blockStride;
     gcfp in = (gcfp)(hbm + (size_t)j * arenaFloats + (size_t)(c.inKind == 1u ? c.inBuf : 0u) * stride);
     for (uint32_t i = tid; i < conv::kFft; i += 256u) W[i] = kTwiddle[i];
@@ -637,13 +648,14 @@ __device__ __forceinline__ void batch_mac_tile_mfma(const BatchCtx& c, uint32_t 
 
 __global__ __launch_bounds__(256)
 void elemhip_convolve_batch_mac(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t batch, uint32_t mode) {
+                                uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t batch, uint32_t mode, uint32_t longMode, size_t perNode) {
     const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, tile = blockIdx.y, tid = threadIdx.x;
     const uint32_t part = blockIdx.z % kMacParts, jBase = (blockIdx.z / kMacParts) * 64u;
     const ConvDesc d = pv.convs[convIdx];
     if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
     BatchCtx c;
-    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) return;     // (the ifft kernel writes the zeros)
+    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c, perNode)) return;     // (the ifft kernel writes the zeros)
+    if (conv_use_long(c.st, batch, longMode)) return;
     // (mode != 0: the nodes whose IR fits the matrix-core kernel are rendered by elemhip_convolve_batch_mac_mfma)
     if (mode != 0u && c.st.P <= kTileHist) return;
     __shared__ __attribute__((aligned(16))) char ldsRaw[(kMacR * 20u + (kMacDP + 1u) * kMacU * 16u) * 8u];
@@ -658,24 +670,23 @@ void elemhip_convolve_batch_mac(PlanView pv, uint32_t* recs, float* hbm, const G
 // operand roles exchanged (the layout probe of the bring-up: wrong sums by construction).
 __global__ __launch_bounds__(256)
 void elemhip_convolve_batch_mac_mfma(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                     uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t batch, uint32_t mode, uint32_t chunks) {
+                                     uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t batch, uint32_t mode, uint32_t chunks, uint32_t longMode, size_t perNode) {
     const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, tile = blockIdx.y, tid = threadIdx.x, jFirst = blockIdx.z * chunks * kMfmaOut;
     const ConvDesc d = pv.convs[convIdx];
     if (jFirst >= batch || !root_running((gcup)recs, d.rootRec, g->numOut)) return;
     BatchCtx c;
-    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c) || c.st.P > kTileHist) return;
+    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c, perNode) || c.st.P > kTileHist || conv_use_long(c.st, batch, longMode)) return;
     __shared__ __attribute__((aligned(16))) char ldsRaw[kMfmaLdsBytes];
     c2 (*Xm)[16] = reinterpret_cast<c2 (*)[16]>(ldsRaw);
     c2 (*Hm)[16] = reinterpret_cast<c2 (*)[16]>(ldsRaw + (size_t)kMfmaRing * 16u * 8u);
-    if (mode == 2u) { if (tile == 0u) batch_mac_tile_mfma<true, true>(c, tile, jFirst, chunks, batch, tid, Xm, Hm); else batch_mac_tile_mfma<false, true>(c, tile, jFirst, chunks, batch, tid, Xm, Hm); }
-    else if (tile == 0u) batch_mac_tile_mfma<true, false>(c, tile, jFirst, chunks, batch, tid, Xm, Hm);
+    if (tile == 0u) batch_mac_tile_mfma<true, false>(c, tile, jFirst, chunks, batch, tid, Xm, Hm);
     else batch_mac_tile_mfma<false, false>(c, tile, jFirst, chunks, batch, tid, Xm, Hm);
 }
 
 // K2b (node, j): inverse FFT of the block's partition sum; head half -> the node's output buffer of block j, tail half -> tails[j + 1]
 __global__ __launch_bounds__(256)
 void elemhip_convolve_batch_ifft(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                 uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t macMode) {
+                                 uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t macMode, uint32_t longMode, size_t perNode) {
     __shared__ c2 A[conv::kFft], B[conv::kFft], W[conv::kFft];
     const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, j = blockIdx.y, tid = threadIdx.x;
     const ConvDesc d = pv.convs[convIdx];
@@ -683,10 +694,11 @@ void elemhip_convolve_batch_ifft(PlanView pv, uint32_t* recs, float* hbm, const 
     BatchCtx c;
     const uint32_t stride = g->blockStride;
     gfp out = (gfp)hbm + (size_t)j * arenaFloats + (size_t)d.outHbm * stride;
-    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) {
+    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c, perNode)) {
         for (uint32_t i = tid; i < 512u; i += 256u) out[i] = 0.0f;
         return;
     }
+    if (conv_use_long(c.st, gridDim.y, longMode)) return;
     for (uint32_t i = tid; i < conv::kFft; i += 256u) W[i] = kTwiddle[i];
     // bins 2 tid, 2 tid + 1 of the sum; the conjugate-symmetric half makes the 1024-point transform's input
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -709,14 +721,23 @@ void elemhip_convolve_batch_ifft(PlanView pv, uint32_t* recs, float* hbm, const 
 
 __global__ __launch_bounds__(256)
 void elemhip_convolve_batch_finish(PlanView pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                   uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch) {
+                                   uint32_t arenaFloats, float* scratchAll, uint32_t maxBatch, uint32_t longMode, size_t perNode) {
     const uint32_t convIdx = pv.convWork[workBegin + blockIdx.x] & 0xFFFFu, j = blockIdx.y, tid = threadIdx.x, batch = gridDim.y;
     const ConvDesc d = pv.convs[convIdx];
     if (!root_running((gcup)recs, d.rootRec, g->numOut)) return;
     BatchCtx c;
-    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c)) return;
+    if (!batch_ctx(d, (gup)recs, g, scratchAll, convIdx, maxBatch, c, perNode)) return;
+    if (conv_use_long(c.st, batch, longMode)) return;
     const uint32_t stride = g->blockStride, P = c.st.P, b0 = ((gcup)c.scratch)[0];
     gfp out = (gfp)hbm + (size_t)j * arenaFloats + (size_t)d.outHbm * stride;
+    // the node's last input blocks in the time domain (a later launch set may take the long-partition path: conv_long.inc)
+    if (const uint32_t R = c.st.hdr[conv::H_HISTBLKS]) {
+        if (j + R >= batch) {
+            gcfp in = (gcfp)(hbm + (size_t)j * arenaFloats + (size_t)(c.inKind == 1u ? c.inBuf : 0u) * stride);
+            gfp hist = c.st.overlap + 512u + (size_t)((b0 + j) % R) * 512u;
+            for (uint32_t i = tid; i < 512u; i += 256u) hist[i] = c.inKind == 1u ? in[i] : c.cval;
+        }
+    }
     for (uint32_t i = tid; i < 512u; i += 256u) {
         const float y = out[i] + c.tails[(size_t)j * 512u + i];
         out[i] = d.fuseRootRec == kNone ? y : y * c.gain;
@@ -732,6 +753,8 @@ void elemhip_convolve_batch_finish(PlanView pv, uint32_t* recs, float* hbm, cons
     }
 }
 
+#include "conv_long.inc"
+
 namespace elemhip {
 
 void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g,
@@ -739,13 +762,22 @@ void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* h
     hipLaunchKernelGGL(elemhip_convolve_kernel, dim3(numWorkgroups), dim3(256), 0, s, pv, recs, hbm, g, workBegin);
 }
 
-size_t convolve_batch_scratch_floats(uint32_t maxBatch) { return batch_scratch_floats(maxBatch); }
+size_t convolve_batch_scratch_floats(uint32_t maxBatch, uint32_t longHistRows) {
+    return batch_scratch_floats_512(maxBatch) + (longHistRows ? long_scratch_floats(maxBatch, longHistRows) : 0u);
+}
 
+// One launch set of the convolve nodes of a level. `longHistRows` != 0: nodes with long-partition spectra render whole sets of a
+// multiple of 8 blocks through the long-partition kernels (conv_long.inc; longHistRows = the most tap groups any IR has, - 1);
+// `anyShortPath`: some node of the level (or this set's size) still needs the 512-partition kernels.
 void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
                            uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch, uint32_t macMode,
-                           bool anyShortIr, bool anyLongIr) {
+                           bool anyShortIr, bool anyLongIr, uint32_t longHistRows, bool anyShortPath, uint32_t longStateBlocks) {
     const dim3 grid(numNodes, batch), block(256);
-    hipLaunchKernelGGL(elemhip_convolve_batch_fft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, macMode);
+    const size_t perNode = convolve_batch_scratch_floats(maxBatch, longHistRows);
+    const bool longSet = longHistRows != 0u && batch >= 8u && (batch & 7u) == 0u;
+    const uint32_t longMode = longSet ? 1u : 0u;
+    if (!longSet || anyShortPath) {
+    hipLaunchKernelGGL(elemhip_convolve_batch_fft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, macMode, longMode, perNode);
     // the partition sums: nodes whose IR has at most kTileHist partitions on the matrix cores (macMode != 0), the others through the
     // vector kernel — (node, 16-bin tile, 64-block chunk x partition run)
     if (macMode != 0u && anyShortIr) {
@@ -753,18 +785,32 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
         const uint32_t runs = (batch + kMfmaOut - 1u) / kMfmaOut, pairs = numNodes * (conv::kBlock / 16u);
         uint32_t per = (runs * pairs) / 512u;      // (two workgroups per CU: LDS)
         per = per < 1u ? 1u : (per > runs ? runs : per);
-        hipLaunchKernelGGL(elemhip_convolve_batch_mac_mfma, dim3(numNodes, conv::kBlock / 16u, (runs + per - 1u) / per), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, macMode, per);
+        hipLaunchKernelGGL(elemhip_convolve_batch_mac_mfma, dim3(numNodes, conv::kBlock / 16u, (runs + per - 1u) / per), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, macMode, per, longMode, perNode);
     }
     if (macMode == 0u || anyLongIr)
-    hipLaunchKernelGGL(elemhip_convolve_batch_mac, dim3(numNodes, conv::kBlock / 16u, kMacParts * ((batch + 63u) / 64u)), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, macMode);
-    hipLaunchKernelGGL(elemhip_convolve_batch_ifft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, macMode);
-    hipLaunchKernelGGL(elemhip_convolve_batch_finish, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch);
+    hipLaunchKernelGGL(elemhip_convolve_batch_mac, dim3(numNodes, conv::kBlock / 16u, kMacParts * ((batch + 63u) / 64u)), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, macMode, longMode, perNode);
+    hipLaunchKernelGGL(elemhip_convolve_batch_ifft, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, macMode, longMode, perNode);
+    hipLaunchKernelGGL(elemhip_convolve_batch_finish, grid, block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, longMode, perNode);
+    }
+    if (longSet) {
+        const uint32_t chunks = batch / 8u;
+        hipLaunchKernelGGL(elemhip_convolve_long_fft, dim3(numNodes, longHistRows + chunks), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
+        hipLaunchKernelGGL(elemhip_convolve_long_mac, dim3(numNodes, (lfft::kBins + 255u) / 256u, (chunks + kLongRun - 1u) / kLongRun), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
+        hipLaunchKernelGGL(elemhip_convolve_long_ifft, dim3(numNodes, chunks), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
+        hipLaunchKernelGGL(elemhip_convolve_long_state, dim3(numNodes, longStateBlocks < batch ? longStateBlocks : batch), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longMode, perNode);
+        hipLaunchKernelGGL(elemhip_convolve_long_tail, dim3(numNodes), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longMode, perNode);
+    }
 }
+
+uint32_t convolve_long_tap_group() { return kLongTaps; }
+uint32_t convolve_long_row_floats() { return kRow * 2u; }
 
 uint32_t convolve_mfma_max_partitions() { return kTileHist; }
 
-hipError_t upload_convolve_tables(const float* twiddleReIm /* 2 * 1024 floats */) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(kTwiddle), twiddleReIm, sizeof(float) * 2 * conv::kFft);
+hipError_t upload_convolve_tables(const float* twiddleReIm /* 2 * 1024 floats */, const float* twiddle8192ReIm /* 2 * 8192 floats */) {
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(kTwiddle), twiddleReIm, sizeof(float) * 2 * conv::kFft);
+    if (e != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(kTw8192), twiddle8192ReIm, sizeof(float) * 2 * lfft::N);
 }
 
 } // namespace elemhip

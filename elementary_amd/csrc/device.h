@@ -194,6 +194,8 @@ enum : uint32_t {
     H_FILL_NEXT = 4, H_BLK_NEXT = 5,   // written by the node's main workgroup, committed by the epilogue
     H_PREVALID0 = 6,    // [2]: block index whose older-partition sum pre[i] holds
     H_PRESLOW_FOR = 8,  // block index preSlow holds (only when a call straddles two input blocks)
+    H_Q = 9,            // long partitions (4096 samples) of the IR, 0: the node has no long-partition spectra (conv_long.inc)
+    H_HISTBLKS = 10,    // blocks of the time-domain input ring behind `overlap` (0: none)
     kHeaderDwords = 16,
 };
 }

@@ -170,7 +170,12 @@ Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), devi
             const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)conv::kFft;
             tw[2 * k] = (float)std::cos(a); tw[2 * k + 1] = (float)std::sin(a);
         }
-        if (upload_convolve_tables(tw.data()) != hipSuccess) { fail(kHipError); return; }
+        std::vector<float> tw8(2 * 8192);     // ... and cis(-2 pi j / 8192) for the long-partition transforms (conv_long.inc, fft4096.h)
+        for (uint32_t k = 0; k < 8192; ++k) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)k / 8192.0;
+            tw8[2 * k] = (float)std::cos(a); tw8[2 * k + 1] = (float)std::sin(a);
+        }
+        if (upload_convolve_tables(tw.data(), tw8.data()) != hipSuccess) { fail(kHipError); return; }
     }
     // LCG jump-ahead table for `rand` (Noise.h:28-32): s_k = A[k]*s_0 + C[k] (mod 2^32)
     std::vector<uint32_t> lcg(2 * (kMaxBlock + 1));
@@ -423,9 +428,20 @@ int Engine::setConvolverIr(Node& n, const ResourcePtr& res) {
     const uint32_t P = (uint32_t)((len + B - 1) / B);
     const uint32_t older = P > 2 ? P - 2 : 0;
     const uint32_t S = std::min<uint32_t>(conv::kMaxSlices, std::max<uint32_t>(1, (older + conv::kSlicePartitions - 1) / conv::kSlicePartitions));
-    const size_t words = conv::kHeaderDwords + 2 * ((size_t)2 * P + 2 * S + 1) * 512 + 1024;
+    // Long partitions (conv_long.inc): launch sets of a multiple of 8 blocks evaluate an IR of at least kLongMinP 512-partitions as
+    // Q partitions of 4096 samples (8192-point spectra, G rows padded with zero rows to a multiple of the MAC's tap group) from a
+    // ring of the node's last R input blocks in the time domain; both live behind `overlap`.
+    constexpr uint32_t kLongMinP = 32;
+    const uint32_t tapGroup = convolve_long_tap_group(), rowFloats = convolve_long_row_floats();
+    const uint32_t Q = (convLong && P >= kLongMinP) ? (uint32_t)((len + 4095) / 4096) : 0u;
+    const uint32_t Qp = (Q + tapGroup - 1) / tapGroup * tapGroup;
+    const uint32_t R = Q ? 8u * Qp + 8u : 0u;
+    const size_t words512 = conv::kHeaderDwords + 2 * ((size_t)2 * P + 2 * S + 1) * 512 + 1024;
+    const size_t words = words512 + (size_t)R * 512 + (size_t)Qp * rowFloats;
     std::vector<uint32_t> blob(conv::kHeaderDwords + (size_t)P * 1024, 0u);
-    blob[conv::H_P] = P; blob[conv::H_S] = S;
+    blob[conv::H_P] = P; blob[conv::H_S] = S; blob[conv::H_Q] = Q; blob[conv::H_HISTBLKS] = R;
+    n.convQp = Qp; n.convHistBlocks = R; n.convP = P;
+    convMaxQp = std::max(convMaxQp, Qp);
     convMinP = std::min(convMinP, P); convMaxP = std::max(convMaxP, P);   // (over the engine's lifetime: which MAC kernels a launch set needs)
     // IR partition spectra in double, scaled by 1/1024 (exact), rounded to float, Nyquist packed into bin 0
     std::vector<std::complex<double>> a(N), tw(N / 2);
@@ -449,10 +465,38 @@ int Engine::setConvolverIr(Node& n, const ResourcePtr& res) {
         dst[0] = (float)(a[0].real() * sc); dst[1] = (float)(a[N / 2].real() * sc);
         for (uint32_t k = 1; k < N / 2; ++k) { dst[2 * k] = (float)(a[k].real() * sc); dst[2 * k + 1] = (float)(a[k].imag() * sc); }
     }
+    // G_q = RFFT_8192([g_q | 0]) / 16384 in double, rounded to float: the device transforms return 16384 x the circular convolution (fft4096.h)
+    std::vector<float> G((size_t)Qp * rowFloats, 0.0f);
+    if (Q) {
+        const uint32_t N8 = 8192;
+        std::vector<std::complex<double>> a8(N8), tw8(N8 / 2);
+        for (uint32_t k = 0; k < N8 / 2; ++k) { const double ang = -2.0 * 3.14159265358979323846 * k / N8; tw8[k] = {std::cos(ang), std::sin(ang)}; }
+        for (uint32_t q = 0; q < Q; ++q) {
+            for (uint32_t i = 0; i < N8; ++i) { const size_t j = (size_t)q * 4096 + i; a8[i] = (i < 4096 && j < len) ? (double)h[j] : 0.0; }
+            for (uint32_t i = 1, j = 0; i < N8; ++i) {            // bit reversal
+                uint32_t bit = N8 >> 1;
+                for (; j & bit; bit >>= 1) j ^= bit;
+                j ^= bit;
+                if (i < j) std::swap(a8[i], a8[j]);
+            }
+            for (uint32_t m = 2; m <= N8; m <<= 1)
+                for (uint32_t s0 = 0; s0 < N8; s0 += m)
+                    for (uint32_t k = 0; k < m / 2; ++k) {
+                        const std::complex<double> u = a8[s0 + k], t = a8[s0 + k + m / 2] * tw8[k * (N8 / m)];
+                        a8[s0 + k] = u + t; a8[s0 + k + m / 2] = u - t;
+                    }
+            float* dst = G.data() + (size_t)q * rowFloats;
+            for (uint32_t k = 0; k <= N8 / 2; ++k) { dst[2 * k] = (float)(a8[k].real() / 16384.0); dst[2 * k + 1] = (float)(a8[k].imag() / 16384.0); }
+        }
+    }
     int rc = allocRing(n, words);
     if (rc != kOk) return rc;
-    if (dry) std::memcpy(n.ring.ptr, blob.data(), blob.size() * 4);
-    else HIP_OK(hipMemcpy(n.ring.ptr, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+    const size_t gOff = (words512 + (size_t)R * 512) * 4;       // bytes: header + 512-partition state + input ring
+    if (dry) { std::memcpy(n.ring.ptr, blob.data(), blob.size() * 4); if (Q) std::memcpy((char*)n.ring.ptr + gOff, G.data(), G.size() * 4); }
+    else {
+        HIP_OK(hipMemcpy(n.ring.ptr, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+        if (Q) HIP_OK(hipMemcpy((char*)n.ring.ptr + gOff, G.data(), G.size() * 4, hipMemcpyHostToDevice));
+    }
     writeParamPtr(n, rec::CONV_STATE, n.ring.ptr);
     if (n.convSlices != S) { n.convSlices = S; planStale = true; }
     return kOk;
@@ -1495,6 +1539,7 @@ int Engine::setOption(const std::string& key, double value) {
     std::lock_guard<std::mutex> lock(mu);
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
     if (key == "host_out_direct") { hostOutDirect = value != 0; return kOk; }   // elemhip_process: epilogue writes the pinned host block itself
+    if (key == "conv_long") { convLong = value != 0; return kOk; }   // IRs set from now on get (or do not get) long-partition spectra; sets of older IRs keep theirs
     if (key == "conv_mfma") { convMfma = std::max(0, std::min(1, (int)value)); return kOk; }   // partition MAC of launch sets: 1 matrix cores (default), 0 packed vector FMAs
     if (key == "skip_idle_launches") { skipIdleLaunches = value != 0; dropGraphs(); return kOk; }
     if (key == "fuse_epilogue") { fuseEpilogue = value != 0; dropGraphs(); return kOk; }
@@ -1529,6 +1574,9 @@ int Engine::setOption(const std::string& key, double value) {
     }
     if (key == "spec_lonely_blocks") { lonelyBlocks = std::max(0, (int)value); return kOk; }   // background mode: a one-off shape is queued for compilation once its
     if (key == "spec_lonely_ms") { lonelyMs = std::max(0, (int)value); return kOk; }           // plan has rendered this many blocks and been current this long
+    // run-time compiler tunings (PROCESS-wide; bit-identical samples by construction, island_ops.inc): later plans compile with them
+    if (key == "biquad_form") { if (!Jit::get().setTuning("ELEMHIP_BIQUAD_FORM", (int)value)) return kInvalidPropertyValue; specTextCache.clear(); islandCache.clear(); islandShapeCache.clear(); planStale = true; return kOk; }
+    if (key == "wide_chain_depth") { if (!Jit::get().setTuning("ELEMHIP_WIDE_CHAIN_DEPTH", (int)value)) return kInvalidPropertyValue; specTextCache.clear(); islandCache.clear(); islandShapeCache.clear(); planStale = true; return kOk; }
     if (key == "jit_cache_entries") { Jit::get().setEntryCap((uint32_t)std::max(0.0, value)); return kOk; }   // PROCESS-wide: compiled shapes kept in memory (0: default 256)
     if (key == "time_batch") { timeBatch = std::max(1, std::min(256, (int)value)); return kOk; }
     if (key == "graph_blocks") { graphBlocks = std::max(1, (int)value); dropGraphs(); return kOk; }
@@ -2146,8 +2194,20 @@ void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32
     const uint32_t cb = p.convLevelOffsets[l], ce = p.convLevelOffsets[l + 1];
     uint32_t mains = 0;
     while (cb + mains < ce && (p.convWork[cb + mains] >> 16) == 0u) ++mains;   // main entries lead a level's work list
-    if (mains) launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks, (uint32_t)convMfma,
-                                     convMinP <= convolve_mfma_max_partitions(), convMaxP > convolve_mfma_max_partitions());
+    if (!mains) return;
+    // which nodes of the level have long-partition spectra (an IR can be replaced without a re-plan: looked up per launch set)
+    bool anyShortPath = false;
+    uint32_t stateBlocks = 1;
+    for (uint32_t k = 0; k < mains; ++k) {
+        const uint32_t ci = p.convWork[cb + k] & 0xFFFFu;
+        auto it = ci < p.convNodeIds.size() ? nodes.find(p.convNodeIds[ci]) : nodes.end();
+        if (it == nodes.end() || it->second.convQp == 0u) { anyShortPath = true; continue; }
+        stateBlocks = std::max(stateBlocks, std::max(it->second.convHistBlocks, it->second.convP));
+    }
+    const uint32_t longRows = (convLong && convMaxQp) ? convMaxQp - 1u : 0u;
+    if (longRows && batch >= 8u && (batch & 7u) == 0u && stateBlocks > 1u) convLongSets++;
+    launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks, (uint32_t)convMfma,
+                          convMinP <= convolve_mfma_max_partitions(), convMaxP > convolve_mfma_max_partitions(), longRows, anyShortPath, stateBlocks);
 }
 
 void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
@@ -2229,7 +2289,7 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             rc = ensureOutRing(std::max<size_t>(nOut, 1) * bs * (size_t)batchBlocks);
             if (rc != kOk) return rc;
             if (!p.convs.empty()) {
-                const size_t need = p.convs.size() * convolve_batch_scratch_floats((uint32_t)batchBlocks);
+                const size_t need = p.convs.size() * convolve_batch_scratch_floats((uint32_t)batchBlocks, (convLong && convMaxQp) ? convMaxQp - 1u : 0u);
                 if (need > convScratchFloats) {
                     HIP_OK(hipStreamSynchronize(stream));
                     if (dConvScratch) (void)hipFree(dConvScratch);

@@ -89,6 +89,7 @@ struct Node {
     uint32_t eventCount = 0;    // meter / snapshot: readouts already relayed by processQueuedEvents
     uint32_t logRelayed = 0;    // snapshot: entries of the per-block readout log already relayed
     uint32_t convSlices = 1;    // convolve: helper slices its current impulse response wants (conv.hip)
+    uint32_t convQp = 0, convHistBlocks = 0, convP = 0;   // convolve: long-partition tap rows (0: none), blocks of its input ring, 512-partitions (conv_long.inc)
     bool mc = false;            // multi-output node (mc.*): one record per output channel, planned as one entry per channel
     std::vector<uint32_t> chanRecs;   // records of output channels 1, 2, ... (allocated when a plan first needs them)
     std::vector<std::vector<float>> relayCh;   // mc.capture: one relay per capture channel (pendingEventData, mc/Capture.h:152)
@@ -311,6 +312,9 @@ private:
     int  graphBlocks = 8;
     bool hostOutDirect = true;             // process(): the epilogue kernel writes into the mapped pinned output block
     uint32_t convMinP = 0xFFFFFFFFu, convMaxP = 0;   // fewest / most partitions of any impulse response set so far
+    bool convLong = true;                  // option "conv_long": launch sets of a multiple of 8 blocks render IRs of >= 32 partitions with 4096-sample partitions (conv_long.inc)
+    uint64_t convLongSets = 0;             // launch sets in which some node took the long-partition kernels (describe_plan)
+    uint32_t convMaxQp = 0;                // most long-partition tap rows of any impulse response set so far (sizes the scratch)
     int convMfma = 1;                      // conv.hip elemhip_convolve_batch_mac: 1 v_mfma_f32_4x4x1_16B_f32 Toeplitz tiles, 0 v_pk_fma_f32 (r03)
     bool skipIdleLaunches = true;          // option "skip_idle_launches": launches of a level whose islands all belong to roots that do not run are left out
     bool fuseEpilogue = false;             // option "fuse_epilogue": elemhip_process' launch set of one ends in the last level's kernel (no epilogue launch);
@@ -425,6 +429,7 @@ struct Plan {
     std::vector<std::pair<int32_t, int32_t>> tapPairs;       // (tapIn node id, id of the in-island tapOut whose private buffer it reads inside a launch set, or 0)
     std::vector<std::pair<int32_t, int32_t>> eventNodes;   // (node id, owning root id) of meter / snapshot nodes, render order
     std::vector<ConvDesc> convs;           // convolve nodes (conv.hip)
+    std::vector<int32_t> convNodeIds;      // ... and their node ids (same order)
     std::vector<uint32_t> convWork;        // conv workgroups, level-major
     std::vector<uint32_t> convLevelOffsets; // numLevels + 1
     std::vector<int32_t> rootIds;          // same order as `roots`

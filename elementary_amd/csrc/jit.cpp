@@ -57,6 +57,11 @@ static std::string libraryDir() {
 
 // tuning experiments ("NAME=VALUE NAME2=VALUE2" -> #define lines in front of the node library, part of the cache key) exist only
 // in a `make EXPERIMENTAL=1` build: several of the hooks they reach render wrong samples by design (measurement only)
+// whitelisted tunings (Jit::setTuning): "#define NAME VALUE" lines in front of the node library
+static std::mutex gTuningMu;
+static std::string gTuning;
+static std::string tuningDefines() { std::lock_guard<std::mutex> l(gTuningMu); return gTuning; }
+
 static std::string experimentalDefines() {
 #ifdef ELEMHIP_EXPERIMENTAL
     const char* d = std::getenv("ELEMHIP_JIT_DEFINES");
@@ -311,6 +316,7 @@ static std::string sourcePrefix(uint32_t ldsWords, uint32_t block, size_t reserv
 #ifdef ELEMHIP_EXPERIMENTAL
     s += "#define ELEMHIP_EXPERIMENTAL 1\n";
 #endif
+    s += tuningDefines();
     const std::string defs = experimentalDefines();
     if (!defs.empty()) {
         std::string tok;
@@ -336,8 +342,21 @@ std::string Jit::fullSource(const std::string& generated, uint32_t ldsWords, uin
 
 // The key is a hash of the whole translation unit; its first ~300 KB are the same for every shape of one LDS size, so the hash
 // state behind them is kept (FNV-1a runs front to back: same keys as hashing the full source, a tenth of the time).
+bool Jit::setTuning(const std::string& name, int value) {
+    const bool ok = (name == "ELEMHIP_BIQUAD_FORM" && value >= 0 && value <= 2) ||
+                    (name == "ELEMHIP_WIDE_CHAIN_DEPTH" && (value == 2 || value == 4 || value == 8));
+    if (!ok) return false;
+    std::lock_guard<std::mutex> l(gTuningMu);
+    // replace an earlier line of the same name
+    const std::string head = "#define " + name + " ";
+    size_t at = gTuning.find(head);
+    if (at != std::string::npos) gTuning.erase(at, gTuning.find('\n', at) - at + 1);
+    gTuning += head + std::to_string(value) + "\n";
+    return true;
+}
+
 std::string Jit::keyFor(const std::string& generated, uint32_t ldsWords, uint32_t block) {
-    const std::string defs = experimentalDefines();
+    const std::string defs = experimentalDefines() + "|" + tuningDefines();
     const uint64_t pk = ((uint64_t)block << 32) | ldsWords;
     uint64_t h1 = 0, h2 = 0;
     bool have = false;

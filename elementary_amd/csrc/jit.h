@@ -55,6 +55,9 @@ public:
     int wait(const std::shared_ptr<SpecEntry>& e);   // blocks until compiled: 1 ready, -1 failed
     static std::string fullSource(const std::string& generated, uint32_t ldsWords, uint32_t block);
     JitStats stats();
+    // a whitelisted tuning define of the run-time compiler (PROCESS-wide, part of every later kernel's cache key). Only knobs that
+    // leave every sample bit-identical are accepted: "ELEMHIP_BIQUAD_FORM" 0..2, "ELEMHIP_WIDE_CHAIN_DEPTH" 2 | 4 | 8. false = refused.
+    bool setTuning(const std::string& name, int value);
     void setEntryCap(uint32_t cap);                  // option "jit_cache_entries": in-memory entries (code objects + loaded modules) kept; 0 = default
     void noteModuleLoaded(int delta);
     void shutdownAtExit();

@@ -22,12 +22,14 @@ void launch_level_rt(hipStream_t s, const PlanView& pv, uint32_t* recs, float* h
                      uint32_t levelBegin, uint32_t numIslands, uint32_t ldsBytes);
 void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g,
                      uint32_t workBegin, uint32_t numWorkgroups);
-size_t convolve_batch_scratch_floats(uint32_t maxBatch);   // per convolve node
+size_t convolve_batch_scratch_floats(uint32_t maxBatch, uint32_t longHistRows);   // per convolve node (longHistRows: 0 = no long-partition area)
 void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
                            uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch, uint32_t macMode,
-                           bool anyShortIr, bool anyLongIr);
+                           bool anyShortIr, bool anyLongIr, uint32_t longHistRows, bool anyShortPath, uint32_t longStateBlocks);
 uint32_t convolve_mfma_max_partitions();   // IRs of up to this many 512-tap partitions take the matrix-core MAC
-hipError_t upload_convolve_tables(const float* twiddleReIm);
+uint32_t convolve_long_tap_group();        // long-partition IR spectra are allocated in multiples of this many rows
+uint32_t convolve_long_row_floats();       // floats per long-partition spectrum row (4097 bins, padded)
+hipError_t upload_convolve_tables(const float* twiddleReIm, const float* twiddle8192ReIm);
 void launch_patches(hipStream_t s, const Patch* patches, uint32_t count, uint32_t* recs, uint32_t* globals);
 hipError_t launch_bus_sum(hipStream_t s, float* dst, const float* const* partials, uint32_t count, size_t n);   // dst = ((p0 + p1) + p2) + ... (rank order)
 

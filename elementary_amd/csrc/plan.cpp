@@ -663,6 +663,7 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             I.rootRec = d.rootRec; I.split = 0;                                         // no island-kernel workgroup
             convLevel.push_back(B.level);
             p.convs.push_back(d);
+            p.convNodeIds.push_back(x.n->id);
             continue;
         }
 
@@ -1967,6 +1968,7 @@ std::string Engine::describePlan() {
                       (unsigned long long)js.diskFilesRemoved, js.workers);
         s += b;
     }
+    kv("conv_long_sets", convLongSets); kv("conv_long", convLong ? 1 : 0); kv("conv_max_long_tap_rows", convMaxQp);
     kv("num_taps", p.taps.size()); kv("taps_in_sets", p.tapsInSets ? 1 : 0); kv("num_tap_nodes", p.taps.size() + p.tapPairs.size()); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());
     s += "\"level_sizes\":[";
     for (size_t l = 0; l + 1 < p.levelOffsets.size(); ++l) { if (l) s += ","; s += std::to_string(p.levelOffsets[l + 1] - p.levelOffsets[l]); }

@@ -78,9 +78,23 @@ for k in sorted(set(ctr["FETCH_SIZE"]) | set(ctr["WRITE_SIZE"])):
             row["hbm_bytes_per_dispatch"] = row["fetch_bytes_corrected_x2_mean"] + row["write_bytes_mean"]
         pmc_rows.append(row)
 pmc_rows.sort(key=lambda r: -r.get("hbm_bytes_per_dispatch", 0.0) * r["dispatches"])
-json.dump({"command": cmd, "passes": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE (three separate runs), --output-format csv",
+
+
+def bench_line(path):
+    """the JSON line the command itself printed in that pass: its own step time (with / without the profiler attached)"""
+    try:
+        lines = [ln for ln in open(path, errors="replace").read().splitlines() if ln.startswith("{")]
+        j = json.loads(lines[-1])
+        return {k: j.get(k) for k in ("value", "unit", "steps", "ms_per_step", "us_per_block", "us_per_block_step") if k in j}
+    except Exception:
+        return None
+
+
+own = {"without_profiler": bench_line(os.path.join(src, f"prof_{name}_plain.log")), "under_kernel_trace": bench_line(os.path.join(src, f"prof_{name}_stats.log"))}
+json.dump({"command": cmd, "command_own_step_time": own, "passes": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE (three separate runs), --output-format csv",
            "hbm_bytes": "2 x FETCH_SIZE (KB) + WRITE_SIZE (KB), per dispatch; the counter files name a dispatch by its TOTAL grid (X * Y * Z work-items)",
            "kernel_trace": trace_rows, "pmc": pmc_rows}, open(out, "w"), indent=1)
+print("own step time:", own)
 for r in trace_rows[:12]:
     print(f"trace {r['kernel'][:34]:34s} lds {r['lds_bytes']:6d} {r['part']:13s} grid {r['grid_work_items']:>16s} n={r['dispatches']:4d} mean {r['mean_us']:9.1f} us")
 for r in pmc_rows[:10]:

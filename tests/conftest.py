@@ -6,7 +6,8 @@ import pytest
 # Deterministic kernel choice for the suite: engines render through the ahead-of-time interpreter kernels unless a test
 # asks for the run-time specialised ones (tests/test_gpu_spec.py sets `specialize` per engine). The product default is 1
 # (specialised kernels compiled in the background, used once ready).
-os.environ.setdefault("ELEMHIP_SPECIALIZE", "0")
+# ELEMHIP_TEST_SPECIALIZE=1 runs the whole suite under the product default instead (kernel choice then depends on compile timing).
+os.environ.setdefault("ELEMHIP_SPECIALIZE", os.environ.get("ELEMHIP_TEST_SPECIALIZE", "0"))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -130,6 +130,7 @@ def test_partition_mac_on_matrix_cores_and_on_vector_fmas(gpu_required, mode):
     rt, x = _c3(hip, ch, blocks)
     rt.set_option("batch_blocks", 256)
     rt.set_option("conv_mfma", mode)
+    rt.set_option("conv_long", 0)        # (r05: a 256-block set of these IRs would take the long-partition kernels, not this MAC)
     got = np.concatenate([_blocks(rt, x, 0, 256, ch), _blocks(rt, x, 256, 93, ch), _blocks(rt, x, 349, 7, ch)])
     assert rt.stats()["batch_launches"] >= 3
     ref_rt, _ = _c3(lambda sr, bs: oracle.PortRuntime(sr, bs), ch, blocks)
@@ -171,6 +172,53 @@ def test_multi_block_and_single_block_calls_interleave(gpu_required, taps):
         assert float(np.abs(got.astype(np.float64) - ref).max()) <= TOL, (kind, n, k)
         k += n
     assert a.stats()["batch_launches"] >= batched     # the multi-block kernels did run
+
+
+@pytest.mark.parametrize("taps", [16384, 40000, 96000])
+def test_long_partition_sets_interleave_with_every_other_path(gpu_required, taps):
+    """conv_long.inc: launch sets of a multiple of 8 blocks render IRs of >= 32 partitions with 4096-sample partitions (8192-point
+    overlap-save, the history in front of a set from the node's time-domain input ring). One stream through sets of 8, 64, 72 and
+    16 blocks (long partitions), 10, 5 and 3 blocks (512-sample partitions) and single-block calls (main + helper workgroups), a
+    new IR half way (the convolver restarts from silence), two nodes with different IR lengths in one level — each stretch against
+    the restatement; then the same stream with `conv_long` = 0: the two evaluations agree far inside the tolerance."""
+    from elementary_amd import el
+    ir_a, ir_b, ir_c = graphs.c3_impulse_response(0, taps), graphs.c3_impulse_response(1, 20000), graphs.c3_impulse_response(2, 3000)
+    roots = [el.convolve({"path": "ir", "key": "a"}, el.in_({"channel": 0})),
+             el.mul(0.5, el.convolve({"path": "irc", "key": "c"}, el.mul(0.7, el.in_({"channel": 1}))))]      # 6 partitions: never long
+    plan = [("blocks", 8), ("one", 2), ("blocks", 64), ("blocks", 10), ("blocks", 72), ("one", 1), ("swap", 0), ("blocks", 16), ("blocks", 5),
+            ("blocks", 64), ("one", 3), ("blocks", 3), ("blocks", 8)]
+    total = sum(n for kind, n in plan if kind != "swap")
+    x = graphs.c3_input(2, total * 512)
+    outs = {}
+    for long_on in (1, 0):
+        a, c = hip(48000.0, 512), oracle.PortRuntime(48000.0, 512)
+        a.set_option("conv_long", long_on)
+        for rt in (a, c):
+            assert rt.add_shared_resource("ir", ir_a) and rt.add_shared_resource("irc", ir_c)
+            assert rt.render(*roots)["result"] == 0
+        k, got_all = 0, []
+        for kind, n in plan:
+            if kind == "swap":
+                for rt in (a, c):
+                    assert rt.add_shared_resource("ir2", ir_b)
+                    assert rt.render(el.convolve({"path": "ir2", "key": "a"}, el.in_({"channel": 0})), roots[1])["result"] == 0
+                continue
+            ref = np.stack([c.process(x[:, (k + i) * 512:(k + i + 1) * 512], 2, 512) for i in range(n)])
+            if kind == "blocks":
+                got = _blocks(a, x, k, n, 2)
+            else:
+                got = np.stack([a.process(x[:, (k + i) * 512:(k + i + 1) * 512], 2, 512) for i in range(n)])
+            err = np.abs(got.astype(np.float64) - ref).max(axis=(1, 2))
+            assert float(err.max()) <= TOL, (long_on, kind, n, k, int(err.argmax()), float(err.max()))
+            got_all.append(got)
+            k += n
+        outs[long_on] = np.concatenate(got_all)
+        assert a.stats()["batch_launches"] >= 8
+        if long_on:
+            assert a.describe_plan()["conv_long_sets"] >= 4, a.describe_plan()["conv_long_sets"]     # the long-partition kernels did run
+        else:
+            assert a.describe_plan()["conv_long_sets"] == 0
+    assert float(np.abs(outs[1].astype(np.float64) - outs[0]).max()) <= 5e-7
 
 
 def test_partial_blocks_switch_the_multi_block_path_off(gpu_required):

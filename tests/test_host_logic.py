@@ -353,3 +353,96 @@ def test_relocated_programs_in_verify_mode():
         assert bad == 0, (sr, relocated, bad)
         total += relocated
     assert total >= 16 + 48 + 100
+
+
+def test_release_library_carries_no_measurement_hooks():
+    """the wrong-sample hooks (ELEMHIP_EXP_*, the out-of-range chain stores, the persistent chains) and the
+    ELEMHIP_JIT_DEFINES back door exist only in a `make EXPERIMENTAL=1` build: a release library's embedded node-library text
+    (what its run-time compiler sees) has the blocks removed (tools/strip_experimental.py), jit.cpp does not read the variable,
+    `conv_mfma` takes 0 / 1, and the only tunings the compiler accepts are the whitelisted bit-identical ones."""
+    from elementary_amd.runtime import LIB_PATH, ElemHipError
+    data = open(LIB_PATH, "rb").read()
+    for needle in (b"ELEMHIP_EXP_", b"ELEMHIP_JIT_DEFINES", b"ELEMHIP_CHAIN_OOB_STORES", b"ELEMHIP_PERSISTENT_CHAINS", b"ELEMHIP_STREAM_PER_BLOCK"):
+        assert needle not in data, needle
+    assert b"ELEMHIP_SPEC_BLOCK" in data            # (the embedded text is there)
+    rt = Runtime(48000.0, 512, device=-1)
+    rt.set_option("conv_mfma", 2)                    # clamped to 1: the operand-swapped bring-up probe is gone
+    rt.set_option("biquad_form", 1)
+    rt.set_option("biquad_form", 0)
+    with pytest.raises(ElemHipError):
+        rt.set_option("biquad_form", 3)
+    with pytest.raises(ElemHipError):
+        rt.set_option("stream_ring", 0)
+    # and the stripper itself: nested, #elif chains, #else branches
+    import subprocess, sys, tempfile
+    src = "a\n#if defined(ELEMHIP_EXPERIMENTAL) && defined(X)\nbad1\n#elif defined(ELEMHIP_EXPERIMENTAL) && defined(Y)\nbad2\n#else\nkeep1\n#endif\n" \
+          "#ifdef OTHER\nkeep2\n#if defined(ELEMHIP_EXPERIMENTAL) && defined(Z)\nbad3\n#endif\n#else\nkeep3\n#endif\n" \
+          "#if defined(ELEMHIP_EXPERIMENTAL) && defined(A)\nbad4\n#elif FOO\nkeep4\n#else\nkeep5\n#endif\nz\n"
+    with tempfile.NamedTemporaryFile("w", suffix=".inc", delete=False) as f:
+        f.write(src)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "strip_experimental.py"), f.name],
+                         capture_output=True, text=True, check=True).stdout
+    os.unlink(f.name)
+    assert out == "a\nkeep1\n#ifdef OTHER\nkeep2\n#else\nkeep3\n#endif\n#if FOO\nkeep4\n#else\nkeep5\n#endif\nz\n", out
+
+
+def test_kernel_cache_is_bounded_and_one_off_shapes_are_deferred(tmp_path, monkeypatch):
+    """jit.cpp (r05): the in-memory table is capped (entries no plan references are evicted, least recently used first), an entry
+    keeps a few KB of generated text, not the 300 KB translation unit; describe_plan() reports the compiler's books."""
+    rt = Runtime(44100.0, 512, device=-1)
+    rt.set_option("specialize", 2)
+    rt.set_option("jit_cache_entries", 4)
+    x = el.in_({"channel": 0})
+    ops = [el.tanh, el.sin, lambda s: el.mul(0.5, s), lambda s: el.add(0.1, s), el.abs, lambda s: el.pole(0.5, s), el.cos]
+    for k, op in enumerate(ops):        # seven structurally different one-island graphs, one after the other
+        assert rt.render(op(el.lowpass(500.0 + k, 0.7, x)))["result"] == 0
+    p = rt.describe_plan()
+    jit = p["jit"]
+    assert jit["entries"] <= 4 + 2 and jit["evictions"] >= 1, jit
+    assert jit["compiles"] + jit["disk_hits"] >= 7, jit
+    assert jit["text_bytes_held"] <= jit["entries"] * 200_000, jit          # generated text only
+    assert p["shapes"]["total"] >= 1 and p["shapes"]["ready"] == p["shapes"]["total"]
+    assert 0.0 <= p["interp_block_fraction"] <= 1.0
+    rt.set_option("jit_cache_entries", 0)
+
+
+def test_fft4096_core_on_the_host():
+    """elementary_amd/csrc/fft4096.h (the transform core of the long-partition convolver, conv_long.inc) compiled for the HOST:
+    256 emulated threads, forward / inverse real transforms of 8192 samples against a double-precision DFT and one overlap-save
+    convolution step against the direct sum."""
+    import json
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = "/opt/rocm/lib/llvm/bin/clang++" if os.path.exists("/opt/rocm/lib/llvm/bin/clang++") else shutil.which("clang++")
+    if not cxx:
+        pytest.skip("needs clang++ (ext_vector_type)")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "fft4096_host")
+        subprocess.run([cxx, "-std=c++17", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "elementary_amd", "csrc"),
+                        os.path.join(root, "tests", "native", "fft4096_host.cpp"), "-o", exe], check=True)
+        res = subprocess.run([exe], capture_output=True, text=True)
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert res.returncode == 0 and out["ok"], out
+    assert out["overlap_save_max_err"] <= 5e-7 and out["roundtrip_max_err"] <= 2e-6, out
+
+
+def test_rccl_exchange_snippet_compiles_and_links():
+    """INTEGRATION.md §6 / north_star "RCCL over xGMI only for the final output-bus reduce": the documented exchange step (RCCL
+    send / recv to rank 0 + elemhip_sum_buses in rank order, and the ncclReduce alternative) as a translation unit compiled and
+    linked against librccl and libelemhip. Not run: no multi-GPU node is available to the builder."""
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = "/opt/rocm/lib/llvm/bin/clang++" if os.path.exists("/opt/rocm/lib/llvm/bin/clang++") else shutil.which("hipcc")
+    if not cxx or not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("needs the ROCm toolchain and the RCCL headers")
+    with tempfile.TemporaryDirectory() as d:
+        res = subprocess.run([cxx, "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                              os.path.join(root, "tests", "native", "rccl_bus_sum.cpp"), "-L" + os.path.join(root, "elementary_amd"), "-lelemhip",
+                              "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-o", os.path.join(d, "rccl_bus_sum")],
+                             capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert os.path.getsize(os.path.join(d, "rccl_bus_sum")) > 1000

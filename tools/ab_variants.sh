@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (r05): ELEMHIP_JIT_DEFINES and the ELEMHIP_EXP_* / *_CHAINS hooks exist only in a library built with `make -C elementary_amd/csrc EXPERIMENTAL=1`.
 # Run ON THE GPU BOX: bench + per-wave busy trace of the C2 voice kernel for a list of JIT-define / option variants.
 # usage: tools/ab_variants.sh outdir "DEFINES|opt1=v opt2=v" ...
 out=$1; shift; mkdir -p $out

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (r05): ELEMHIP_JIT_DEFINES and the ELEMHIP_EXP_* / *_CHAINS hooks exist only in a library built with `make -C elementary_amd/csrc EXPERIMENTAL=1`.
 # Cost of polling without s_wakeup (island_ops.inc ELEMHIP_WAKE): the C2 and C4 benches for several poll periods, and the old
 # ping-and-sleep-8 protocol for comparison (measurement only: it is the one that corrupts other waves' wait states).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
