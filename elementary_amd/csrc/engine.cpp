@@ -120,11 +120,14 @@ TablePool::~TablePool() { for (DevBuf& b : free) (void)hipFree(b.ptr); }
 // ---------------------------------------------------------------------------------------------
 Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), device(dev) {
     auto fail = [&](int code) { initErr = code; };
-    // A block's buffers are LDS slots of kMaxBlock frames. A host block that is a multiple of that is rendered as slices of
-    // kMaxBlock frames (the sample-rate nodes cannot tell; taps, whose delay IS the block, are refused at commit): the engine's
-    // own block size is the slice, the host's the limit of a process() call.
+    // A block's buffers are LDS slots of at most kMaxBlock frames. A longer host block is rendered as k equal slices — the smallest k
+    // that divides it into slices of 64 .. kMaxBlock frames (1024 -> 2 x 512, 700 -> 2 x 350, 1023 -> 3 x 341; r04 took multiples of
+    // 512 only) — the sample-rate nodes cannot tell; taps, whose delay IS the block, are refused at commit: the engine's own block size
+    // is the slice, the host's the limit of a process() call. A size no such k divides (a prime above 512) is refused.
     hostBlockSize = bs;
-    if (bs > (int)kMaxBlock && bs % (int)kMaxBlock == 0 && bs <= 64 * (int)kMaxBlock) { bs = (int)kMaxBlock; blockSize = bs; }
+    if (bs > (int)kMaxBlock && bs <= 64 * (int)kMaxBlock)
+        for (int k = (bs + (int)kMaxBlock - 1) / (int)kMaxBlock; k <= bs / 64; ++k)
+            if (bs % k == 0) { bs /= k; blockSize = bs; break; }
     if (const char* e = std::getenv("ELEMHIP_SPECIALIZE")) specialize = std::max(0, std::min(2, std::atoi(e)));
     if (const char* e = std::getenv("ELEMHIP_PLAN_CACHE")) planCache = std::max(0, std::min(2, std::atoi(e)));   // 2: verify mode (tests)
     if (bs <= 0 || bs > (int)kMaxBlock) { fail(kBlockTooLarge); return; }

@@ -22,11 +22,12 @@
  * when no gfx950 device is usable.
  *
  * Block size: the reference sizes its buffers to any blockSize (Runtime.h:44); this engine keeps a
- * block's buffers in LDS slots of 512 frames. blockSize <= 512: as given. A MULTIPLE of 512 (1024, 2048 ... 32768): accepted,
- * elemhip_process / elemhip_process_blocks_host render such a block as slices of 512 frames — the same samples for every node
- * that works at the sample rate; a graph with tapIn / tapOut (whose delay IS the block, Feedback.h:90-126) is refused at commit
- * (code 104), `meter` reports the last 512 frames of a block, and the device-resident elemhip_process_blocks (whose layout is in
- * blocks) answers 102. Any other size above 512: elemhip_create fails (code 102).
+ * block's buffers in LDS slots of at most 512 frames. blockSize <= 512: as given. Above 512 (up to 32768): accepted when the block
+ * splits into k EQUAL slices of 64 .. 512 frames (1024 = 2 x 512, 700 = 2 x 350, 1023 = 3 x 341; the smallest such k is taken):
+ * elemhip_process / elemhip_process_blocks_host render such a block slice by slice — the same samples for every node that works at
+ * the sample rate; a graph with tapIn / tapOut (whose delay IS the block, Feedback.h:90-126) is refused at commit (code 104),
+ * `meter` reports the last slice of a block, and the device-resident elemhip_process_blocks (whose layout is in blocks) answers
+ * 102. A size above 512 that no such k divides (a prime): elemhip_create fails (code 102).
  */
 #ifndef ELEMHIP_H
 #define ELEMHIP_H

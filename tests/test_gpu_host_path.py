@@ -232,7 +232,7 @@ def test_cli_benchmark_host(gpu_required):
     assert float(np.abs(got - ref).max()) <= TOL
 
 
-@pytest.mark.parametrize("bs", [1024, 2048])
+@pytest.mark.parametrize("bs", [1024, 2048, 700, 1023])
 def test_host_blocks_longer_than_512_frames(gpu_required, bs):
     """Runtime(sr, blockSize > 512) (the reference has no limit, Runtime.h:44): a block that is a multiple of 512 frames is rendered
     as slices of 512. elemhip_process with full and short blocks and elemhip_process_blocks_host (whole HOST blocks: the state
@@ -245,7 +245,8 @@ def test_host_blocks_longer_than_512_frames(gpu_required, bs):
         a.set_option("specialize", 2)
         assert a.render(*roots_fn())["result"] == 0 and c.render(*roots_fn())["result"] == 0
         worst, k = 0.0, 0
-        for n in (bs, bs, 1500 if bs == 2048 else 700, bs, 512, bs):          # process(): full, short and one-slice calls
+        # (r05: any size that splits into equal slices of 64 .. 512 frames: 700 -> 2 x 350, 1023 -> 3 x 341)
+        for n in (bs, bs, bs * 2 // 3 + 1, bs, min(512, bs - 1), bs):          # process(): full, short and one-slice calls
             x = np.stack([lcg_noise(n, 7 + k, 0.5)]) if n_in else None
             got, ref = a.process(x, n_out, n), c.process(x, n_out, n)
             assert got.shape == ref.shape == (n_out, n)
@@ -267,4 +268,5 @@ def test_host_blocks_longer_than_512_frames(gpu_required, bs):
         assert float(np.abs(got - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
         with pytest.raises(ElemHipError):
             a.process_blocks(2, n_out)
-        assert a.stats()["spec_launches"] > 0
+        if bs % 512 == 0:                      # (slices that are no multiple of 64 frames render through the interpreter kernels: plan.cpp specIsland)
+            assert a.stats()["spec_launches"] > 0

@@ -305,17 +305,18 @@ def test_island_program_cache_reuses_unchanged_islands():
 
 
 def test_block_sizes_above_one_lds_slot():
-    """Runtime(sr, blockSize) (Runtime.h:44): up to 512 frames as given; a multiple of 512 is accepted (rendered in slices of 512),
-    a graph with taps — whose loop delay is the host's block — is then refused at commit; any other size above 512 fails at creation."""
+    """Runtime(sr, blockSize) (Runtime.h:44): up to 512 frames as given; above that, a size that splits into k equal slices of 64 .. 512
+    frames is accepted (rendered slice by slice; r04: multiples of 512 only), a graph with taps — whose loop delay is the host's
+    block — is then refused at commit; a size no such k divides (a prime) or above 32768 fails at creation."""
     from elementary_amd.runtime import ElemHipError
-    for bs in (1024, 2048, 32768):
+    for bs in (1024, 2048, 32768, 700, 1000, 1023, 514):
         rt = dry(48000.0, bs)
         assert rt.block_size == bs
         assert rt.render(el.mul(0.5, el.cycle(220.0)))["result"] == 0
         loop = el.tapOut({"name": "fb"}, el.add(el.in_({"channel": 0}), el.mul(0.5, el.tapIn({"name": "fb"}))))
         assert rt.render(loop)["result"] == 104                      # UnsupportedGraph
         assert rt.render(el.mul(0.25, el.cycle(330.0)))["result"] == 0  # and the runtime goes on
-    for bs in (513, 700, 1000, 512 * 65):
+    for bs in (521, 1031, 512 * 65):              # 521 and 1031 are primes
         with pytest.raises(ElemHipError):
             dry(48000.0, bs)
     ok = dry(48000.0, 512)
@@ -386,24 +387,38 @@ def test_release_library_carries_no_measurement_hooks():
     assert out == "a\nkeep1\n#ifdef OTHER\nkeep2\n#else\nkeep3\n#endif\n#if FOO\nkeep4\n#else\nkeep5\n#endif\nz\n", out
 
 
-def test_kernel_cache_is_bounded_and_one_off_shapes_are_deferred(tmp_path, monkeypatch):
+def test_kernel_cache_is_bounded_and_one_off_shapes_are_deferred():
     """jit.cpp (r05): the in-memory table is capped (entries no plan references are evicted, least recently used first), an entry
-    keeps a few KB of generated text, not the 300 KB translation unit; describe_plan() reports the compiler's books."""
-    rt = Runtime(44100.0, 512, device=-1)
-    rt.set_option("specialize", 2)
-    rt.set_option("jit_cache_entries", 4)
-    x = el.in_({"channel": 0})
-    ops = [el.tanh, el.sin, lambda s: el.mul(0.5, s), lambda s: el.add(0.1, s), el.abs, lambda s: el.pole(0.5, s), el.cos]
-    for k, op in enumerate(ops):        # seven structurally different one-island graphs, one after the other
-        assert rt.render(op(el.lowpass(500.0 + k, 0.7, x)))["result"] == 0
-    p = rt.describe_plan()
+    keeps a few KB of generated text, not the 300 KB translation unit; describe_plan() reports the compiler's books. (In a process
+    of its own: the table is process-wide, and this suite's other engines leave entries behind.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import json, sys
+sys.path.insert(0, %r)
+import torch
+from elementary_amd import el
+from elementary_amd.runtime import Runtime
+rt = Runtime(44100.0, 512, device=-1)
+rt.set_option("specialize", 2)
+rt.set_option("jit_cache_entries", 4)
+x = el.in_({"channel": 0})
+ops = [el.tanh, el.sin, lambda s: el.mul(0.5, s), lambda s: el.add(0.1, s), el.abs, lambda s: el.pole(0.5, s), el.cos]
+for k, op in enumerate(ops):        # seven structurally different one-island graphs, one after the other
+    assert rt.render(op(el.lowpass(500.0 + k, 0.7, x)))["result"] == 0
+print(json.dumps(rt.describe_plan()))
+""" % root
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    p = json.loads(res.stdout.strip().splitlines()[-1])
     jit = p["jit"]
     assert jit["entries"] <= 4 + 2 and jit["evictions"] >= 1, jit
     assert jit["compiles"] + jit["disk_hits"] >= 7, jit
     assert jit["text_bytes_held"] <= jit["entries"] * 200_000, jit          # generated text only
     assert p["shapes"]["total"] >= 1 and p["shapes"]["ready"] == p["shapes"]["total"]
     assert 0.0 <= p["interp_block_fraction"] <= 1.0
-    rt.set_option("jit_cache_entries", 0)
 
 
 def test_fft4096_core_on_the_host():
