@@ -222,7 +222,7 @@ def run_configs(names, timeout_s: float):
     t_all = time.perf_counter()
     for name in names:
         if name == "c4":
-            cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c4", "--steps", "16", "--warmup", "4"]
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c4", "--steps", "64", "--warmup", "8"]
         else:
             cmd = [sys.executable, os.path.join(ROOT, "benchmarks", "driver_configs.py"), name]
         t0 = time.perf_counter()

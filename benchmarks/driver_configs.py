@@ -455,9 +455,6 @@ def c5(commits: int = 520, blocks_after: int = 8, rate: float = 28.0, churn: boo
     voices = 128
     free_batches = int(seconds * rate) + 8
     texts, creates, sizes = _c5_batches(voices, commits + free_batches, churn=churn)
-    ctx = mp.get_context("spawn")
-    pool = ctx.Pool(1)
-    ref_job = pool.apply_async(_c5_reference_worker, ((texts[:commits + 1], commits, blocks_after),))
     rt = Runtime(graphs.C2_SAMPLE_RATE, BLOCK, device=0)
     rt.set_option("specialize", 1)               # a live graph never waits for a compiler: background compilation, the product default
     counted, got = _c5_counted(rt, texts, commits, blocks_after, rate)
@@ -467,8 +464,11 @@ def c5(commits: int = 520, blocks_after: int = 8, rate: float = 28.0, churn: boo
     free = _c5_free_running(rt, texts, lambda k: rt.process_blocks(k, 2, out_ptr=out.data_ptr()), seconds, rate, first=commits + 1)
     st = rt.stats()
     plan = rt.describe_plan()
-    ref_stats, ref_out, kind = ref_job.get(timeout=600)
-    pool.close()
+    # the reference engine through the same schedule AFTER the GPU legs (a latency measurement: nothing else of this script runs
+    # beside either engine), in a process of its own
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(1) as pool:
+        ref_stats, ref_out, kind = pool.apply(_c5_reference_worker, ((texts[:commits + 1], commits, blocks_after),))
     parity = _parity(got, ref_out, f"every block of the counted leg ({got.shape[0]} blocks: 48 settling + {commits} commits x {blocks_after} synchronous blocks, gc every 16 commits) "
                                    f"vs the {kind} engine driven through the same instruction batches on the same block schedule")
     # where the samples first differ, if they do (a diagnostic worth more than a bare `false`)

@@ -798,8 +798,18 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
         hipLaunchKernelGGL(elemhip_convolve_long_mac, dim3(numNodes, (lfft::kBins + 255u) / 256u, (chunks + kLongRun - 1u) / kLongRun), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
         hipLaunchKernelGGL(elemhip_convolve_long_ifft, dim3(numNodes, chunks), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
         hipLaunchKernelGGL(elemhip_convolve_long_state, dim3(numNodes, longStateBlocks < batch ? longStateBlocks : batch), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longMode, perNode);
-        hipLaunchKernelGGL(elemhip_convolve_long_tail, dim3(numNodes), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longMode, perNode);
+        hipLaunchKernelGGL(elemhip_convolve_long_tail, dim3(numNodes), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, 0u, perNode);
     }
+}
+
+// before the next 512-partition evaluation (a block-at-a-time launch, a set that does not take the long partitions) of convolve nodes
+// a long-partition set rendered last: their overlap (conv_long.inc, elemhip_convolve_long_tail mode 1). `numWork` entries of the
+// plan's conv work list from `workBegin` on are looked at; helper entries and nodes whose overlap is current return at once.
+void launch_convolve_fix_overlap(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
+                                 uint32_t numWork, float* scratch, uint32_t maxBatch, uint32_t longHistRows) {
+    if (!numWork) return;
+    const size_t perNode = convolve_batch_scratch_floats(maxBatch, longHistRows);
+    hipLaunchKernelGGL(elemhip_convolve_long_tail, dim3(numWork), dim3(256), 0, s, pv, recs, hbm, g, workBegin, 0u, scratch, maxBatch, 0u, 1u, perNode);
 }
 
 uint32_t convolve_long_tap_group() { return kLongTaps; }

@@ -17,6 +17,10 @@
 #include <stdint.h>
 #endif
 
+#ifndef __HIPCC_RTC__
+#include "conv_state.h"     // namespace conv: the convolve node's state layout (not part of the run-time compiled text)
+#endif
+
 namespace elemhip {
 
 enum : uint32_t {
@@ -181,24 +185,6 @@ struct ConvDesc {
     uint32_t fuseRootRec; // kNone, or the record of a root folded into this node: its fade is applied here (Core.h:66-78)
     uint32_t pad_;
 };
-
-// Convolver state: one device allocation per `path` assignment, zero-initialised except H.
-//   header[16] | H[P][512] float2 | X[P][512] float2 | pre[2][S][512] float2 | preSlow[512] float2 | inbuf[512] | overlap[512]
-// Spectra are 1024-point real-FFT bins 0..511 with the (real) Nyquist bin packed into bin 0's imaginary part.
-namespace conv {
-enum : uint32_t {
-    kBlock = 512, kFft = 1024, kBinGroups = 8, kMaxSlices = 8, kSlicePartitions = 96,
-    H_P = 0,            // partitions = ceil(trimmed IR length / 512)
-    H_S = 1,            // partial-sum slices the helpers produce
-    H_FILL = 2, H_BLK = 3,             // frames already in the current input block / index of that block
-    H_FILL_NEXT = 4, H_BLK_NEXT = 5,   // written by the node's main workgroup, committed by the epilogue
-    H_PREVALID0 = 6,    // [2]: block index whose older-partition sum pre[i] holds
-    H_PRESLOW_FOR = 8,  // block index preSlow holds (only when a call straddles two input blocks)
-    H_Q = 9,            // long partitions (4096 samples) of the IR, 0: the node has no long-partition spectra (conv_long.inc)
-    H_HISTBLKS = 10,    // blocks of the time-domain input ring behind `overlap` (0: none)
-    kHeaderDwords = 16,
-};
-}
 
 struct TapEntry {
     uint32_t rec;        // tapOut record: p0/p1 shared tap buffer ptr, p2/p3 private delay buffer ptr

@@ -1185,6 +1185,9 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
             if (nit == nodes.end() || rit == nodes.end()) continue;
             auto a = rit->second.props.find("active");                       // GraphRenderSequence.h:192
             if (a == rit->second.props.end() || !a->second.isBool() || !a->second.b) continue;
+            bool seen = false;                                              // (an mc.* node is one plan entry per output channel: relayed once)
+            for (const Item& it : items) if (it.n == &nit->second) { seen = true; break; }
+            if (seen) continue;
             items.push_back({&nit->second, items.size() * kRecDwords * 4, order++});
         }
         blocksNow = st.blocksRendered;
@@ -1315,6 +1318,10 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
         const uint32_t count = rc_[rec::EVT_COUNT];
         float fa, fb; std::memcpy(&fa, &rc_[rec::EVT_A], 4); std::memcpy(&fb, &rc_[rec::EVT_B], 4);
         const uint32_t lmask = shadow[(size_t)n.rec * kRecDwords + rec::EVT_LOGMASK], lcap = lmask + 1u;
+        // The reference's readout queue (SingleWriterSingleReaderQueue.h, capacity 32) cannot tell "32 x k pushes since the last relay"
+        // from "none": its write position is back on the read position, size() answers 0 and processEvents reports nothing — a meter
+        // polled every 32nd block, a snapshot that latches exactly 32 times per block (a 3 kHz train at 48 kHz and 512 frames). Kept.
+        auto wrapsToEmpty = [](uint32_t pushes) { return pushes != 0u && (pushes & 31u) == 0u; };
         if (n.op == OP_METER) {                                           // Analyzers.h:23-62
             const uint32_t fresh = count - n.eventCount;
             if (!fresh) continue;
@@ -1327,7 +1334,7 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
                     float mn, mx; std::memcpy(&mn, &e[4 * k + 1], 4); std::memcpy(&mx, &e[4 * k + 2], 4);
                     evs.push_back({blockOf(take - 1 - k), it.order, "meter", "{\"min\": " + numStr(mn) + ", \"max\": " + numStr(mx) + ", \"source\": " + src + "}"});
                 }
-            } else evs.push_back({lastBlock, it.order, "meter", "{\"min\": " + numStr(fa) + ", \"max\": " + numStr(fb) + ", \"source\": " + srcOf(n) + "}"});
+            } else if (!wrapsToEmpty(fresh)) evs.push_back({lastBlock, it.order, "meter", "{\"min\": " + numStr(fa) + ", \"max\": " + numStr(fb) + ", \"source\": " + srcOf(n) + "}"});
             n.eventCount = count;
         } else {                                                          // Analyzers.h:83-131
             const uint32_t blk = rc_[rec::EVT_BLK], logn = rc_[rec::EVT_LOGN];
@@ -1340,9 +1347,10 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
                 const std::string src = srcOf(n);
                 for (uint32_t k = 0; k < take; ++k) {
                     float v; std::memcpy(&v, &e[4 * k + 1], 4);
+                    if (wrapsToEmpty(e[4 * k + 2])) continue;             // (per-block relay: the pushes of that block alone)
                     evs.push_back({blockOf((uint64_t)(blk - 1u - e[4 * k])), it.order, "snapshot", "{\"source\": " + src + ", \"data\": " + numStr(v) + "}"});
                 }
-            } else evs.push_back({lastBlock, it.order, "snapshot", "{\"source\": " + srcOf(n) + ", \"data\": " + numStr(fb) + "}"});
+            } else if (!wrapsToEmpty(count - n.eventCount)) evs.push_back({lastBlock, it.order, "snapshot", "{\"source\": " + srcOf(n) + ", \"data\": " + numStr(fb) + "}"});
             n.eventCount = count; n.logRelayed = logn;
         }
     }
@@ -1375,6 +1383,9 @@ uint32_t Engine::eventWindowBlocks() {
         if (n.op == OP_SCOPE) {
             auto q = n.props.find("size");
             const double size = (q != n.props.end() && q->second.isNumber()) ? q->second.num : 512.0;
+            // a scope whose `size` is below the block hands on less per relay than a block brings: its ring overruns under a per-block
+            // relay too, and where it does depends on every single relay — only a relay per block reproduces that
+            if (size < (double)blockSize) return 1u;
             const double room = 8192.0 - 1.0 - std::max(1.0, size);
             w = std::min<uint32_t>(w, (uint32_t)std::max(1.0, std::floor(room / (double)blockSize)));
         }
@@ -1878,7 +1889,7 @@ int Engine::processSliceLocked(const float* const* in, size_t nIn, float* const*
         st.specLaunches += p.specGraphLaunches; st.graphReplays++;
     } else if (specBlock) enqueueBatch(p, 1u, outDev);
     else if (specFade) enqueueSpecBlock(p, outDev);
-    else enqueueBlock(p, outDev);
+    else { fixConvOverlaps(p); enqueueBlock(p, outDev); }
     if (nOut > 0 && !outDev) HIP_OK(hipMemcpyAsync(hOut, dOutRing, nOut * (size_t)blockSize * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     HIP_OK(hipGetLastError());
@@ -1924,6 +1935,7 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
         rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize * batch); if (rc != kOk) return -rc;
     }
     lastTimeBatch = batch;
+    fixConvOverlaps(p);
     for (size_t b = 0; b < numBlocks; ++b) {
         for (size_t l = 0; l < L; ++l) {
             const uint32_t lb = p.levelOffsets[l], le = p.levelOffsets[l + 1];
@@ -2208,9 +2220,18 @@ void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32
         stateBlocks = std::max(stateBlocks, std::max(it->second.convHistBlocks, it->second.convP));
     }
     const uint32_t longRows = (convLong && convMaxQp) ? convMaxQp - 1u : 0u;
-    if (longRows && batch >= 8u && (batch & 7u) == 0u && stateBlocks > 1u) convLongSets++;
+    const bool longSet = longRows && batch >= 8u && (batch & 7u) == 0u;
+    if (longSet && stateBlocks > 1u) { convLongSets++; convOverlapStale = true; }
+    if (!longSet) fixConvOverlaps(p);
     launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks, (uint32_t)convMfma,
                           convMinP <= convolve_mfma_max_partitions(), convMaxP > convolve_mfma_max_partitions(), longRows, anyShortPath, stateBlocks);
+}
+
+void Engine::fixConvOverlaps(const Plan& p) {
+    if (!convOverlapStale || p.convs.empty() || !dConvScratch) return;
+    launch_convolve_fix_overlap(stream, p.view, dRecs, dHbm, dGlobals, 0u, (uint32_t)p.convWork.size(), dConvScratch, (uint32_t)batchBlocks,
+                                (convLong && convMaxQp) ? convMaxQp - 1u : 0u);
+    convOverlapStale = false;
 }
 
 void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
@@ -2354,6 +2375,7 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
         if (haveIn) HIP_OK(hipMemcpyAsync(dHbm, inDev + done * nIn * bs, nIn * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
         rc = flushPending();
         if (rc != kOk) return rc;
+        fixConvOverlaps(p);      // (convolve nodes a long-partition set rendered last: their overlap, before block-at-a-time launches read it)
         // (a plan is captured at its third block-at-a-time chunk: a live graph's plan renders the two blocks of its root fades this
         //  way, then launch sets take over and the next commit replaces it — a capture would be made and thrown away every time)
         if (graphOk && chunk == G && (p.graphExec || ++p.blockChunks > 2u)) {

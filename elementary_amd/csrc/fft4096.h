@@ -73,14 +73,25 @@ LFFT_FD void pass_read(const c2* buf, uint32_t tid, c2 (&v)[16]) {
 #pragma unroll
     for (uint32_t r = 0; r < 16; ++r) v[r] = buf[pad(tid + kThreads * r)];
 }
-// v[r] *= exp(-2 pi i r k / (16 Ns)), k = tid mod Ns
-template <class WP>
-LFFT_FD void pass_twiddle(c2 (&v)[16], uint32_t tid, uint32_t s, WP W) {
+// v[r] *= exp(-2 pi i r k / (16 Ns)), k = tid mod Ns. The factors come from three small tables (LDS on the device: 3 KB; the first
+// build read them from the 8192-entry table in global memory, 15 scattered 8-byte loads per thread and pass):
+//   pass 1 (Ns = 16):  exp(-2 pi i j / 256),  j = r k <= 225            -> T256[j]
+//   pass 2 (Ns = 256): exp(-2 pi i j / 4096), j = r k <= 3825 = 64 h + l -> A64[h] * B64[l]   (one extra rounding: ~1e-7 relative)
+constexpr uint32_t kTabT = 0, kTabA = 256, kTabB = 320, kTabSize = 384;
+// table entry i (0 .. kTabSize) as an index into the 8192-entry table w^j
+LFFT_FD uint32_t tab_source(uint32_t i) { return i < kTabA ? 32u * i : (i < kTabB ? 128u * (i - kTabA) : 2u * (i - kTabB)); }
+template <class TP>
+LFFT_FD void pass_twiddle(c2 (&v)[16], uint32_t tid, uint32_t s, TP tab) {
     if (s == 0u) return;
-    const uint32_t Ns = s == 1u ? 16u : 256u, k = tid & (Ns - 1u);
-    const uint32_t unit = (s == 1u ? 32u : 2u) * k;           // table index of exp(-2 pi i k / (16 Ns)) in the 8192-entry table
+    if (s == 1u) {
+        const uint32_t k = tid & 15u;
 #pragma unroll
-    for (uint32_t r = 1; r < 16; ++r) { const c2 t = W[unit * r]; v[r] = cmul(v[r], t); }
+        for (uint32_t r = 1; r < 16; ++r) v[r] = cmul(v[r], tab[kTabT + r * k]);
+    } else {
+        const uint32_t k = tid & 255u;
+#pragma unroll
+        for (uint32_t r = 1; r < 16; ++r) { const uint32_t j = r * k; v[r] = cmul(v[r], cmul(tab[kTabA + (j >> 6)], tab[kTabB + (j & 63u)])); }
+    }
 }
 LFFT_FD void pass_write(c2* buf, uint32_t tid, uint32_t s, const c2 (&v)[16]) {
     const uint32_t Ns = s == 0u ? 1u : (s == 1u ? 16u : 256u), k = tid & (Ns - 1u);

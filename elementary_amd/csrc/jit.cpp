@@ -21,6 +21,8 @@
 #include <dirent.h>
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <spawn.h>
+#include <sys/wait.h>
 #include <hip/hiprtc.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -28,6 +30,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -88,6 +91,7 @@ struct Jit::Impl {
     std::string cacheDir;
     std::string versionTag;
     bool keepSource = false;
+    std::string helper;                     // elemhip_jitc next to the library: one compiler process per worker ("" = compile in-process)
     uint32_t entryCap = 256;
     uint64_t diskCapBytes = 512ull << 20;
     int64_t diskBytes = -1;                 // -1: not scanned yet
@@ -110,10 +114,19 @@ struct Jit::Impl {
 #endif
         unsigned n = std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 4u));   // a plan of a new graph brings several shapes at once
         if (const char* t = std::getenv("ELEMHIP_JIT_THREADS")) n = (unsigned)std::max(1, std::atoi(t));
+        // hiprtc serialises compilations inside a process (jitc_main.cpp): the workers hand their shapes to a helper process each
+        // (elemhip_jitc next to the library; ELEMHIP_JIT_INPROCESS=1 or a missing helper: the in-process compiler, one at a time)
+        {
+            const char* inproc = std::getenv("ELEMHIP_JIT_INPROCESS");
+            const std::string h = libraryDir() + "/elemhip_jitc";
+            if (!(inproc && std::atoi(inproc) != 0) && ::access(h.c_str(), X_OK) == 0) helper = h;
+        }
         // The compiler library (comgr) is loaded lazily by the first hiprtc compile and registers its static destructors
         // then. Do that first compile here, on the calling thread (~45 ms, once per process), and register the exit hook
         // right after it: the hook then runs BEFORE those destructors whenever the process exits, however early.
-        warmUp();
+        // (With the helper the compiler never runs in this process: only the exit hook that stops the workers is registered.)
+        if (helper.empty()) warmUp();
+        else std::atexit([] { if (Impl* i = exitHookTarget) i->shutdown(); });
         for (unsigned i = 0; i < n; ++i) workers.emplace_back([this] { run(); });
     }
     ~Impl() { shutdown(); }
@@ -208,6 +221,44 @@ struct Jit::Impl {
         // the 300 KB translation unit lives for the duration of the compile only (ELEMHIP_JIT_KEEP_SOURCE=1: it stays in the entry)
         const std::string src = Jit::fullSource(e.generated, e.ldsWords, e.block);
         if (keepSource) { std::lock_guard<std::mutex> l(e.mu); e.source = src; }
+        if (!helper.empty()) {
+            // out of process: source -> <key>.<pid>.src, the helper writes <key>.<pid>.tmp (+ its log), renamed into place on success
+            (void)mkdir(cacheDir.c_str(), 0755);
+            const std::string stem = cacheDir + "/" + e.key + "." + std::to_string((long)getpid());
+            const std::string srcPath = stem + ".src", outPath = stem + ".tmp", logPath = stem + ".log";
+            bool ok = false;
+            { std::ofstream sf(srcPath, std::ios::binary); if (sf) { sf.write(src.data(), (std::streamsize)src.size()); ok = (bool)sf; } }
+            int status = -1;
+            if (ok) {
+                posix_spawn_file_actions_t fa;
+                posix_spawn_file_actions_init(&fa);
+                posix_spawn_file_actions_addopen(&fa, 2, logPath.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+                posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0644);
+                char* const argv[] = {const_cast<char*>(helper.c_str()), const_cast<char*>(srcPath.c_str()), const_cast<char*>(outPath.c_str()), nullptr};
+                pid_t pid = 0;
+                if (posix_spawn(&pid, helper.c_str(), &fa, nullptr, argv, ::environ) == 0) { while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {} }
+                posix_spawn_file_actions_destroy(&fa);
+            }
+            { std::ifstream lf(logPath, std::ios::binary); if (lf) e.log.assign((std::istreambuf_iterator<char>(lf)), std::istreambuf_iterator<char>()); }
+            (void)std::remove(srcPath.c_str()); (void)std::remove(logPath.c_str());
+            if (ok && WIFEXITED(status) && WEXITSTATUS(status) == 0) {
+                std::ifstream cf(outPath, std::ios::binary);
+                std::vector<char> code((std::istreambuf_iterator<char>(cf)), std::istreambuf_iterator<char>());
+                if (code.size() > 64) {
+                    e.code.swap(code);
+                    e.compileMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    const bool written = std::rename(outPath.c_str(), path.c_str()) == 0;
+                    if (!written) (void)std::remove(outPath.c_str());
+                    e.state.store(1, std::memory_order_release);
+                    if (written) trimDisk((int64_t)e.code.size());
+                    return;
+                }
+            }
+            (void)std::remove(outPath.c_str());
+            std::fprintf(stderr, "[elemhip] jit: compilation of shape %s failed (helper status %d):\n%.3000s\n", e.key.c_str(), status, e.log.c_str());
+            e.state.store(-1, std::memory_order_release);
+            return;
+        }
         hiprtcProgram prog = nullptr;
         if (hiprtcCreateProgram(&prog, src.c_str(), "elemhip_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
             e.log = "hiprtcCreateProgram failed"; e.state.store(-1, std::memory_order_release); return;
@@ -275,6 +326,21 @@ struct Jit::Impl {
         std::lock_guard<std::mutex> l(mu);
         diskBytes = total; st.diskBytes = (uint64_t)total; st.diskFilesRemoved += removed;
         if (removed) notOnDisk.clear();
+    }
+
+    // (mu held) a backed-up plan queue is swept for requests nobody waits for any more — the voice was replaced before a worker got to
+    // its shape: they would only be dropped when their turn came, and until then they sit in the table above its cap
+    void sweep(const std::shared_ptr<SpecEntry>& keep) {
+        if (queue.size() <= std::max<size_t>(16, 2 * workers.size())) return;
+        for (auto q = queue.begin(); q != queue.end();) {
+            if (q->use_count() <= 2 && *q != keep) {
+                (*q)->state.store(-2, std::memory_order_release);
+                auto m = entries.find((*q)->key);
+                if (m != entries.end() && m->second == *q) entries.erase(m);
+                st.abandoned++;
+                q = queue.erase(q);
+            } else ++q;
+        }
     }
 
     // (mu held) the table stays under its cap: entries nobody references (no plan, no queue) go, least recently used first
@@ -419,18 +485,7 @@ std::shared_ptr<SpecEntry> Jit::requestKey(const std::string& key, const std::st
             if (deferred) impl->st.deferred++;
             else {
                 impl->queue.push_back(e); impl->st.queued++;
-                // a backed-up queue is swept for requests nobody waits for (they would only be dropped when their turn came)
-                if (impl->queue.size() > 64) {
-                    for (auto q = impl->queue.begin(); q != impl->queue.end();) {
-                        if (q->use_count() <= 2 && *q != e) {
-                            (*q)->state.store(-2, std::memory_order_release);
-                            auto m = impl->entries.find((*q)->key);
-                            if (m != impl->entries.end() && m->second == *q) impl->entries.erase(m);
-                            impl->st.abandoned++;
-                            q = impl->queue.erase(q);
-                        } else ++q;
-                    }
-                }
+                impl->sweep(e);
                 impl->cv.notify_one();
             }
             impl->evict();
@@ -446,8 +501,21 @@ void Jit::promote(const std::shared_ptr<SpecEntry>& e, bool urgent) {
     int expect = 2;
     if (!e->state.compare_exchange_strong(expect, 0, std::memory_order_acq_rel)) return;
     std::lock_guard<std::mutex> l(impl->mu);
-    if (urgent) { impl->queue.push_back(e); impl->st.queued++; }
-    else { impl->lowQueue.push_back(e); impl->st.promoted++; }
+    if (urgent) { impl->queue.push_back(e); impl->st.queued++; impl->sweep(e); impl->evict(); }
+    else {
+        impl->lowQueue.push_back(e); impl->st.promoted++;
+        // (promoted one-off shapes whose plans are gone by now: same sweep, the low queue is only served when the plan queue is empty)
+        if (impl->lowQueue.size() > 32)
+            for (auto q = impl->lowQueue.begin(); q != impl->lowQueue.end();) {
+                if (q->use_count() <= 2 && *q != e) {
+                    (*q)->state.store(-2, std::memory_order_release);
+                    auto m = impl->entries.find((*q)->key);
+                    if (m != impl->entries.end() && m->second == *q) impl->entries.erase(m);
+                    impl->st.abandoned++;
+                    q = impl->lowQueue.erase(q);
+                } else ++q;
+            }
+    }
     impl->cv.notify_one();
 }
 

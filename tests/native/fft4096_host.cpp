@@ -14,7 +14,7 @@
 using namespace lfft;
 typedef std::complex<double> cd;
 
-static std::vector<c2> gW;
+static std::vector<c2> gW, gTab;
 
 static void fft4096_emulated(std::vector<c2>& buf) {           // buf: padded, holds the input at pad(i); the result lands the same way
     std::vector<c2> regs(256 * 16);
@@ -22,7 +22,7 @@ static void fft4096_emulated(std::vector<c2>& buf) {           // buf: padded, h
         for (uint32_t tid = 0; tid < 256; ++tid) {
             c2 v[16];
             pass_read(buf.data(), tid, v);
-            pass_twiddle(v, tid, s, gW.data());
+            pass_twiddle(v, tid, s, gTab.data());
             dft16(v);
             for (int r = 0; r < 16; ++r) regs[tid * 16 + r] = v[r];
         }
@@ -62,6 +62,8 @@ static void real_inverse(const std::vector<c2>& Y, std::vector<float>& out) {   
 int main() {
     gW.resize(N);
     for (uint32_t j = 0; j < N; ++j) { const double a = -2.0 * M_PI * (double)j / (double)N; gW[j] = mk((float)std::cos(a), (float)std::sin(a)); }
+    gTab.resize(kTabSize);
+    for (uint32_t i = 0; i < kTabSize; ++i) gTab[i] = gW[tab_source(i)];
     uint32_t seed = 12345u;
     auto rnd = [&] { seed = 1664525u * seed + 1013904223u; return (float)((double)seed / 2147483648.0 - 1.0); };
     // 1. forward transform vs double DFT
