@@ -797,8 +797,7 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
         hipLaunchKernelGGL(elemhip_convolve_long_fft, dim3(numNodes, longHistRows + chunks), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
         hipLaunchKernelGGL(elemhip_convolve_long_mac, dim3(numNodes, (lfft::kBins + 255u) / 256u, (chunks + kLongRun - 1u) / kLongRun), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
         hipLaunchKernelGGL(elemhip_convolve_long_ifft, dim3(numNodes, chunks), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
-        hipLaunchKernelGGL(elemhip_convolve_long_state, dim3(numNodes, longStateBlocks < batch ? longStateBlocks : batch), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longMode, perNode);
-        hipLaunchKernelGGL(elemhip_convolve_long_tail, dim3(numNodes), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, 0u, perNode);
+        (void)longStateBlocks;      // (the 512-partition state — spectra ring, overlap — is made on demand: launch_convolve_fix_overlap)
     }
 }
 
@@ -806,10 +805,12 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
 // a long-partition set rendered last: their overlap (conv_long.inc, elemhip_convolve_long_tail mode 1). `numWork` entries of the
 // plan's conv work list from `workBegin` on are looked at; helper entries and nodes whose overlap is current return at once.
 void launch_convolve_fix_overlap(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                 uint32_t numWork, float* scratch, uint32_t maxBatch, uint32_t longHistRows) {
+                                 uint32_t numWork, float* scratch, uint32_t maxBatch, uint32_t longHistRows, uint32_t maxPartitions) {
     if (!numWork) return;
     const size_t perNode = convolve_batch_scratch_floats(maxBatch, longHistRows);
-    hipLaunchKernelGGL(elemhip_convolve_long_tail, dim3(numWork), dim3(256), 0, s, pv, recs, hbm, g, workBegin, 0u, scratch, maxBatch, 0u, 1u, perNode);
+    // the 1024-point spectra of the last P blocks from the input ring, then the overlap of the last block
+    hipLaunchKernelGGL(elemhip_convolve_long_state, dim3(numWork, maxPartitions ? maxPartitions : 1u), dim3(256), 0, s, pv, recs, hbm, g, workBegin, scratch, maxBatch, perNode);
+    hipLaunchKernelGGL(elemhip_convolve_long_tail, dim3(numWork), dim3(256), 0, s, pv, recs, hbm, g, workBegin, scratch, maxBatch, perNode);
 }
 
 uint32_t convolve_long_tap_group() { return kLongTaps; }

@@ -1586,6 +1586,7 @@ int Engine::setOption(const std::string& key, double value) {
         if (profileLaunches) { profMs.clear(); profSets = 0; profBlocks = 0; }
         return kOk;
     }
+    if (key == "max_shape_launches") { maxShapeLaunches = std::max(1, std::min(64, (int)value)); dropGraphs(); return kOk; }
     if (key == "spec_lonely_blocks") { lonelyBlocks = std::max(0, (int)value); return kOk; }   // background mode: a one-off shape is queued for compilation once its
     if (key == "spec_lonely_ms") { lonelyMs = std::max(0, (int)value); return kOk; }           // plan has rendered this many blocks and been current this long
     // run-time compiler tunings (PROCESS-wide; bit-identical samples by construction, island_ops.inc): later plans compile with them
@@ -2116,18 +2117,26 @@ bool Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
     if (e <= b) return false;
     bool spec = specialize != 0 && !p.shapes.empty();
     std::vector<std::pair<hipFunction_t, const Plan::SpecShape*>> fns;   // function null: the shape is not compiled (yet)
+    struct InterpRun { uint32_t begin, count; };                          // contiguous stretches of specLists the interpreter kernel renders
+    std::vector<InterpRun> interpRuns;
     if (spec) {
         bool any = false;
+        int specTaken = 0;
         for (const Plan::SpecShape& sh : p.shapes) {
             if (sh.level != (uint32_t)l) continue;
-            hipFunction_t fn = sh.entry->function(device);
+            // (the level's shapes are listed biggest first, plan.cpp: the first `maxShapeLaunches` compiled ones get their kernels)
+            hipFunction_t fn = specTaken < maxShapeLaunches ? sh.entry->function(device) : nullptr;
+            if (fn) ++specTaken;
             any = any || fn != nullptr;
             // A launch whose islands all belong to roots that do not run (a replaced root once its fade-out has settled stays in
             // the plan until the next commit) would start workgroups that return at once — and, as a second launch of its
             // level, cost a fork to a side stream and a join. The host mirrors the root fades (mirrorRootFades), and launch
             // sets are only rendered while every running root's fade is settled: what runs does not change inside a set.
             if (skipIdleLaunches && !anyRootRuns(sh.roots, hGlobals.numOut)) { st.idleLaunchesSkipped++; continue; }
-            fns.emplace_back(fn, &sh);
+            if (fn) { fns.emplace_back(fn, &sh); continue; }
+            // not compiled (yet), or beyond the launch cap: joins the interpreter run that ends where its list begins, or starts one
+            if (!interpRuns.empty() && interpRuns.back().begin + interpRuns.back().count == sh.listBegin) interpRuns.back().count += sh.count;
+            else interpRuns.push_back({sh.listBegin, sh.count});
         }
         if (!any) spec = false;
     }
@@ -2137,7 +2146,7 @@ bool Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
     // instead of 64 CUs twice.
     uint32_t rb = p.restOffsets[l], re = p.restOffsets[l + 1];
     if (re > rb && skipIdleLaunches && l < p.restRoots.size() && !anyRootRuns(p.restRoots[l], hGlobals.numOut)) { re = rb; st.idleLaunchesSkipped++; }
-    const size_t launches = fns.size() + (re > rb ? 1 : 0);
+    const size_t launches = fns.size() + interpRuns.size() + (re > rb ? 1 : 0);
     if (launches == 0) return false;
     const bool fork = launches > 1;
     const bool fused = epiOut != nullptr && batch == 1u && launches == 1 && fns.size() == 1 && fns[0].first != nullptr;
@@ -2165,15 +2174,14 @@ bool Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         HIP_WARN(hipStreamWaitEvent(s2, forkEvent, 0));
         return s2;
     };
+    for (const InterpRun& r : interpRuns) {   // these shapes' islands go through the interpreter kernel (their lists have the levelIslands entry format)
+        PlanView pv = p.view;
+        pv.levelIslands = p.dSpecLists;
+        launch_level(streamFor(k++), pv, dRecs, dHbm, dGlobals, dLcg, r.begin, r.count, p.levelLdsBytes[l], batch, arenaFloats, statelessRows);
+        islandBlocksInterp += (uint64_t)r.count * batch;
+    }
     for (auto& f : fns) {
         hipStream_t st_ = streamFor(k++);
-        if (!f.first) {   // this shape's islands go through the interpreter kernel (their list has the levelIslands entry format)
-            PlanView pv = p.view;
-            pv.levelIslands = p.dSpecLists;
-            launch_level(st_, pv, dRecs, dHbm, dGlobals, dLcg, f.second->listBegin, f.second->count, p.levelLdsBytes[l], batch, arenaFloats, statelessRows);
-            islandBlocksInterp += (uint64_t)f.second->count * batch;
-            continue;
-        }
         PlanView pv = p.view;
         uint32_t* recs = dRecs; float* hbm = dHbm; const Globals* g = dGlobals; const uint32_t* lcg = dLcg;
         const uint32_t* list = p.dSpecLists + f.second->listBegin;
@@ -2230,7 +2238,7 @@ void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32
 void Engine::fixConvOverlaps(const Plan& p) {
     if (!convOverlapStale || p.convs.empty() || !dConvScratch) return;
     launch_convolve_fix_overlap(stream, p.view, dRecs, dHbm, dGlobals, 0u, (uint32_t)p.convWork.size(), dConvScratch, (uint32_t)batchBlocks,
-                                (convLong && convMaxQp) ? convMaxQp - 1u : 0u);
+                                (convLong && convMaxQp) ? convMaxQp - 1u : 0u, convMaxP);
     convOverlapStale = false;
 }
 
@@ -2329,9 +2337,9 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
                                         nIn * bs * sizeof(float), chunk, hipMemcpyDeviceToDevice, stream));
             rc = flushPending();
             if (rc != kOk) return rc;
-            enqueueBatch(p, (uint32_t)chunk);
-            if (outDev && nOut > 0)
-                HIP_OK(hipMemcpyAsync(outDev + done * nOut * bs, dOutRing, chunk * nOut * bs * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            // the set's epilogue sums the roots straight into the caller's [block][channel][frame] buffer (r04: into the engine's ring and
+            // a device-to-device copy behind it — 5.6 us of a 135 us C3 set, 100 us of a C4 set)
+            enqueueBatch(p, (uint32_t)chunk, (outDev && nOut > 0) ? outDev + done * nOut * bs : nullptr);
             hGlobals.sampleTime += (int64_t)(chunk * bs);
             done += chunk;
             st.blocksRendered += chunk;

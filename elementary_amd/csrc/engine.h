@@ -394,6 +394,7 @@ private:
     // gets there, a static patch does within its first second (plan.cpp "deferred")
     void promoteDeferredShapes();
     int lonelyBlocks = 64, lonelyMs = 30;  // options "spec_lonely_blocks", "spec_lonely_ms"
+    int maxShapeLaunches = 6;              // option "max_shape_launches": specialised launches per level (the shapes with the most islands); the rest -> one interpreter launch
     uint64_t islandBlocksSpec = 0, islandBlocksInterp = 0;   // island x block units rendered by specialised / interpreter kernels (describe_plan)
     bool anyRootRuns(const std::vector<int32_t>& rootIds, size_t nOut) const;   // host mirror of spec_root_running (Core.h:28-31, GraphRenderSequence.h:214-219)
     void mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t nIn);

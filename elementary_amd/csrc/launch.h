@@ -27,7 +27,7 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
                            uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch, uint32_t macMode,
                            bool anyShortIr, bool anyLongIr, uint32_t longHistRows, bool anyShortPath, uint32_t longStateBlocks);
 void launch_convolve_fix_overlap(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
-                                 uint32_t numWork, float* scratch, uint32_t maxBatch, uint32_t longHistRows);
+                                 uint32_t numWork, float* scratch, uint32_t maxBatch, uint32_t longHistRows, uint32_t maxPartitions);
 uint32_t convolve_mfma_max_partitions();   // IRs of up to this many 512-tap partitions take the matrix-core MAC
 uint32_t convolve_long_tap_group();        // long-partition IR spectra are allocated in multiples of this many rows
 uint32_t convolve_long_row_floats();       // floats per long-partition spectrum row (4097 bins, padded)

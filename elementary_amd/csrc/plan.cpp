@@ -1831,8 +1831,15 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
                 auto& slot = byText[tx.key];
                 slot.first = &tx; slot.second.push_back(isl);
             }
-            for (auto& kvk : byText) {
-                auto& kv = kvk.second;
+            // the level's shapes, the ones with the most islands first (ties: by key): a level renders at most `max_shape_launches`
+            // specialised launches, the biggest shapes — everything behind them in this list is ONE contiguous run the interpreter
+            // kernel takes in one launch (Engine::launchLevelBatch). A live graph of structurally different voices used to give every
+            // voice whose kernel had been compiled a launch (and a side stream) of its own: 60 launches per level and set, 150 us per block.
+            std::vector<std::pair<const std::string*, std::pair<SpecText*, std::vector<uint32_t>>*>> order;
+            for (auto& kvk : byText) order.emplace_back(&kvk.first, &kvk.second);
+            std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.second->second.size() > b.second->second.size(); });
+            for (auto& ord : order) {
+                auto& kv = *ord.second;
                 // background mode: a shape only one island has (a voice that is fading out next to its replacement, a
                 // one-off graph) is not worth a compile at commit time: its plan may be gone in 30 ms. It gets a DEFERRED entry —
                 // known to the kernel cache, not queued — and renders through the interpreter kernel; once this plan has rendered
