@@ -1553,6 +1553,8 @@ int Engine::setOption(const std::string& key, double value) {
     std::lock_guard<std::mutex> lock(mu);
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
     if (key == "host_out_direct") { hostOutDirect = value != 0; return kOk; }   // elemhip_process: epilogue writes the pinned host block itself
+    if (key == "conv_direct_io") { convDirectIo = value != 0; return kOk; }
+    if (key == "conv_long_mac_lds") { convLongMacLds = value != 0; return kOk; }   // long-partition sums: LDS-tiled kernel (1) or the register kernel over L2 (0)
     if (key == "conv_long") { convLong = value != 0; return kOk; }   // IRs set from now on get (or do not get) long-partition spectra; sets of older IRs keep theirs
     if (key == "conv_mfma") { convMfma = std::max(0, std::min(1, (int)value)); return kOk; }   // partition MAC of launch sets: 1 matrix cores (default), 0 packed vector FMAs
     if (key == "skip_idle_launches") { skipIdleLaunches = value != 0; dropGraphs(); return kOk; }
@@ -2232,7 +2234,37 @@ void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32
     if (longSet && stateBlocks > 1u) { convLongSets++; convOverlapStale = true; }
     if (!longSet) fixConvOverlaps(p);
     launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks, (uint32_t)convMfma,
-                          convMinP <= convolve_mfma_max_partitions(), convMaxP > convolve_mfma_max_partitions(), longRows, anyShortPath, stateBlocks);
+                          convMinP <= convolve_mfma_max_partitions(), convMaxP > convolve_mfma_max_partitions(), longRows, anyShortPath, stateBlocks, convLongMacLds,
+                          longSet ? setInDirect : nullptr, setNumIn, longSet ? setOutDirect : nullptr, setNumOut);
+}
+
+// A plan that consists of long-partition convolvers only (BASELINE configs[2]: root(convolve(in)) per channel — in and root folded into
+// the node's launches) needs neither the copy of the caller's input blocks into the arenas nor the bus-sum epilogue of a launch set:
+// the long-partition kernels read the [block][channel][frame] input where it lies, and when every output channel of the call is the
+// folded root of exactly one running convolver they write the caller's output buffer themselves (r05: 8.4 + 9.5 us of a 118 us C3 set).
+void Engine::chooseConvDirectIo(const Plan& p, size_t nIn, size_t nOut, uint32_t batch, bool haveIn, bool& dIn, bool& dOut) {
+    dIn = dOut = false;
+    if (!convDirectIo || !convLong || !convMaxQp || p.convs.empty() || !p.levelIslands.empty() || !p.hosts.empty() || !p.taps.empty()) return;
+    if (batch < 8u || (batch & 7u) != 0u) return;
+    std::vector<uint32_t> fused;
+    for (size_t ci = 0; ci < p.convs.size(); ++ci) {
+        auto it = ci < p.convNodeIds.size() ? nodes.find(p.convNodeIds[ci]) : nodes.end();
+        if (it == nodes.end() || it->second.convQp == 0u) return;            // a node without long-partition spectra: the 512-partition kernels read the arenas
+        if (p.convs[ci].fuseRootRec != kNone) fused.push_back(p.convs[ci].fuseRootRec);
+    }
+    dIn = haveIn;
+    std::vector<uint8_t> seen(nOut, 0);
+    size_t covered = 0;
+    for (int32_t id : p.rootIds) {
+        auto it = nodes.find(id);
+        if (it == nodes.end()) return;
+        const Node& r = it->second;
+        const bool on = r.target > 0.5f, settled = std::fabs(r.target - r.gain) <= 1e-6f;
+        if (!((on || !settled) && r.channel >= 0 && (size_t)r.channel < nOut)) continue;   // not running (or a channel the call does not ask for)
+        if (std::find(fused.begin(), fused.end(), r.rec) == fused.end() || seen[(size_t)r.channel]) return;
+        seen[(size_t)r.channel] = 1; ++covered;
+    }
+    dOut = covered == nOut && nOut > 0;
 }
 
 void Engine::fixConvOverlaps(const Plan& p) {
@@ -2259,7 +2291,13 @@ void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
         if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)l); }
     }
     if (prof) (void)hipEventRecord(profEvent(), stream);
-    if (!fused) launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, outRing, batch, arenaFloats);
+    if (setOutDirect) {
+        // the convolvers wrote the caller's buffer themselves (chooseConvDirectIo): what is left of the epilogue is the device's sample
+        // clock, moved on by a parameter patch (applied in stream order with the next call's patches)
+        const int64_t t = hGlobals.sampleTime + (int64_t)blockSize * (int64_t)batch;
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, sampleTime) / 4), (uint32_t)((uint64_t)t & 0xFFFFFFFFu), 0u});
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, sampleTime) / 4 + 1), (uint32_t)((uint64_t)t >> 32), 0u});
+    } else if (!fused) launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, outRing, batch, arenaFloats);
     else st.fusedEpilogues++;
     debugSync("set: epilogue", batch);
     if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)L); profSets++; profBlocks += batch; }
@@ -2332,14 +2370,21 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             }
             setInRing(nullptr, 0);
             hGlobals.blockSlot = 0;
-            if (haveIn)   // host inputs of block b -> arena buffers 0..nIn-1 of block b's arena
+            bool dIn = false, dOut = false;
+            chooseConvDirectIo(p, nIn, nOut, (uint32_t)chunk, haveIn, dIn, dOut);
+            float* const outTarget = (outDev && nOut > 0) ? outDev + done * nOut * bs : nullptr;
+            setInDirect = dIn ? inDev + done * nIn * bs : nullptr; setNumIn = (uint32_t)nIn;
+            setOutDirect = dOut ? (outTarget ? outTarget : dOutRing) : nullptr; setNumOut = (uint32_t)nOut;
+            if (dIn || dOut) convDirectSets++;
+            if (haveIn && !dIn)   // host inputs of block b -> arena buffers 0..nIn-1 of block b's arena
                 HIP_OK(hipMemcpy2DAsync(dHbm, (size_t)p.numHbmBuffers * bs * sizeof(float), inDev + done * nIn * bs, nIn * bs * sizeof(float),
                                         nIn * bs * sizeof(float), chunk, hipMemcpyDeviceToDevice, stream));
             rc = flushPending();
             if (rc != kOk) return rc;
             // the set's epilogue sums the roots straight into the caller's [block][channel][frame] buffer (r04: into the engine's ring and
             // a device-to-device copy behind it — 5.6 us of a 135 us C3 set, 100 us of a C4 set)
-            enqueueBatch(p, (uint32_t)chunk, (outDev && nOut > 0) ? outDev + done * nOut * bs : nullptr);
+            enqueueBatch(p, (uint32_t)chunk, outTarget);
+            setInDirect = nullptr; setOutDirect = nullptr;
             hGlobals.sampleTime += (int64_t)(chunk * bs);
             done += chunk;
             st.blocksRendered += chunk;

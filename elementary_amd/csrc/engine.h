@@ -315,6 +315,12 @@ private:
     bool convLong = true;                  // option "conv_long": launch sets of a multiple of 8 blocks render IRs of >= 32 partitions with 4096-sample partitions (conv_long.inc)
     bool convOverlapStale = false;         // some convolve node was last rendered by a long-partition set: its `overlap` is made on demand (fixConvOverlaps)
     void fixConvOverlaps(const Plan& p);   // ... before the next 512-partition evaluation (block-at-a-time launches, sets that are no multiple of 8 blocks)
+    bool convLongMacLds = true;            // option "conv_long_mac_lds"
+    bool convDirectIo = true;              // option "conv_direct_io": a plan of long-partition convolvers only reads the caller's input / writes the caller's output in place
+    // the launch set being enqueued (enqueueBlocks -> enqueueBatch -> launchConvolveBatch): where its convolvers read / write directly
+    const float* setInDirect = nullptr; float* setOutDirect = nullptr; uint32_t setNumIn = 0, setNumOut = 0;
+    uint64_t convDirectSets = 0;
+    void chooseConvDirectIo(const Plan& p, size_t nIn, size_t nOut, uint32_t batch, bool haveIn, bool& dIn, bool& dOut);
     uint64_t convLongSets = 0;             // launch sets in which some node took the long-partition kernels (describe_plan)
     uint32_t convMaxQp = 0;                // most long-partition tap rows of any impulse response set so far (sizes the scratch)
     int convMfma = 1;                      // conv.hip elemhip_convolve_batch_mac: 1 v_mfma_f32_4x4x1_16B_f32 Toeplitz tiles, 0 v_pk_fma_f32 (r03)

@@ -25,7 +25,8 @@ void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* h
 size_t convolve_batch_scratch_floats(uint32_t maxBatch, uint32_t longHistRows);   // per convolve node (longHistRows: 0 = no long-partition area)
 void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
                            uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch, uint32_t macMode,
-                           bool anyShortIr, bool anyLongIr, uint32_t longHistRows, bool anyShortPath, uint32_t longStateBlocks);
+                           bool anyShortIr, bool anyLongIr, uint32_t longHistRows, bool anyShortPath, uint32_t longStateBlocks, bool longMacLds,
+                           const float* inDirect, uint32_t numInCh, float* outDirect, uint32_t numOutCh);
 void launch_convolve_fix_overlap(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
                                  uint32_t numWork, float* scratch, uint32_t maxBatch, uint32_t longHistRows, uint32_t maxPartitions);
 uint32_t convolve_mfma_max_partitions();   // IRs of up to this many 512-tap partitions take the matrix-core MAC

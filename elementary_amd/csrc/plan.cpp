@@ -1975,7 +1975,7 @@ std::string Engine::describePlan() {
                       (unsigned long long)js.diskFilesRemoved, js.workers);
         s += b;
     }
-    kv("conv_long_sets", convLongSets); kv("conv_long", convLong ? 1 : 0); kv("conv_max_long_tap_rows", convMaxQp);
+    kv("conv_direct_io_sets", convDirectSets); kv("conv_long_sets", convLongSets); kv("conv_long", convLong ? 1 : 0); kv("conv_max_long_tap_rows", convMaxQp);
     kv("num_taps", p.taps.size()); kv("taps_in_sets", p.tapsInSets ? 1 : 0); kv("num_tap_nodes", p.taps.size() + p.tapPairs.size()); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());
     s += "\"level_sizes\":[";
     for (size_t l = 0; l + 1 < p.levelOffsets.size(); ++l) { if (l) s += ","; s += std::to_string(p.levelOffsets[l + 1] - p.levelOffsets[l]); }

@@ -114,6 +114,10 @@ def test_c3_large_launch_sets_vs_restatement(gpu_required, ch, batch, blocks):
     rt.set_option("batch_blocks", batch)
     got = np.concatenate([_blocks(rt, x, k0, min(batch + 37, blocks - k0), ch) for k0 in range(0, blocks, batch + 37)])
     assert rt.stats()["batch_launches"] >= 2
+    plan = rt.describe_plan()
+    # r05: the whole-batch sets take the long-partition kernels, reading the caller's input and writing the caller's output in place
+    # (a plan of convolvers only: no arena copy, no bus-sum epilogue); the 37-block remainders take the 512-partition kernels
+    assert plan["conv_long_sets"] >= 1 and plan["conv_direct_io_sets"] >= 1, (plan["conv_long_sets"], plan["conv_direct_io_sets"])
     ref_rt, _ = _c3(lambda sr, bs: oracle.PortRuntime(sr, bs), ch, blocks)
     ref = np.stack([ref_rt.process(x[:, k * 512:(k + 1) * 512], ch, 512) for k in range(blocks)])
     err = np.abs(got.astype(np.float64) - ref).max(axis=(1, 2))
