@@ -193,6 +193,9 @@ def c3(steps: int = 16, warmup: int = 2, set_blocks: int = 1024, gpu_only: bool 
         assert rt.add_shared_resource(f"ir{c}", graphs.c3_impulse_response(c))
     assert rt.render(*graphs.c3_graph(ch))["result"] == 0
     rt.set_option("batch_blocks", set_blocks)
+    for kv in [t for t in os.environ.get("ELEMHIP_C3_OPTS", "").split(",") if t]:      # (A/B runs: "conv_long_mac_lds=0,conv_direct_io=0")
+        k_, v_ = kv.split("=", 1)
+        rt.set_option(k_, float(v_))
     x = graphs.c3_input(ch, 64 * BLOCK)
     xin = torch.from_numpy(np.ascontiguousarray(x.reshape(ch, 64, BLOCK).transpose(1, 0, 2))).cuda().repeat(max(warmup, steps) * set_blocks // 64, 1, 1).contiguous()
     outs = torch.zeros(((warmup + steps) * set_blocks, ch, BLOCK), dtype=torch.float32, device="cuda")
