@@ -315,7 +315,7 @@ private:
     bool convLong = true;                  // option "conv_long": launch sets of a multiple of 8 blocks render IRs of >= 32 partitions with 4096-sample partitions (conv_long.inc)
     bool convOverlapStale = false;         // some convolve node was last rendered by a long-partition set: its `overlap` is made on demand (fixConvOverlaps)
     void fixConvOverlaps(const Plan& p);   // ... before the next 512-partition evaluation (block-at-a-time launches, sets that are no multiple of 8 blocks)
-    bool convLongMacLds = true;            // option "conv_long_mac_lds"
+    bool convLongMacLds = false;           // option "conv_long_mac_lds": the LDS-tiled partition sums (measured slower than the register kernel over L2: 36.6 vs 27.4 us per C3 set)
     bool convDirectIo = true;              // option "conv_direct_io": a plan of long-partition convolvers only reads the caller's input / writes the caller's output in place
     // the launch set being enqueued (enqueueBlocks -> enqueueBatch -> launchConvolveBatch): where its convolvers read / write directly
     const float* setInDirect = nullptr; float* setOutDirect = nullptr; uint32_t setNumIn = 0, setNumOut = 0;
