@@ -192,6 +192,7 @@ struct Jit::Impl {
                 if (!e) continue;
             }
             compile(*e);
+            e->preload();
             {
                 std::lock_guard<std::mutex> l(mu);
                 const int s = e->state.load(std::memory_order_acquire);
@@ -558,6 +559,27 @@ hipFunction_t SpecEntry::function(int device) {
     perDevice.emplace(device, std::make_pair(mod, fn));
     Jit::get().noteModuleLoaded(+1);
     return fn;
+}
+
+void SpecEntry::wantOn(int device) {
+    if (device < 0) return;
+    bool ready;
+    {
+        std::lock_guard<std::mutex> l(mu);
+        if (std::find(wantDevices.begin(), wantDevices.end(), device) == wantDevices.end()) wantDevices.push_back(device);
+        ready = state.load(std::memory_order_acquire) == 1 && perDevice.find(device) == perDevice.end();
+    }
+    if (ready && hipSetDevice(device) == hipSuccess) (void)function(device);       // (the caller is a commit on the control thread)
+}
+
+void SpecEntry::preload() {
+    if (state.load(std::memory_order_acquire) != 1) return;
+    std::vector<int> devs;
+    { std::lock_guard<std::mutex> l(mu); devs = wantDevices; }
+    for (int d : devs) {
+        if (hipSetDevice(d) != hipSuccess) continue;
+        (void)function(d);
+    }
 }
 
 // The last reference is gone (evicted from the table and no plan left that names it — a plan is destroyed only after the

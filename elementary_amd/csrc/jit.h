@@ -28,6 +28,10 @@ struct SpecEntry {
     std::atomic<uint64_t> lastUse{0};   // Jit tick of the newest request / launch look-up (eviction order)
     std::mutex mu;
     std::unordered_map<int, std::pair<hipModule_t, hipFunction_t>> perDevice;
+    std::vector<int> wantDevices;         // devices whose engines asked for this shape: the compile worker loads the code object there, so that
+                                          // the first launch does not pay the ~1 ms of hipModuleLoadData inside a render call
+    void wantOn(int device);              // (control thread) remember the device; a ready entry is loaded at once, off the render path
+    void preload();                       // (compile worker) load on every wanted device
     hipFunction_t function(int device);   // nullptr until ready (or if loading failed)
     std::string fullText();               // the translation unit hiprtc saw (debug / tests: elemhip_spec_info)
     ~SpecEntry();                         // unloads its modules (each on its own device)

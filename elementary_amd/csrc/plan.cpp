@@ -1855,6 +1855,7 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
                 sh.optional = lonely;
                 sh.deferred = defer;
                 sh.entry = Jit::get().requestKey(tx.key, tx.text, ldsW, (uint32_t)blockSize, defer);
+                if (!dry) sh.entry->wantOn(device);
                 if (defer) p.deferredShapes++;
                 sh.level = (uint32_t)l; sh.listBegin = (uint32_t)p.specLists.size();
                 sh.stateless = p.islands[kv.second[0]].stateless != 0u;
