@@ -582,6 +582,11 @@ def main() -> None:
                     sync_native["specialize"] = 2
                     sync_native["product_default_specialize_1"] = _bc._native_host(
                         graphs.c2_graph(voices=my_voices, channels=2, first_voice=first), graphs.C2_SAMPLE_RATE, blocks=2000, env={"ELEMHIP_SPECIALIZE": "1"})
+                    # ... and opt-in `resident`: the calls handed to a kernel that stays on the GPU (interpreter island bodies behind
+                    # device-wide barriers between this graph's levels; resident.hip)
+                    sync_native["resident_opt_in"] = _bc._native_host(
+                        graphs.c2_graph(voices=my_voices, channels=2, first_voice=first), graphs.C2_SAMPLE_RATE, blocks=2000,
+                        env={"ELEMHIP_SPECIALIZE": "1", "ELEMHIP_RESIDENT": "1"})
             except Exception as e:      # noqa: BLE001  (a missing binary is reported, not fatal)
                 sync_native = {"error": str(e)[:200]}
 

@@ -62,7 +62,7 @@ def _ref_engine(sr):
 # C1 — BASELINE configs[0]: the cli benchmark's own graph and its own protocol (cli/Benchmark.cpp:70-101: one warm-up block,
 # N timed synchronous process() calls of 512 frames from a native host)
 # ------------------------------------------------------------------------------------------------------------------------------
-def _native_run(roots, sr, blocks, spec, dump):
+def _native_run(roots, sr, blocks, spec, dump, resident=False):
     """examples/bench_cli (C++ over include/elemhip/Runtime.hpp): `blocks` timed calls; every rendered block lands in `dump`."""
     import subprocess
     import tempfile
@@ -76,7 +76,7 @@ def _native_run(roots, sr, blocks, spec, dump):
         bpath = os.path.join(d, "batch.json")
         open(bpath, "w").write(batch_to_json(sent[0]))
         res = subprocess.run([exe, bpath, str(blocks), str(sr), os.path.join(d, "last.f32"), dump], capture_output=True, text=True, timeout=300,
-                             env=dict(os.environ, ELEMHIP_SPECIALIZE=str(spec)))
+                             env=dict(os.environ, ELEMHIP_SPECIALIZE=str(spec), ELEMHIP_RESIDENT="1" if resident else "0"))
     if res.returncode != 0:
         return {"error": res.stderr[-300:]}
     line = [l for l in res.stderr.splitlines() if l.startswith("{")]
@@ -113,6 +113,13 @@ def c1(calls: int = 4000):
                 got = np.fromfile(dump, dtype=np.float32).reshape(calls + 1, 2, BLOCK)
                 r["parity"] = _parity(got, ref, f"every one of the {calls + 1} blocks the native host rendered (warm-up block included) vs the {kind} engine")
             out[spec] = r
+        # option `resident` (opt-in): the same protocol with the calls handed to a kernel that stays on the GPU (resident.hip)
+        dump = os.path.join(d, "allres.f32")
+        r = _native_run(roots, sr, calls, 1, dump, resident=True)
+        if "error" not in r and os.path.exists(dump):
+            got = np.fromfile(dump, dtype=np.float32).reshape(calls + 1, 2, BLOCK)
+            r["parity"] = _parity(got, ref, f"every one of the {calls + 1} blocks the native host rendered with ELEMHIP_RESIDENT=1 vs the {kind} engine")
+        out["resident"] = r
     # the same graph through launch sets (what an offline caller gets), output left in HBM
     rt = Runtime(sr, BLOCK, device=0)
     rt.set_option("specialize", 2)
@@ -139,10 +146,14 @@ def c1(calls: int = 4000):
     rec = {
         "config": "BASELINE configs[0] (C1): cli/Benchmark graph, 2 ch el.lowpass(800, 1, el.mul(0.3, el.cycle(440 + c))), 18 nodes, sr 44100, blockSize 512",
         "protocol": "cli/Benchmark.cpp:70-101 on a native host (examples/bench_cli, C++ over the C-ABI): 1 warm-up block, then one synchronous "
-                    "elemhip_process call per 512-frame block through host buffers (PCIe + launch + synchronise inside every call)",
+                    "elemhip_process call per 512-frame block through host buffers (PCIe + launches + the wait for the block inside every call: the call returns when "
+                    "the block's epilogue kernel has published its word to mapped host memory behind the output block, option `sync_poll`)",
         "value": (BLOCK / (us * 1e-6)) if us else None, "unit": "samples/s", "steps": calls, "ms_per_step": (us * 1e-3) if us else None,
         "us_per_call": {"mean": us, "p50": main.get("us_p50"), "p99": main.get("us_p99")}, "specialize": 2,
         "product_default_specialize_1": {k: out.get(1, {}).get(k) for k in ("us_mean", "us_p50", "us_p99", "parity", "error") if k in out.get(1, {})},
+        "resident_opt_in": dict({k: out.get("resident", {}).get(k) for k in ("us_mean", "us_p50", "us_p99", "us_max", "parity", "error") if k in out.get("resident", {})},
+                                note="option `resident` = 1 (ELEMHIP_RESIDENT=1), product default otherwise: no launch and no stream synchronise per call; "
+                                     "the GPU spins on a word in mapped host memory while the host is away (leaves after `resident_idle_us`, default 2000)"),
         "launch_sets": {"us_per_block": sets_us, "samples_per_s": BLOCK / (sets_us * 1e-6), "blocks_per_set": B, "sets_timed": nset,
                         "parity": _parity(keep, ref_sets, f"the last timed set ({B} blocks) vs the {kind} engine advanced through all {(nset + 1) * B} blocks")},
         "roofline": _roofline(alg, us, "algorithmic bytes per block / mean call time; a lone serial phasor -> sin -> svf chain per channel: latency-bound by construction") if us else None,

@@ -169,6 +169,7 @@ int elemhip_get_stats(elemhip_t* h, elemhip_stats* out) {
     out->batch_launches = s.batchLaunches;
     out->spec_launches = s.specLaunches; out->spec_shapes = s.specShapes; out->spec_islands = s.specIslands;
     out->last_jit_wait_ms = s.lastJitWaitMs; out->last_graph_capture_ms = s.lastGraphCaptureMs;
+    out->resident_launches = s.residentLaunches; out->resident_blocks = s.residentBlocks;
     return elemhip::kOk;
 }
 

@@ -122,13 +122,16 @@ Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), devi
     auto fail = [&](int code) { initErr = code; };
     // A block's buffers are LDS slots of at most kMaxBlock frames. A longer host block is rendered as k equal slices — the smallest k
     // that divides it into slices of 64 .. kMaxBlock frames (1024 -> 2 x 512, 700 -> 2 x 350, 1023 -> 3 x 341; r04 took multiples of
-    // 512 only) — the sample-rate nodes cannot tell; taps, whose delay IS the block, are refused at commit: the engine's own block size
-    // is the slice, the host's the limit of a process() call. A size no such k divides (a prime above 512) is refused.
+    // 512 only) — the sample-rate nodes cannot tell; taps, whose delay IS the host's block (Feedback.h:29-31, 66-67, 103-104), keep
+    // shared buffers of the HOST's block size and every slice reads / writes its own stretch of them (setTapSlice): the engine's own
+    // block size is the slice, the host's the limit of a process() call. A size no such k divides (a prime above 512) is refused.
     hostBlockSize = bs;
     if (bs > (int)kMaxBlock && bs <= 64 * (int)kMaxBlock)
         for (int k = (bs + (int)kMaxBlock - 1) / (int)kMaxBlock; k <= bs / 64; ++k)
             if (bs % k == 0) { bs /= k; blockSize = bs; break; }
     if (const char* e = std::getenv("ELEMHIP_SPECIALIZE")) specialize = std::max(0, std::min(2, std::atoi(e)));
+    if (const char* e = std::getenv("ELEMHIP_SYNC_POLL")) syncPoll = std::atoi(e) != 0;
+    if (const char* e = std::getenv("ELEMHIP_RESIDENT")) residentOpt = std::atoi(e) != 0;   // (a native host without access to the options)
     if (const char* e = std::getenv("ELEMHIP_PLAN_CACHE")) planCache = std::max(0, std::min(2, std::atoi(e)));   // 2: verify mode (tests)
     if (bs <= 0 || bs > (int)kMaxBlock) { fail(kBlockTooLarge); return; }
     if (dev == -1) {
@@ -202,7 +205,13 @@ Engine::~Engine() {
         for (auto& kv : resources) { std::free(kv.second->dev.ptr); for (DevBuf& d : kv.second->devCh) std::free(d.ptr); }
         return;
     }
+    residentStop();
     if (stream) (void)hipStreamSynchronize(stream);
+    if (hResident) (void)hipHostFree(hResident);
+    if (hDone) (void)hipHostFree(hDone);
+    if (hResIn) (void)hipHostFree(hResIn);
+    if (hResOut) (void)hipHostFree(hResOut);
+    if (dResidentSync) (void)hipFree(dResidentSync);
     current.reset(); pending.reset();
     for (auto& kv : nodes) if (kv.second.ring.ptr) (void)hipFree(kv.second.ring.ptr);
     for (auto& kv : resources) { if (kv.second->dev.ptr) (void)hipFree(kv.second->dev.ptr); for (DevBuf& d : kv.second->devCh) if (d.ptr) (void)hipFree(d.ptr); }
@@ -238,8 +247,15 @@ Engine::~Engine() {
     if (ownStream && stream) (void)hipStreamDestroy(stream);
 }
 
+// Every entry point that takes the render lock — except the per-block process() calls themselves — first asks a resident kernel
+// (option "resident") to leave: it owns the engine's stream for as long as it lives.
+struct RenderGuard {
+    std::lock_guard<std::mutex> l;
+    explicit RenderGuard(Engine& e) : l(e.mu) { e.residentStop(); }
+};
+
 void Engine::setStream(hipStream_t s) {
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     if (dry) return;
     if (stream) (void)hipStreamSynchronize(stream);
     if (ownStream && stream) (void)hipStreamDestroy(stream);
@@ -524,7 +540,7 @@ ResourcePtr Engine::tapResource(const std::string& name) {
     auto it = resources.find(name);
     if (it != resources.end()) return it->second;
     auto r = std::make_shared<Resource>();
-    r->channels.emplace_back((size_t)blockSize, 0.0f);
+    r->channels.emplace_back((size_t)hostBlockSize, 0.0f);      // AudioBufferResource(1, getBlockSize()) (Feedback.h:29-31): the HOST's block
     r->isTap = true;
     resources.emplace(name, r);
     return r;
@@ -614,6 +630,9 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
     } else if (nn.op == OP_TAPOUT) {                                              // Feedback.h:66-67
         rc = allocRing(nn, (size_t)blockSize);
         if (rc == kOk) writeParamPtr(nn, rec::TAP_PRIVATE, nn.ring.ptr);
+        tapNodeIds.push_back(id);
+    } else if (nn.op == OP_TAPIN) {
+        tapNodeIds.push_back(id);
     } else if (nn.op == OP_METER || nn.op == OP_SNAPSHOT) {                       // per-block readout log (device.h EVT_LOG): 1024 entries of 4 dwords
         rc = allocRing(nn, (size_t)kEventLogEntries * 4u);
         if (rc == kOk) { writeParamPtr(nn, rec::EVT_LOG, nn.ring.ptr); writeParam(nn, rec::EVT_LOGMASK, kEventLogEntries - 1u); }
@@ -794,7 +813,7 @@ int Engine::setProperty(int32_t id, const std::string& key, const Value& v) {   
                 int rc = ensureResourceOnDevice(r);
                 if (rc != kOk) return rc;
                 n.res = r;
-                writeParamPtr(n, rec::TAP_SHARED, r->dev.ptr);
+                writeParamPtr(n, rec::TAP_SHARED, dry ? r->dev.ptr : (const void*)(reinterpret_cast<const float*>(r->dev.ptr) + tapSliceOff));
             }
             break;
         case OP_SAMPLE:                                            // Sample.h:25-75
@@ -1055,12 +1074,6 @@ int Engine::commit(std::unique_lock<std::mutex>& renderLock) {   // Runtime.h:20
         // (not a reference code path: its buildRenderSequence cannot fail. The roots stay swapped as in the reference;
         // the rebuild stays owed so that the next commit retries instead of rendering the old sequence forever.)
         if (!p) { rebuildOwed = true; return kUnsupportedGraph; }
-        if (hostBlockSize != blockSize && (!p->taps.empty() || !p->tapPairs.empty())) {
-            // tapIn / tapOut delay their signal by one BLOCK of the host (Feedback.h:90-126): slices of 512 frames would shorten the loop
-            std::fprintf(stderr, "[elemhip] tapIn / tapOut need blockSize <= %u (this runtime was created with %d)\n", (unsigned)kMaxBlock, hostBlockSize);
-            rebuildOwed = true;
-            return kUnsupportedGraph;
-        }
         rebuildOwed = false;
         // mc.capture: the reference (re)creates the node's multi-channel ring whenever a render sequence that holds it is pushed
         // (GraphRenderSequence.h:165-169 sets `_internal:numChildren`, mc/Capture.h:21-31 allocates children - 1 channels of
@@ -1098,6 +1111,7 @@ int Engine::apply(const Value& batch) {   // Runtime.h:170-218
     std::lock_guard<std::mutex> control(ctl);
     std::unique_lock<std::mutex> lock(mu);
     if (!dry && hipSetDevice(device) != hipSuccess) return kHipError;
+    residentStop();
     if (!batch.isArray()) return kInvalidInstructionFormat;
     shouldRebuild = false;   // a local in the reference: ACTIVATE_ROOTS and COMMIT must share a batch
     static const bool applyTiming = std::getenv("ELEMHIP_APPLY_TIMING") != nullptr;   // time per instruction kind of a batch, on stderr
@@ -1175,7 +1189,7 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
     std::shared_ptr<Plan> plan;
     uint64_t windowBlocks = 0, blocksNow = 0;
     {   // ---- (a) under the render lock: snapshot of the records, stream-ordered behind everything rendered so far ----
-        std::lock_guard<std::mutex> lock(mu);
+        RenderGuard lock(*this);
         if (!current) return kOk;
         if (hipSetDevice(device) != hipSuccess) return kHipError;
         plan = current;
@@ -1355,7 +1369,7 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
         }
     }
     {   // ---- (c) read positions back to the device: parameter patches, applied in stream order at once (no synchronise) ----
-        std::lock_guard<std::mutex> lock(mu);
+        RenderGuard lock(*this);
         for (const Wb& w : writeBack) writeParam(*w.n, w.dword, w.value);
         relayBlocksMark = blocksNow;
         if (!writeBack.empty()) { const int rc = flushPending(); if (rc != kOk) return rc; }
@@ -1371,7 +1385,7 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
 // capture node's take is placed by the relay that sees its gate fall, so it wants a relay per block.
 uint32_t Engine::eventWindowBlocks() {
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     const std::shared_ptr<Plan> pl = pending ? pending : current;
     uint32_t w = kEventLogEntries;
     if (!pl) return w;
@@ -1396,7 +1410,7 @@ uint32_t Engine::eventWindowBlocks() {
 // ---- gc / resources -------------------------------------------------------------------------------
 size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     if (!dry) (void)hipSetDevice(device);
     std::vector<int32_t> pruned;
     for (auto it = nodes.begin(); it != nodes.end(); ++it) {
@@ -1432,6 +1446,7 @@ size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
             if (freshFlag[cr]) { freshRecs.erase(std::remove(freshRecs.begin(), freshRecs.end(), cr), freshRecs.end()); freshFlag[cr] = 0; }
             freeRecs.push_back(cr);
         }
+        if (n.op == OP_TAPIN || n.op == OP_TAPOUT) tapNodeIds.erase(std::remove(tapNodeIds.begin(), tapNodeIds.end(), id), tapNodeIds.end());
         nodes.erase(id);
     }
     if (!pruned.empty()) { if (++nodesEpoch == 0u) nodesEpoch = 1u; }      // (Inlet::src memos name erased nodes now)
@@ -1444,7 +1459,7 @@ size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
 
 size_t Engine::lastGc(int32_t* out, size_t cap) {
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     size_t k = 0;
     for (int32_t id : lastPruned) { if (out && k < cap) out[k] = id; ++k; }
     return k;
@@ -1452,7 +1467,7 @@ size_t Engine::lastGc(int32_t* out, size_t cap) {
 
 bool Engine::hasNode(int32_t id) {
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     return nodes.find(id) != nodes.end();
 }
 
@@ -1460,7 +1475,7 @@ bool Engine::hasNode(int32_t id) {
 // noteOff(), i.e. target gain 0 (Sample.h:78-81, 174-177). The reader state lives in the node record.
 void Engine::reset() {
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     for (auto& kv : nodes) {
         Node& n = kv.second;
         if (n.op == OP_SAMPLE) {
@@ -1476,7 +1491,7 @@ void Engine::reset() {
 
 int Engine::registerNodeType(const std::string& type, const HostVTable& vt) {   // Runtime.h:480-487
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     if (hostTypes.count(type) || opTable().count(type)) return kNodeTypeAlreadyExists;
     if (!vt.process) return kInvalidInstructionFormat;
     hostTypes.emplace(type, std::unique_ptr<HostVTable>(new HostVTable(vt)));
@@ -1490,7 +1505,7 @@ static std::string idToHex(int32_t id) {   // Types.h:16-27
 
 std::string Engine::snapshotJson() {   // Runtime.h:489-498: { nodeIdToHex(id): node.getProperties() }
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     std::map<std::string, const Node*> sorted;
     for (auto& kv : nodes) sorted.emplace(idToHex(kv.first), &kv.second);
     std::string out = "{";
@@ -1513,7 +1528,7 @@ std::string Engine::snapshotJson() {   // Runtime.h:489-498: { nodeIdToHex(id): 
 
 std::string Engine::sharedResourceKeysJson() {   // SharedResourceMap::keys (SharedResource.h)
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     std::vector<std::string> keys;
     for (auto& kv : resources) keys.push_back(kv.first);
     std::sort(keys.begin(), keys.end());
@@ -1525,7 +1540,7 @@ std::string Engine::sharedResourceKeysJson() {   // SharedResourceMap::keys (Sha
 
 bool Engine::addSharedResource(const std::string& name, const float* const* ch, size_t nCh, size_t nSamples) {
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     if (resources.count(name)) return false;                 // insert-only (SharedResource.h:61-63)
     auto r = std::make_shared<Resource>();
     for (size_t c = 0; c < nCh; ++c) r->channels.emplace_back(ch[c], ch[c] + nSamples);
@@ -1535,7 +1550,7 @@ bool Engine::addSharedResource(const std::string& name, const float* const* ch, 
 
 void Engine::pruneSharedResources() {   // SharedResource.h:94-102
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     if (!dry) (void)hipSetDevice(device);
     for (auto it = resources.begin(); it != resources.end();) {
         if (it->second.use_count() == 1) {
@@ -1550,8 +1565,13 @@ void Engine::pruneSharedResources() {   // SharedResource.h:94-102
 
 int Engine::setOption(const std::string& key, double value) {
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     if (key == "use_graph") { useGraph = value != 0.0; return kOk; }
+    if (key == "sync_poll") { syncPoll = value != 0.0; return kOk; }   // elemhip_process: wait for the epilogue's word in mapped host memory (1) or synchronise the stream (0)
+    // elemhip_process through a kernel that stays on the GPU between calls (resident.hip): opt-in, the GPU spins while the host is away
+    if (key == "resident") { residentOpt = value != 0.0; residentStreak = 0; return kOk; }
+    if (key == "resident_idle_us") { residentIdleUs = (uint32_t)std::max(10.0, std::min(5e6, value)); return kOk; }
+    if (key == "resident_after") { residentAfter = (uint32_t)std::max(1.0, std::min(1e6, value)); return kOk; }
     if (key == "host_out_direct") { hostOutDirect = value != 0; return kOk; }   // elemhip_process: epilogue writes the pinned host block itself
     if (key == "conv_direct_io") { convDirectIo = value != 0; return kOk; }
     if (key == "conv_long_mac_lds") { convLongMacLds = value != 0; return kOk; }   // long-partition sums: LDS-tiled kernel (1) or the register kernel over L2 (0)
@@ -1602,6 +1622,7 @@ int Engine::setOption(const std::string& key, double value) {
 
 // ---- block rendering ----------------------------------------------------------------------------------
 int Engine::flushPending() {
+    residentStop();
     if (nextRec > recCapacity) {   // grow the record arena (device idle: we hold `mu` and sync every call)
         uint32_t cap = recCapacity;
         while (cap < nextRec) cap *= 2;
@@ -1723,7 +1744,8 @@ void Engine::enqueueBlock(const Plan& p, float* outRing) {
         if (ce > cb) launch_convolve(stream, p.view, dRecs, dHbm, dGlobals, cb, ce - cb);
         if (!p.hosts.empty()) (void)renderHostNodes(p, l);
     }
-    launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, outRing);
+    launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, outRing, armFlag, armValue);
+    if (armFlag) flagArmed = true;
     debugSync("block: epilogue");
 }
 
@@ -1783,8 +1805,23 @@ void Engine::mirrorRootFades(const Plan& p, uint32_t n, uint32_t nOut, uint32_t 
     }
 }
 
+// A host block longer than the engine's: slice `off / blockSize` of it renders the frames [off, off + blockSize) — and a tap's delay
+// is the HOST's block (TapOutNode::promoteTapBuffers copies numSamples frames of its delay buffer to the shared one, TapInNode copies
+// numSamples frames back out: Feedback.h:88-109, 40-54), so the slice reads and promotes ITS stretch of the shared buffers: the tap
+// records' shared-buffer pointers move with the slice (parameter patches, applied in front of the slice's kernels).
+void Engine::setTapSlice(size_t off) {
+    if (off == tapSliceOff) return;
+    tapSliceOff = off;
+    if (dry) return;
+    for (int32_t id : tapNodeIds) {
+        auto it = nodes.find(id);
+        if (it == nodes.end() || !it->second.res || !it->second.res->dev.ptr) continue;
+        writeParamPtr(it->second, rec::TAP_SHARED, reinterpret_cast<const float*>(it->second.res->dev.ptr) + off);
+    }
+}
+
 int Engine::process(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n, int64_t sampleTime) {
-    if (n <= (size_t)blockSize || hostBlockSize == blockSize) return processSlice(in, nIn, out, nOut, n, sampleTime);
+    if (hostBlockSize == blockSize) return processSlice(in, nIn, out, nOut, n, sampleTime);
     if (n > (size_t)hostBlockSize) return kBlockTooLarge;
     if (nIn > kMaxHostIn || nOut > kMaxOutBus) return kTooManyChannels;
     // a host block longer than the engine's: slice by slice (each slice is a block of its own to the kernels), the render lock held
@@ -1793,9 +1830,10 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
     std::vector<const float*> ip(nIn);
     std::vector<float*> op(nOut);
     std::lock_guard<std::mutex> lock(mu);
-    for (size_t off = 0; off < n; off += (size_t)blockSize) {
+    for (size_t off = 0; off < n || off == 0; off += (size_t)blockSize) {
         for (size_t c = 0; c < nIn; ++c) ip[c] = in[c] + off;
         for (size_t c = 0; c < nOut; ++c) op[c] = out[c] + off;
+        if (!tapNodeIds.empty()) setTapSlice(off);
         const int rc = processSliceLocked(ip.data(), nIn, op.data(), nOut, std::min((size_t)blockSize, n - off), sampleTime + (int64_t)off, off == 0);
         if (rc != kOk) return rc;
     }
@@ -1815,6 +1853,7 @@ int Engine::processSliceLocked(const float* const* in, size_t nIn, float* const*
     if (n > (size_t)blockSize) return kBlockTooLarge;
     if (nIn > kMaxHostIn || nOut > kMaxOutBus) return kTooManyChannels;
     if (n != conv::kBlock) convAligned = false;   // a convolver's input block may now be partly filled at a call boundary
+    if (residentLive && (pending || !residentOpt)) residentStop();
     int rc = adopt ? swapInPending() : kOk;
     if (rc != kOk) return rc;
     if (!current) return kOk;   // no render sequence yet: outputs untouched (Runtime.h:287-289)
@@ -1830,6 +1869,21 @@ int Engine::processSliceLocked(const float* const* in, size_t nIn, float* const*
     setInRing(nullptr, 0);
     rc = ensureOutRing(std::max<size_t>(nOut, 1) * blockSize);
     if (rc != kOk) return rc;
+    // option "resident": a run of plain blocks (nothing to flush, every fade settled, the same plan and channel counts) is handed
+    // to the resident kernel through mapped host memory — no launch, no stream synchronise
+    {
+        const bool plain = residentOpt && n == (size_t)blockSize && residentEligible(p, nIn, nOut);
+        if (residentLive && (!plain || residentPlan != &p || residentNIn != nIn || residentNOut != nOut)) residentStop();
+        if (!plain) residentStreak = 0;
+        else if (!residentLive && ++residentStreak > residentAfter) {
+            rc = residentStart(p, nIn, nOut);
+            if (rc != kOk) return rc;
+        }
+        if (residentLive) {
+            rc = residentBlock(in, nIn, out, nOut, n);
+            if (rc != kResidentGone) return rc;
+        }
+    }
     // A whole block of a settled sequence whose island shapes are all compiled goes through the specialised kernels as a
     // launch set of one (stages pipelined inside the workgroup, no interpreter image); everything else block by block.
     const bool specLevels = n == (size_t)blockSize && specBlockOk(p);
@@ -1871,6 +1925,18 @@ int Engine::processSliceLocked(const float* const* in, size_t nIn, float* const*
         }
         outDev = hostOutDirect ? hOutDev : nullptr;
     }
+    // the call ends when the epilogue's word arrives (sync_poll): only when the epilogue writes the host's block itself, nothing is
+    // being profiled and no hipGraph replays the launches (a captured launch would publish a stale value)
+    const bool graphPath = specBlock && specBlockGraph && useGraph && !profileLaunches && !debugSyncOn();
+    flagArmed = false; armFlag = nullptr;
+    if (syncPoll && outDev && !graphPath && !profileLaunches && !debugSyncOn() && p.hosts.empty()) {
+        if (!hDone) {
+            HIP_OK(hipHostMalloc((void**)&hDone, 64, hipHostMallocMapped | hipHostMallocCoherent));
+            *hDone = 0;
+            HIP_OK(hipHostGetDevicePointer((void**)&dDone, hDone, 0));
+        }
+        armFlag = dDone; armValue = ++doneSeq;
+    }
     if (specBlock && specBlockGraph && useGraph && !profileLaunches && !debugSyncOn()) {
         // the launch set of one (level launches, side-stream forks and joins, batch epilogue) replayed from a captured graph
         float* const target = outDev ? outDev : dOutRing;
@@ -1894,8 +1960,32 @@ int Engine::processSliceLocked(const float* const* in, size_t nIn, float* const*
     else if (specFade) enqueueSpecBlock(p, outDev);
     else { fixConvOverlaps(p); enqueueBlock(p, outDev); }
     if (nOut > 0 && !outDev) HIP_OK(hipMemcpyAsync(hOut, dOutRing, nOut * (size_t)blockSize * sizeof(float), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
-    HIP_OK(hipGetLastError());
+    armFlag = nullptr;
+    bool arrived = false;
+    if (flagArmed) {
+        // spin on the epilogue's word (2 ms at most: a graph that takes longer gains nothing from it; a kernel that faulted never
+        // publishes — the synchronise below reports it)
+        const uint32_t want = armValue;
+        uint32_t spins = 0;
+        std::chrono::steady_clock::time_point t0;
+        for (;;) {
+            if (__atomic_load_n(hDone, __ATOMIC_ACQUIRE) == want) { arrived = true; break; }
+            __builtin_ia32_pause();
+            if ((++spins & 0x3FFu) == 0u) {
+                const auto now = std::chrono::steady_clock::now();
+                if (spins == 0x400u) t0 = now;
+                else if (now - t0 > std::chrono::milliseconds(2)) break;
+            }
+        }
+        flagArmed = false;
+        syncPolls++;
+        if (!arrived) syncPollFallbacks++;
+    }
+    // (every 256th call still synchronises: the runtime retires its launch bookkeeping there)
+    if (!arrived || (++unsyncedCalls & 255u) == 0u) {
+        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipGetLastError());
+    }
     if (profUsed) profCollect();
     for (size_t c = 0; c < nOut; ++c) std::memcpy(out[c], hOut + c * blockSize, n * sizeof(float));
     mirrorRootFades(p, (uint32_t)n, (uint32_t)nOut, (uint32_t)nIn);
@@ -1906,8 +1996,112 @@ int Engine::processSliceLocked(const float* const* in, size_t nIn, float* const*
     return kOk;
 }
 
+// ---- option "resident" (resident.hip) -------------------------------------------------------------------------------------------
+bool Engine::residentEligible(const Plan& p, size_t nIn, size_t nOut) const {
+    if (!p.convs.empty() || !p.hosts.empty() || profileLaunches || debugSyncOn() || hGlobals.trace) return false;
+    if (!patches.empty() || !freshRecs.empty() || !recClones.empty()) return false;
+    if (p.view.numRoots > kResidentMaxRoots || p.levelOffsets.size() < 2 || p.levelOffsets.size() - 1 > kResidentMaxLevels) return false;
+    if (p.levelOffsets.back() == 0u) return false;
+    return batchEligible(p, nOut, true);      // every running root's fade settled: the epilogue has no per-root state to advance
+}
+
+int Engine::residentStart(const Plan& p, size_t nIn, size_t nOut) {
+    if (!hResident) {
+        HIP_OK(hipHostMalloc((void**)&hResident, sizeof(ResidentCtl), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_OK(hipHostGetDevicePointer((void**)&dResidentCtl, hResident, 0));
+        HIP_OK(hipMalloc((void**)&dResidentSync, 64));
+    }
+    const size_t inF = std::max<size_t>(nIn, 1) * (size_t)blockSize, outF = std::max<size_t>(nOut, 1) * (size_t)blockSize;
+    if (inF > resInFloats) {
+        if (hResIn) (void)hipHostFree(hResIn);
+        hResIn = nullptr; resInFloats = 0;
+        HIP_OK(hipHostMalloc((void**)&hResIn, inF * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_OK(hipHostGetDevicePointer((void**)&dResIn, hResIn, 0));
+        resInFloats = inF;
+    }
+    if (outF > resOutFloats) {
+        if (hResOut) (void)hipHostFree(hResOut);
+        hResOut = nullptr; resOutFloats = 0;
+        HIP_OK(hipHostMalloc((void**)&hResOut, outF * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_OK(hipHostGetDevicePointer((void**)&dResOut, hResOut, 0));
+        resOutFloats = outF;
+    }
+    ResidentLevels lv{};
+    lv.count = (uint32_t)p.levelOffsets.size() - 1;
+    uint32_t widest = 1;
+    for (uint32_t l = 0; l <= lv.count; ++l) lv.offset[l] = p.levelOffsets[l];
+    for (uint32_t l = 0; l < lv.count; ++l) widest = std::max(widest, lv.offset[l + 1] - lv.offset[l]);
+    // one workgroup per compute unit at most: every workgroup has to be ON the device for the barriers between the levels to complete
+    const uint32_t groups = std::min<uint32_t>(widest, (uint32_t)std::max(1, cuCount));
+    if (p.maxLdsBytes > residentLdsConfigured) {
+        HIP_OK(configure_resident(p.maxLdsBytes));
+        residentLdsConfigured = p.maxLdsBytes;
+    }
+    std::memset(hResident, 0, sizeof(ResidentCtl));
+    HIP_OK(hipMemsetAsync(dResidentSync, 0, 64, stream));
+    const uint64_t idleTicks = (uint64_t)residentIdleUs * 100ull, hangTicks = 5ull * 100000000ull;   // s_memrealtime: 100 MHz
+    HIP_OK(launch_resident(stream, p.view, dRecs, dHbm, dGlobals, dLcg, lv, groups, std::max<uint32_t>(p.maxLdsBytes, 1024u), dResidentCtl, dResIn, dResOut,
+                           dResidentSync, idleTicks, hangTicks));
+    residentTicksBody = residentTicksEpilogue = 0;
+    residentLive = true; residentSeq = 0; residentPlan = &p; residentNIn = nIn; residentNOut = nOut;
+    st.residentLaunches++;
+    return kOk;
+}
+
+void Engine::residentStop() {
+    if (!residentLive) return;
+    __atomic_store_n(&hResident->seq, kResidentQuit, __ATOMIC_RELEASE);
+    HIP_WARN(hipStreamSynchronize(stream));
+    if (__atomic_load_n(&hResident->exited, __ATOMIC_ACQUIRE) == 2u)
+        std::fprintf(stderr, "[elemhip] resident kernel: a device-wide barrier timed out; the block it was rendering is lost\n");
+    residentLive = false; residentStreak = 0; residentPlan = nullptr;
+    static const bool trace = std::getenv("ELEMHIP_RESIDENT_TRACE") != nullptr;
+    if (trace && residentSeq)
+        std::fprintf(stderr, "[elemhip] resident kernel left after %u blocks: levels %.2f us, epilogue %.2f us per block (device clock, from the block number's arrival)\n",
+                     residentSeq, 0.01 * (double)residentTicksBody / residentSeq, 0.01 * (double)residentTicksEpilogue / residentSeq);
+}
+
+int Engine::residentBlock(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n) {
+    for (size_t c = 0; c < nIn; ++c) std::memcpy(hResIn + c * blockSize, in[c], n * sizeof(float));
+    const uint32_t seq = ++residentSeq;
+    __atomic_store_n(&hResident->seq, seq, __ATOMIC_RELEASE);
+    uint32_t spins = 0;
+    std::chrono::steady_clock::time_point t0;
+    for (;;) {
+        if (__atomic_load_n(&hResident->done, __ATOMIC_ACQUIRE) == seq) break;
+        if (__atomic_load_n(&hResident->exited, __ATOMIC_ACQUIRE) != 0u) {
+            // it left: by itself (idle) before it saw this block, or on a barrier time-out
+            const bool rendered = __atomic_load_n(&hResident->done, __ATOMIC_ACQUIRE) == seq;
+            const uint32_t code = hResident->exited;
+            HIP_WARN(hipStreamSynchronize(stream));
+            residentLive = false; residentStreak = 0; residentPlan = nullptr;
+            if (rendered) break;
+            if (code == 2u) return kHipError;
+            return kResidentGone;
+        }
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFu) == 0u) {
+            const auto now = std::chrono::steady_clock::now();
+            if (spins == 0x1000u) t0 = now;
+            else if (now - t0 > std::chrono::seconds(10)) {      // (the kernel's own time-outs are 5 s: this is a kernel that never started)
+                __atomic_store_n(&hResident->seq, kResidentQuit, __ATOMIC_RELEASE);
+                HIP_WARN(hipStreamSynchronize(stream));
+                residentLive = false; residentStreak = 0; residentPlan = nullptr;
+                return kHipError;
+            }
+        }
+    }
+    for (size_t c = 0; c < nOut; ++c) std::memcpy(out[c], hResOut + c * blockSize, n * sizeof(float));
+    residentTicksBody += hResident->ticksBody; residentTicksEpilogue += hResident->ticksEpilogue;
+    curBlockTime = hGlobals.sampleTime;
+    hGlobals.sampleTime += (int64_t)n;
+    st.blocksRendered++; st.residentBlocks++;
+    islandBlocksInterp += current->levelOffsets.back();
+    return kOk;
+}
+
 int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap) {
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     if (dry) return -kNoDevice;
     if (hipSetDevice(device) != hipSuccess) return -kHipError;
     int rc = swapInPending();
@@ -1970,7 +2164,7 @@ int Engine::timeLaunches(size_t nOut, size_t numBlocks, float* msOut, size_t cap
 }
 
 int Engine::traceLevel(size_t nOut, uint32_t level, unsigned long long* out, size_t cap) {
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     if (dry) return kNoDevice;
     if (hipSetDevice(device) != hipSuccess) return kHipError;
     int rc = swapInPending();
@@ -2091,7 +2285,7 @@ void Engine::profCollect() {
 // debug / tests: program text and compile state of the k-th specialised shape of the newest plan
 int Engine::specInfo(size_t k, std::string* source, std::string* log, int* state, uint32_t* islands) {
     std::lock_guard<std::mutex> control(ctl);
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     const std::shared_ptr<Plan> pl = pending ? pending : current;
     if (!pl || k >= pl->shapes.size()) return -1;
     const Plan::SpecShape& sh = pl->shapes[k];
@@ -2103,7 +2297,7 @@ int Engine::specInfo(size_t k, std::string* source, std::string* log, int* state
 }
 
 int Engine::launchProfile(double* msOut, size_t cap, uint64_t* launchSets, uint64_t* blocks) {
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     if (launchSets) *launchSets = profSets;
     if (blocks) *blocks = profBlocks;
     const size_t n = std::min(cap, profMs.size());
@@ -2297,8 +2491,10 @@ void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
         const int64_t t = hGlobals.sampleTime + (int64_t)blockSize * (int64_t)batch;
         patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, sampleTime) / 4), (uint32_t)((uint64_t)t & 0xFFFFFFFFu), 0u});
         patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, sampleTime) / 4 + 1), (uint32_t)((uint64_t)t >> 32), 0u});
-    } else if (!fused) launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, outRing, batch, arenaFloats);
-    else st.fusedEpilogues++;
+    } else if (!fused) {
+        launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, outRing, batch, arenaFloats, armFlag, armValue);
+        if (armFlag && batch == 1u) flagArmed = true;
+    } else st.fusedEpilogues++;
     debugSync("set: epilogue", batch);
     if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)L); profSets++; profBlocks += batch; }
 }
@@ -2310,13 +2506,14 @@ void Engine::enqueueSpecBlock(const Plan& p, float* outRing) {
     const uint32_t arenaFloats = p.numHbmBuffers * (uint32_t)blockSize;
     const size_t L = p.levelOffsets.size() - 1;
     for (size_t l = 0; l < L; ++l) (void)launchLevelBatch(p, l, 1u, arenaFloats);
-    launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, outRing);
+    launch_epilogue(stream, p.view, dRecs, dHbm, dGlobals, outRing, armFlag, armValue);
+    if (armFlag) flagArmed = true;
     debugSync("block: specialised levels + epilogue");
     st.specFadeBlocks++;
 }
 
 int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime) {
-    std::lock_guard<std::mutex> lock(mu);
+    RenderGuard lock(*this);
     if (dry) return kNoDevice;
     if (hostBlockSize != blockSize) return kBlockTooLarge;     // (the device-resident layout is [block][channel][blockSize <= 512])
     if (hipSetDevice(device) != hipSuccess) return kHipError;
@@ -2514,11 +2711,36 @@ int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* 
     const size_t bs = (size_t)blockSize;
     // whole HOST blocks, like the reference's block loop (a host block = hostBlockSize / blockSize engine blocks)
     const size_t hb = (size_t)hostBlockSize;
+    bool tapSlices = false;
+    if (hb != bs) { std::lock_guard<std::mutex> lock(mu); tapSlices = !tapNodeIds.empty(); }
+    if (tapSlices) {
+        // taps under a host block longer than the engine's: every slice needs its own stretch of the shared tap buffers (setTapSlice),
+        // which launch sets do not do — host block by host block through process()
+        std::vector<const float*> ip(nIn);
+        std::vector<float*> op(nOut);
+        std::vector<float> tailIn, tailOut;
+        for (size_t f0 = 0; f0 < numFrames; f0 += hb) {
+            const size_t nf = std::min(hb, numFrames - f0);
+            for (size_t c = 0; c < nIn; ++c) ip[c] = in[c] + f0;
+            for (size_t c = 0; c < nOut; ++c) op[c] = out[c] + f0;
+            if (nf < hb) {
+                // the last, partly filled host block is still a whole block to the engine (offline-renderer/index.ts:104-131: inputs
+                // padded with zeros, the frames beyond the caller's arrays dropped)
+                tailIn.assign(nIn * hb, 0.0f); tailOut.assign(nOut * hb, 0.0f);
+                for (size_t c = 0; c < nIn; ++c) { std::memcpy(tailIn.data() + c * hb, in[c] + f0, nf * sizeof(float)); ip[c] = tailIn.data() + c * hb; }
+                for (size_t c = 0; c < nOut; ++c) op[c] = tailOut.data() + c * hb;
+            }
+            const int rc = process(ip.data(), nIn, op.data(), nOut, hb, sampleTime + (int64_t)f0);
+            if (rc != kOk) return rc;
+            if (nf < hb) for (size_t c = 0; c < nOut; ++c) std::memcpy(out[c] + f0, tailOut.data() + c * hb, nf * sizeof(float));
+        }
+        return kOk;
+    }
     const size_t numBlocks = ((numFrames + hb - 1) / hb) * (hb / bs);
     if (numBlocks == 0) return kOk;
     size_t setBlocks;
     {
-        std::lock_guard<std::mutex> lock(mu);
+        RenderGuard lock(*this);
         if (hipSetDevice(device) != hipSuccess) return kHipError;
         setBlocks = (size_t)std::max(1, batchBlocks);
         if (setBlocks < 8) setBlocks = std::min<size_t>(64, numBlocks);     // per-block launch path: still stage whole chunks
@@ -2574,7 +2796,7 @@ int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* 
             }
         }
         {
-            std::lock_guard<std::mutex> lock(mu);
+            RenderGuard lock(*this);
             if (hipSetDevice(device) != hipSuccess) { result = kHipError; break; }
             if (nIn) {
                 // (the copy stream is in order: this H2D runs behind the D2H of set k - 2, which waited for that set's render,
@@ -2606,7 +2828,7 @@ int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* 
         else if (nOut) scatter(last);
     }
     {
-        std::lock_guard<std::mutex> lock(mu);
+        RenderGuard lock(*this);
         if (hipStreamSynchronize(stream) != hipSuccess) result = result == kOk ? kHipError : result;
         if (hipStreamSynchronize(ioStream) != hipSuccess) result = result == kOk ? kHipError : result;
         if (hipGetLastError() != hipSuccess && result == kOk) result = kHipError;

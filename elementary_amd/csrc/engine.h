@@ -164,9 +164,14 @@ struct Stats {
     uint32_t specShapes = 0, specIslands = 0;
     double   lastJitWaitMs = 0.0;
     double   lastGraphCaptureMs = 0.0;     // capture + instantiate of the per-block hipGraph of the current plan
+    uint64_t residentLaunches = 0, residentBlocks = 0;   // option "resident": launches of the resident kernel / blocks it rendered
 };
 
+struct ResidentCtl;     // launch.h
+struct RenderGuard;     // engine.cpp
+
 class Engine {
+    friend struct RenderGuard;
 public:
     Engine(double sampleRate, int blockSize, int device);
     ~Engine();
@@ -229,6 +234,9 @@ private:
     bool dry = false;                      // device == -1: host logic only, cannot render
     double sampleRate;
     int blockSize;                         // the engine's block: <= kMaxBlock frames (one LDS slot per buffer)
+    std::vector<int32_t> tapNodeIds;       // every tapIn / tapOut node alive (setTapSlice)
+    size_t tapSliceOff = 0;                // frames: where in the shared tap buffers the tap records point right now
+    void setTapSlice(size_t off);
     int hostBlockSize = 0;                 // what the host created the runtime with: blockSize, or a multiple of kMaxBlock rendered in slices
     int device;
     hipStream_t stream = nullptr;
@@ -308,6 +316,33 @@ private:
 
     std::shared_ptr<Plan> current, pending;
     uint32_t maxLdsConfigured = 0;
+    // ---- elemhip_process ends by spinning on a word the block's epilogue kernel publishes to mapped host memory behind the output block,
+    // not by synchronising the stream (option "sync_poll", default 1; island.inc publish_done) ----
+    bool syncPoll = true;
+    uint32_t* hDone = nullptr; uint32_t* dDone = nullptr;     // the word: host / device address
+    uint32_t doneSeq = 0;
+    uint32_t* armFlag = nullptr; uint32_t armValue = 0;        // what the epilogue launch of the call being enqueued publishes (null: nothing)
+    bool flagArmed = false;                                    // ... and whether an epilogue kernel took it
+    uint32_t unsyncedCalls = 0;                                // calls since the stream was last synchronised for real
+    uint64_t syncPolls = 0, syncPollFallbacks = 0;
+    // ---- option "resident": elemhip_process through a kernel that stays on the GPU between calls (resident.hip) ----
+    bool residentOpt = false;
+    uint32_t residentIdleUs = 2000;        // option "resident_idle_us": the kernel leaves by itself after this long without a block
+    uint32_t residentAfter = 3;            // ... and is launched once this many plain blocks in a row went through the launch path
+    bool residentLive = false;             // the kernel is (or may still be) on `stream`
+    uint32_t residentSeq = 0, residentStreak = 0;
+    const Plan* residentPlan = nullptr; size_t residentNIn = 0, residentNOut = 0;
+    ResidentCtl* hResident = nullptr; ResidentCtl* dResidentCtl = nullptr;   // mapped host memory, host / device address
+    float* hResIn = nullptr; float* hResOut = nullptr; const float* dResIn = nullptr; float* dResOut = nullptr; size_t resInFloats = 0, resOutFloats = 0;
+    unsigned long long* dResidentSync = nullptr;
+    uint32_t residentLdsConfigured = 0;
+    uint64_t residentTicksBody = 0, residentTicksEpilogue = 0;   // ELEMHIP_RESIDENT_TRACE: device-side phase times of this residency
+    bool residentEligible(const Plan& p, size_t nIn, size_t nOut) const;
+    int residentStart(const Plan& p, size_t nIn, size_t nOut);
+    void residentStop();                   // (`mu` held) ask the kernel to leave and wait until it has; a no-op when it is not there
+    // renders one block through the live kernel: kOk, an error, or kResidentGone — it left (idle) before it saw the block: launch path
+    int residentBlock(const float* const* in, size_t nIn, float* const* out, size_t nOut, size_t n);
+    static constexpr int kResidentGone = -1000;
     bool useGraph = true;
     int  graphBlocks = 8;
     bool hostOutDirect = true;             // process(): the epilogue kernel writes into the mapped pinned output block

@@ -1900,6 +1900,7 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
     const auto tUpload = std::chrono::steady_clock::now();
     p.buildUs[4] = std::chrono::duration<double, std::micro>(tUpload - tTables).count();
     renderLock.lock();   // ---- from here on: render-side state ----
+    residentStop();
     st.specShapes = (uint32_t)p.shapes.size(); st.specIslands = (uint32_t)p.specLists.size();
     if (jitWaitMs >= 0.0) st.lastJitWaitMs = jitWaitMs;
     // root records learn whether fade.process() runs on them (Core.h:74-77)
@@ -1976,6 +1977,8 @@ std::string Engine::describePlan() {
                       (unsigned long long)js.diskFilesRemoved, js.workers);
         s += b;
     }
+    kv("sync_poll", syncPoll ? 1 : 0); kv("sync_polls", syncPolls); kv("sync_poll_fallbacks", syncPollFallbacks);
+    kv("resident", residentOpt ? 1 : 0); kv("resident_launches", st.residentLaunches); kv("resident_blocks", st.residentBlocks);
     kv("conv_direct_io_sets", convDirectSets); kv("conv_long_sets", convLongSets); kv("conv_long", convLong ? 1 : 0); kv("conv_max_long_tap_rows", convMaxQp);
     kv("num_taps", p.taps.size()); kv("taps_in_sets", p.tapsInSets ? 1 : 0); kv("num_tap_nodes", p.taps.size() + p.tapPairs.size()); kv("num_convs", p.convs.size()); kv("conv_workgroups", p.convWork.size());
     s += "\"level_sizes\":[";

@@ -70,6 +70,7 @@ class _Stats(C.Structure):
         ("num_nodes_in_plan", C.c_uint32), ("max_lds_bytes", C.c_uint32), ("num_hbm_buffers", C.c_uint32),
         ("graph_replays", C.c_uint64), ("graph_captures", C.c_uint64), ("batch_launches", C.c_uint64),
         ("spec_launches", C.c_uint64), ("spec_shapes", C.c_uint32), ("spec_islands", C.c_uint32), ("last_jit_wait_ms", C.c_double), ("last_graph_capture_ms", C.c_double),
+        ("resident_launches", C.c_uint64), ("resident_blocks", C.c_uint64),
     ]
 
 

@@ -25,7 +25,8 @@
  * block's buffers in LDS slots of at most 512 frames. blockSize <= 512: as given. Above 512 (up to 32768): accepted when the block
  * splits into k EQUAL slices of 64 .. 512 frames (1024 = 2 x 512, 700 = 2 x 350, 1023 = 3 x 341; the smallest such k is taken):
  * elemhip_process / elemhip_process_blocks_host render such a block slice by slice — the same samples for every node that works at
- * the sample rate; a graph with tapIn / tapOut (whose delay IS the block, Feedback.h:90-126) is refused at commit (code 104),
+ * the sample rate; tapIn / tapOut, whose delay IS the host's block (Feedback.h:29-31, 88-109), keep tap buffers of the HOST's block
+ * size and every slice reads / promotes its own stretch of them (r04 refused such graphs with code 104);
  * `meter` reports the last slice of a block, and the device-resident elemhip_process_blocks (whose layout is in blocks) answers
  * 102. A size above 512 that no such k divides (a prime): elemhip_create fails (code 102).
  */
@@ -52,10 +53,11 @@ typedef struct elemhip_stats {
     uint32_t spec_shapes, spec_islands;   /* distinct specialised island shapes / islands they cover in the current plan */
     double   last_jit_wait_ms;    /* time the last commit waited for kernel compilation (option "specialize" = 2) */
     double   last_graph_capture_ms; /* hipGraph capture + instantiate of the current plan's per-block launch sequence */
+    uint64_t resident_launches, resident_blocks;   /* option "resident": launches of the resident kernel / blocks it rendered */
 } elemhip_stats;
 
 /* Runtime(double sampleRate, int blockSize)                      runtime/elem/Runtime.h:44,157-166
- * blockSize is the MAX frames per process call (<= 512). Returns NULL on failure; the reason is
+ * blockSize is the MAX frames per process call (see "Block size" above). Returns NULL on failure; the reason is
  * available from elemhip_last_create_error(). */
 elemhip_t* elemhip_create(double sampleRate, int blockSize, int deviceOrdinal);
 void       elemhip_destroy(elemhip_t*);

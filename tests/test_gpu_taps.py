@@ -130,3 +130,34 @@ def test_tap_graph_swap_between_sets(gpu_required):
     got, ref = np.concatenate(out_a), np.concatenate(out_c)
     assert float(np.abs(got - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
     assert a.stats()["batch_launches"] > 0
+
+
+@pytest.mark.parametrize("bs", [1024, 700, 1536])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_taps_under_host_blocks_longer_than_512_frames(gpu_required, name, bs):
+    """Runtime(sr, blockSize > 512): a tap's delay is the HOST's block (Feedback.h:29-31, 66-67: buffers of getBlockSize() frames;
+    :40-54, 88-109: numSamples frames copied per block), while the engine renders the block as slices of at most 512 frames. Every
+    slice reads and promotes its own stretch of host-block-sized tap buffers (Engine::setTapSlice) — r04 refused such graphs (104).
+    Full blocks, a short block, a one-slice block, then the offline block loop with a ragged tail, against the reference engine
+    created with the same block size."""
+    roots_fn, n_in, _ = CASES[name]
+    a, c = _hip(48000.0, bs), _checker(48000.0, bs)
+    assert a.render(*roots_fn())["result"] == 0 and c.render(*roots_fn())["result"] == 0
+    n_out = len(roots_fn())
+    k = 0
+    for n in (bs, bs, bs, bs * 2 // 3 + 1, bs, min(512, bs - 1), bs, bs, bs):
+        x = np.stack([lcg_noise(n, 31 + 7 * k + ch, 0.5) for ch in range(n_in)])
+        got, ref = a.process(x, n_out, n), c.process(x, n_out, n)
+        assert float(np.abs(got - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max())), (name, bs, k, n)
+        k += 1
+    frames = 6 * bs + 211
+    x = np.stack([lcg_noise(frames, 77 + ch, 0.5) for ch in range(n_in)])
+    got = a.process_blocks_host(x, n_out, frames)
+    nb = (frames + bs - 1) // bs
+    xp = np.zeros((n_in, nb * bs), dtype=np.float32)
+    xp[:, :frames] = x
+    ref = np.concatenate([c.process(xp[:, b * bs:(b + 1) * bs], n_out, bs) for b in range(nb)], axis=1)[:, :frames]
+    assert float(np.abs(got - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max())), (name, bs)
+    x = np.stack([lcg_noise(bs, 5 + ch, 0.5) for ch in range(n_in)])
+    got, ref = a.process(x, n_out, bs), c.process(x, n_out, bs)                # the state after the ragged tail is the reference's
+    assert float(np.abs(got - ref).max()) <= TOL * max(1.0, float(np.abs(ref).max()))
