@@ -44,7 +44,7 @@ static std::string opndExpr(const SpecProgram& sp, uint32_t code, uint32_t tabWo
 }
 
 std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, const SpecProgram& sp,
-                           const std::vector<uint32_t>& stageTab, uint32_t blockSize) {
+                           const std::vector<uint32_t>& stageTab, uint32_t blockSize, uint32_t wavesPerEu) {
     const std::vector<Member>& members = sp.members;
     const std::vector<uint32_t>& operands = sp.operands;
     const uint32_t tabWord = I.ldsProg + I.recOff + I.numRecs;   // LDS word of the staged arena table
@@ -166,7 +166,11 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
     o << "    static constexpr int waveSlots[8] = {";
     for (uint32_t w = 0; w < kWaves; ++w) o << (w ? ", " : "") << waveSlots[w];
     o << "};\n};\n} // namespace gen\n";
-    o << "extern \"C\" __global__ __launch_bounds__(512) void elemhip_spec_island(PlanView pv, uint32_t* recs, float* hbm, const Globals* g,\n"
+    // option "spec_waves_per_eu" (0: the compiler's choice): ask for this many waves per SIMD, i.e. cap the registers so that TWO eight-wave
+    // workgroups fit a CU (4 -> 128 VGPRs); with islands of <= 80 KB of LDS a level of more islands than CUs then renders in one round
+    o << "extern \"C\" __global__ __launch_bounds__(512) ";
+    if (wavesPerEu) o << "__attribute__((amdgpu_waves_per_eu(" << wavesPerEu << ", " << wavesPerEu << "))) ";
+    o << "void elemhip_spec_island(PlanView pv, uint32_t* recs, float* hbm, const Globals* g,\n"
          "        const uint32_t* lcg, const uint32_t* islandList, uint32_t batch, uint32_t arenaFloats, uint32_t streamBase, uint32_t streamSlice,\n"
          "        uint32_t epiGroups, float* epiOut) {\n"
          "    spec_island_main<gen::P>(pv, recs, hbm, g, lcg, islandList, batch, arenaFloats, streamBase, streamSlice);\n"

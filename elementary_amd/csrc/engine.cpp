@@ -1589,6 +1589,7 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "solo_waves") { soloWaves = (uint32_t)std::max(0, std::min(3, (int)value)); planStale = true; return kOk; }
     if (key == "mixer_split") { const int v = (int)value; mixerSplit = (v == 2 || v == 4 || v == 8) ? (uint32_t)v : 1u; planStale = true; return kOk; }
     if (key == "stateless_rows") { statelessRows = (uint32_t)std::max(1, std::min(64, (int)value)); return kOk; }   // gridDim.y of a multi-block launch: blocks that stateless islands render side by side
+    if (key == "spec_waves_per_eu") { specWavesPerEu = std::max(0, std::min(8, (int)value)); specTextCache.clear(); islandCache.clear(); islandShapeCache.clear(); planStale = true; return kOk; }
     if (key == "pipeline_copies") { pipelineCopies = std::max(1, std::min(6, (int)value)); planStale = true; return kOk; }   // next commit re-plans
 #ifdef ELEMHIP_EXPERIMENTAL
     if (key == "stream_ring") { streamRing = value != 0.0; return kOk; }   // 0: measurement only, needs kernels built with ELEMHIP_STREAM_PER_BLOCK

@@ -365,6 +365,7 @@ private:
     bool specBlockGraph = false;           // option "spec_block_graph": replay elemhip_process' launch set of one from a captured hipGraph
     bool specBlocks = true;                // process(): whole blocks of a settled, fully compiled sequence use the specialised kernels
     int  batchBlocks = 64;                 // blocks per multi-block launch in processBlocks (1 = per-block launches)
+    int  specWavesPerEu = 0;               // option "spec_waves_per_eu": amdgpu_waves_per_eu of the specialised kernels (0: the compiler's choice; 4: two workgroups per CU)
     int  pipelineCopies = 6;               // blocks a stateful island keeps in flight inside a multi-block launch
     bool convAligned = true;               // every process call so far rendered whole 512-frame blocks (conv.hip batch path)
     float* dConvScratch = nullptr; size_t convScratchFloats = 0;

@@ -81,7 +81,7 @@ uint32_t leafArityOfOp(uint16_t op);
 } // namespace
 uint32_t leafArityForCodegen(uint16_t op) { return leafArityOfOp(op); }
 std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, const SpecProgram& sp,
-                           const std::vector<uint32_t>& stageTab, uint32_t blockSize);   // codegen.cpp
+                           const std::vector<uint32_t>& stageTab, uint32_t blockSize, uint32_t wavesPerEu);   // codegen.cpp
 namespace {
 uint32_t leafArityOfOp(uint16_t op) {
     if (op == OP_SAW_SHAPE || op == OP_SQUARE_SHAPE || op == OP_PHASE) return 1;
@@ -1633,11 +1633,11 @@ std::shared_ptr<Plan> PlanBuilder::build(uint32_t maxIslandNodes, uint32_t maxCo
             for (uint32_t o : sp.phaseOp) mix((o & kOpKindMask) == kOpHbm ? (kOpHbm | arenaPos(o & kOpValMask)) : o);
             for (uint8_t g : sp.gdirect) mix(g);
             for (uint32_t k = 0; k < 2 * S; ++k) mix(stageTab[k]);
-            mix(bs); mix((uint32_t)sp.hbmTab.size());
+            mix(bs); mix((uint32_t)sp.hbmTab.size()); mix((uint32_t)e.specWavesPerEu);
             auto it = e.specTextCache.find(h);
             if (it == e.specTextCache.end()) {
                 auto txt = std::make_shared<SpecText>();
-                txt->text = emitSpecSource(I, tasks, sp, stageTab, bs);
+                txt->text = emitSpecSource(I, tasks, sp, stageTab, bs, (uint32_t)e.specWavesPerEu);
                 it = e.specTextCache.emplace(h, std::move(txt)).first;
             }
             p.specText[ii] = it->second;

@@ -323,3 +323,22 @@ def test_spec_random_graph_call_by_call(gpu_required, seed):
         scale = max(1.0, float(np.abs(ref).max()))
         assert float(np.abs(got - ref).max()) <= TOL * scale, f"seed {seed}: block {k}: {np.abs(got - ref).max():.3e}"
     assert a.stats()["spec_launches"] > 0
+
+
+def test_register_capped_kernels_render_the_same_samples(gpu_required):
+    """`spec_waves_per_eu` = 4 compiles the specialised kernels for 128 VGPRs (two eight-wave workgroups per CU, with
+    `pipeline_copies` = 3 an island also fits half a CU's LDS): a measurement option (profiles/r05/occupancy_sweep_two_workgroups_per_cu.txt:
+    slower than lane-packing at every size), and register allocation must not change a sample — the every-stateful-node graph and 24
+    synth voices, bit for bit against the default kernels."""
+    from cases import every_stateful_roots
+    for roots_fn, n_out, n_in in ((every_stateful_roots, 3, 1), (lambda: graphs.c2_graph(voices=24), 2, 0)):
+        outs = []
+        for opts in ({}, {"spec_waves_per_eu": 4, "pipeline_copies": 3}):
+            rt = _spec_runtime(48000.0, 512, batch=16)
+            for k, v in opts.items():
+                rt.set_option(k, v)
+            assert rt.render(*roots_fn())["result"] == 0
+            x = np.stack([np.stack([lcg_noise(512, 3 + b, 0.5) for _ in range(n_in)]) for b in range(48)]) if n_in else None
+            outs.append(_render_blocks(rt, 48, n_out, x))
+            assert rt.stats()["spec_launches"] > 0
+        assert np.array_equal(outs[0], outs[1])
