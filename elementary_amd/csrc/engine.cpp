@@ -2530,6 +2530,7 @@ int Engine::processBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
 // `mu` held, device current. Everything is enqueued on `stream`; the caller synchronises.
 int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t nOut, size_t numBlocks, int64_t sampleTime) {
     if (nIn > kMaxHostIn || nOut > kMaxOutBus) return kTooManyChannels;
+    armFlag = nullptr; flagArmed = false;      // (no launch set publishes elemhip_process' completion word)
     int rc = swapInPending();
     if (rc != kOk) return rc;
     if (!current || numBlocks == 0) return kOk;

@@ -462,3 +462,31 @@ def test_rccl_exchange_snippet_compiles_and_links():
                              capture_output=True, text=True)
         assert res.returncode == 0, res.stderr[-2000:]
         assert os.path.getsize(os.path.join(d, "rccl_bus_sum")) > 1000
+
+
+def test_round5_call_path_options_on_a_dry_handle():
+    """`sync_poll` (elemhip_process ends on the epilogue's word in mapped host memory), `resident` / `resident_idle_us` / `resident_after`
+    (the opt-in resident kernel) and `spec_waves_per_eu` (register cap of the generated kernels) are options every handle takes, and
+    `elemhip_describe_plan` says which way a handle waits; unknown keys are still refused; the stats struct carries the resident counters."""
+    from elementary_amd.runtime import ElemHipError
+    rt = dry(48000.0)
+    assert rt.render(el.mul(0.5, el.cycle(220.0)))["result"] == 0
+    d = rt.describe_plan()
+    assert d["sync_poll"] == 1 and d["resident"] == 0 and d["sync_polls"] == 0 and d["resident_blocks"] == 0
+    for key, val in (("sync_poll", 0), ("resident", 1), ("resident_idle_us", 500), ("resident_after", 5), ("spec_waves_per_eu", 4)):
+        rt.set_option(key, val)
+    d = rt.describe_plan()
+    assert d["sync_poll"] == 0 and d["resident"] == 1
+    st = rt.stats()
+    assert st["resident_launches"] == 0 and st["resident_blocks"] == 0
+    with pytest.raises(ElemHipError):
+        rt.set_option("resident_kernel", 1)
+    # the register cap is part of a generated kernel's text (and so of its cache key), nothing else changes
+    rt2 = dry(48000.0)
+    rt2.set_option("specialize", 2)
+    assert rt2.render(el.mul(0.5, el.cycle(220.0)))["result"] == 0
+    plain = rt2.spec_info(0)["source"]
+    rt2.set_option("spec_waves_per_eu", 4)
+    assert rt2.render(el.mul(0.25, el.cycle(221.0)))["result"] == 0
+    capped = rt2.spec_info(0)["source"]
+    assert "amdgpu_waves_per_eu(4, 4)" in capped and "amdgpu_waves_per_eu" not in plain
