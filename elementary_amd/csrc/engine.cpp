@@ -124,11 +124,16 @@ Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), devi
     // that divides it into slices of 64 .. kMaxBlock frames (1024 -> 2 x 512, 700 -> 2 x 350, 1023 -> 3 x 341; r04 took multiples of
     // 512 only) — the sample-rate nodes cannot tell; taps, whose delay IS the host's block (Feedback.h:29-31, 66-67, 103-104), keep
     // shared buffers of the HOST's block size and every slice reads / writes its own stretch of them (setTapSlice): the engine's own
-    // block size is the slice, the host's the limit of a process() call. A size no such k divides (a prime above 512) is refused.
+    // block size is the slice, the host's the limit of a process() call. A size no such k divides (a prime above 512: 521, 1031) is
+    // rendered as slices of kMaxBlock frames and a shorter last one — to the kernels the same as a host that calls process() with
+    // fewer frames than the block size (r04 / early r05 refused such sizes).
     hostBlockSize = bs;
-    if (bs > (int)kMaxBlock && bs <= 64 * (int)kMaxBlock)
+    if (bs > (int)kMaxBlock && bs <= 64 * (int)kMaxBlock) {
+        bool equal = false;
         for (int k = (bs + (int)kMaxBlock - 1) / (int)kMaxBlock; k <= bs / 64; ++k)
-            if (bs % k == 0) { bs /= k; blockSize = bs; break; }
+            if (bs % k == 0) { bs /= k; blockSize = bs; equal = true; break; }
+        if (!equal) { bs = (int)kMaxBlock; blockSize = bs; }
+    }
     if (const char* e = std::getenv("ELEMHIP_SPECIALIZE")) specialize = std::max(0, std::min(2, std::atoi(e)));
     if (const char* e = std::getenv("ELEMHIP_SYNC_POLL")) syncPoll = std::atoi(e) != 0;
     if (const char* e = std::getenv("ELEMHIP_RESIDENT")) residentOpt = std::atoi(e) != 0;   // (a native host without access to the options)
@@ -625,8 +630,8 @@ int Engine::createNode(int32_t id, const std::string& type) {   // Runtime.h:293
     auto ins = nodes.emplace(id, std::move(n));
     Node& nn = ins.first->second;
     int rc = kOk;
-    if (nn.op == OP_DELAY || nn.op == OP_SDELAY) {                                // Delays.h:56, 183
-        rc = setProperty(id, "size", Value::number((double)blockSize));
+    if (nn.op == OP_DELAY || nn.op == OP_SDELAY) {                                // Delays.h:56, 183: the default size is the HOST's block
+        rc = setProperty(id, "size", Value::number((double)hostBlockSize));
     } else if (nn.op == OP_TAPOUT) {                                              // Feedback.h:66-67
         rc = allocRing(nn, (size_t)blockSize);
         if (rc == kOk) writeParamPtr(nn, rec::TAP_PRIVATE, nn.ring.ptr);
@@ -2713,8 +2718,8 @@ int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* 
     const size_t bs = (size_t)blockSize;
     // whole HOST blocks, like the reference's block loop (a host block = hostBlockSize / blockSize engine blocks)
     const size_t hb = (size_t)hostBlockSize;
-    bool tapSlices = false;
-    if (hb != bs) { std::lock_guard<std::mutex> lock(mu); tapSlices = !tapNodeIds.empty(); }
+    bool tapSlices = hb % bs != 0;          // ragged slices (a host block that no k divides evenly): launch sets hold whole engine blocks
+    if (hb != bs && !tapSlices) { std::lock_guard<std::mutex> lock(mu); tapSlices = !tapNodeIds.empty(); }
     if (tapSlices) {
         // taps under a host block longer than the engine's: every slice needs its own stretch of the shared tap buffers (setTapSlice),
         // which launch sets do not do — host block by host block through process()

@@ -28,7 +28,9 @@
  * the sample rate; tapIn / tapOut, whose delay IS the host's block (Feedback.h:29-31, 88-109), keep tap buffers of the HOST's block
  * size and every slice reads / promotes its own stretch of them (r04 refused such graphs with code 104);
  * `meter` reports the last slice of a block, and the device-resident elemhip_process_blocks (whose layout is in blocks) answers
- * 102. A size above 512 that no such k divides (a prime): elemhip_create fails (code 102).
+ * 102. A size above 512 that no such k divides (a prime: 521, 1031): slices of 512 frames and a shorter last one. Above 32768:
+ * elemhip_create fails (code 102). Nodes that size themselves by the block (`delay` / `sdelay` without a `size`, tap buffers) use
+ * the HOST's block size, as in the reference (Delays.h:56, 183; Feedback.h:29-31).
  */
 #ifndef ELEMHIP_H
 #define ELEMHIP_H

@@ -232,7 +232,7 @@ def test_cli_benchmark_host(gpu_required):
     assert float(np.abs(got - ref).max()) <= TOL
 
 
-@pytest.mark.parametrize("bs", [1024, 2048, 700, 1023])
+@pytest.mark.parametrize("bs", [1024, 2048, 700, 1023, 521, 1031])
 def test_host_blocks_longer_than_512_frames(gpu_required, bs):
     """Runtime(sr, blockSize > 512) (the reference has no limit, Runtime.h:44): a block that is a multiple of 512 frames is rendered
     as slices of 512. elemhip_process with full and short blocks and elemhip_process_blocks_host (whole HOST blocks: the state
@@ -245,7 +245,8 @@ def test_host_blocks_longer_than_512_frames(gpu_required, bs):
         a.set_option("specialize", 2)
         assert a.render(*roots_fn())["result"] == 0 and c.render(*roots_fn())["result"] == 0
         worst, k = 0.0, 0
-        # (r05: any size that splits into equal slices of 64 .. 512 frames: 700 -> 2 x 350, 1023 -> 3 x 341)
+        # (r05: any size that splits into equal slices of 64 .. 512 frames: 700 -> 2 x 350, 1023 -> 3 x 341; a size nothing divides —
+        #  521, 1031 are primes — as slices of 512 and a shorter last one)
         for n in (bs, bs, bs * 2 // 3 + 1, bs, min(512, bs - 1), bs):          # process(): full, short and one-slice calls
             x = np.stack([lcg_noise(n, 7 + k, 0.5)]) if n_in else None
             got, ref = a.process(x, n_out, n), c.process(x, n_out, n)
@@ -270,3 +271,22 @@ def test_host_blocks_longer_than_512_frames(gpu_required, bs):
             a.process_blocks(2, n_out)
         if bs % 512 == 0:                      # (slices that are no multiple of 64 frames render through the interpreter kernels: plan.cpp specIsland)
             assert a.stats()["spec_launches"] > 0
+
+
+@pytest.mark.parametrize("bs", [1024, 521])
+def test_default_delay_sizes_follow_the_host_block(gpu_required, bs):
+    """`delay` and `sdelay` created WITHOUT a size take the block size (Delays.h:56, 183): an `sdelay` then delays by one HOST block and
+    a `delay` may reach that far back — the engine's slice (512 frames here) must not show through."""
+    from elementary_amd.runtime import Runtime
+
+    def roots():
+        x = el.in_({"channel": 0})
+        return [el.sdelay({}, x), el.delay({}, el.const({"value": float(bs - 3)}), 0.0, x)]
+    a, c = Runtime(48000.0, bs, device=0), _checker(48000.0, bs)
+    assert a.render(*roots())["result"] == 0 and c.render(*roots())["result"] == 0
+    for k in range(6):
+        x = np.stack([lcg_noise(bs, 11 + k, 0.5)])
+        got, ref = a.process(x, 2, bs), c.process(x, 2, bs)
+        assert float(np.abs(got - ref).max()) <= TOL, (bs, k)
+        if k >= 2:
+            assert float(np.abs(ref).max()) > 0.01          # (both delays have come through)

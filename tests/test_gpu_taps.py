@@ -132,7 +132,7 @@ def test_tap_graph_swap_between_sets(gpu_required):
     assert a.stats()["batch_launches"] > 0
 
 
-@pytest.mark.parametrize("bs", [1024, 700, 1536])
+@pytest.mark.parametrize("bs", [1024, 700, 1536, 1031])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_taps_under_host_blocks_longer_than_512_frames(gpu_required, name, bs):
     """Runtime(sr, blockSize > 512): a tap's delay is the HOST's block (Feedback.h:29-31, 66-67: buffers of getBlockSize() frames;

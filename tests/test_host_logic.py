@@ -305,19 +305,19 @@ def test_island_program_cache_reuses_unchanged_islands():
 
 
 def test_block_sizes_above_one_lds_slot():
-    """Runtime(sr, blockSize) (Runtime.h:44): up to 512 frames as given; above that, a size that splits into k equal slices of 64 .. 512
-    frames is accepted (rendered slice by slice; r04: multiples of 512 only), a graph with taps — whose loop delay is the host's
-    block — commits as well (r05: every slice works on its own stretch of host-block-sized tap buffers; r04 answered 104); a size
-    no such k divides (a prime) or above 32768 fails at creation."""
+    """Runtime(sr, blockSize) (Runtime.h:44): up to 512 frames as given; above that (up to 32768), a size that splits into k equal slices
+    of 64 .. 512 frames is rendered slice by slice (r04: multiples of 512 only), any other size — a prime — as slices of 512 frames and
+    a shorter last one (refused until late r05); a graph with taps — whose loop delay is the host's block — commits as well (every slice
+    works on its own stretch of host-block-sized tap buffers; r04 answered 104); above 32768 creation fails."""
     from elementary_amd.runtime import ElemHipError
-    for bs in (1024, 2048, 32768, 700, 1000, 1023, 514):
+    for bs in (1024, 2048, 32768, 700, 1000, 1023, 514, 521, 1031):
         rt = dry(48000.0, bs)
         assert rt.block_size == bs
         assert rt.render(el.mul(0.5, el.cycle(220.0)))["result"] == 0
         loop = el.tapOut({"name": "fb"}, el.add(el.in_({"channel": 0}), el.mul(0.5, el.tapIn({"name": "fb"}))))
         assert rt.render(loop)["result"] == 0
         assert rt.render(el.mul(0.25, el.cycle(330.0)))["result"] == 0
-    for bs in (521, 1031, 512 * 65):              # 521 and 1031 are primes
+    for bs in (512 * 65, 0, -4):
         with pytest.raises(ElemHipError):
             dry(48000.0, bs)
     ok = dry(48000.0, 512)
