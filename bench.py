@@ -212,6 +212,20 @@ def c4_parity(timed_host, inst: int, first: int, total_blocks: int, tail: int = 
             "what": f"last {tail} blocks of the timed region of {len(picks)} render jobs vs reference engines advanced from time zero through all {total_blocks} blocks"}
 
 
+def _emit(full: dict) -> None:
+    """Every full record on a JSON line of its own, then ONE compact line (< 4 KB: benchmarks/headline.py) LAST — the line the
+    driver parses. The full records also go to gpurun_out/bench_records.jsonl (scratch)."""
+    sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+    import headline
+    rpath = None
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        rpath = os.path.join(ROOT, "gpurun_out", "bench_records.jsonl")
+    except OSError:
+        pass
+    headline.emit(full, records_path=rpath)
+
+
 def run_configs(names, timeout_s: float):
     """The other configurations of BASELINE.json, driver-run (VERDICT r04 "next" #1): each in a process of its own AFTER the headline's
     timed region (this process's engine is idle meanwhile), each record with its own value / ms_per_step x steps / roofline /
@@ -230,7 +244,10 @@ def run_configs(names, timeout_s: float):
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
             lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
             if res.returncode == 0 and lines:
-                rec = json.loads(lines[-1])
+                # `bench.py --workload c4` ends with its own compact line: the full record is the "headline_full" line before it
+                full = [ln for ln in lines if ln.startswith('{"record": "headline_full"')]
+                rec = json.loads(full[-1] if full else lines[-1])
+                rec.pop("record", None)
             else:
                 rec = {"error": f"exit code {res.returncode}", "stderr_tail": res.stderr[-600:]}
         except subprocess.TimeoutExpired:
@@ -340,7 +357,7 @@ def main_c4(args) -> None:
         us = 1e6 * dt / blocks
         sets = max(1, prof["launch_sets"])
         stats = rt.stats()
-        print(json.dumps({
+        _emit({
             "metric": "instance-samples/sec, independent offline render instances (BASELINE configs[3])",
             "value": world * inst * BLOCK * blocks / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -365,7 +382,7 @@ def main_c4(args) -> None:
             "cpu_baseline": base, "speedup_vs_cpu_baseline": (world * inst * BLOCK * blocks / dt) / base["value"] if base else None,
             "speedup_vs_cpu_baseline_note": (f"GPU rate / the reference engine on ALL {base['cores']} host cores this process may use" if base else None),
             "parity": parity,
-        }))
+        })
     if world > 1:
         dist.destroy_process_group()
 
@@ -713,7 +730,7 @@ def main() -> None:
                              "what": f"last {nb} blocks of the rank-0 reduced bus vs the reference engine rendering all {total_voices} voices"}
         if world == 1 and not args.no_configs and my_voices == 256 and not args.device_resident:
             out["configs"] = run_configs([c for c in args.configs.split(",") if c], args.config_timeout)
-        print(json.dumps(out), flush=True)
+        _emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,8 +29,10 @@ def _launch(extra, ranks=2):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]          # rank 0 prints ONE line
-    return json.loads(lines[0])
+    # rank 0 prints its full record on a line of its own, then ONE compact line (< 4 KB) LAST: the line the driver parses
+    assert len(lines) == 2 and json.loads(lines[0]).get("record") == "headline_full", res.stdout[-2000:]
+    assert len(lines[-1].encode()) < 4096 and res.stdout.rstrip().endswith(lines[-1])
+    return json.loads(lines[-1])
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
