@@ -1193,6 +1193,11 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
     std::vector<Item> items;
     std::shared_ptr<Plan> plan;
     uint64_t windowBlocks = 0, blocksNow = 0;
+    // A host block longer than the engine's renders as k slices, each an engine block with readouts of its own; the reference's nodes
+    // see ONE block (a meter reports min / max over all its frames, Analyzers.h:38-39; the relay runs once per host block): the slices
+    // of a host block are put back together here — `hostEnds[h]` = slices of the window rendered when host block h ended.
+    const bool sliced = hostBlockSize != blockSize;
+    std::vector<uint64_t> hostEnds;
     {   // ---- (a) under the render lock: snapshot of the records, stream-ordered behind everything rendered so far ----
         RenderGuard lock(*this);
         if (!current) return kOk;
@@ -1211,7 +1216,11 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
         }
         blocksNow = st.blocksRendered;
         windowBlocks = blocksNow - relayBlocksMark;
-        if (items.empty()) { relayBlocksMark = blocksNow; return kOk; }
+        if (sliced) {
+            for (uint64_t e : hostBlockEnds) if (e > relayBlocksMark && e <= blocksNow) hostEnds.push_back(e - relayBlocksMark);
+            if (windowBlocks && (hostEnds.empty() || hostEnds.back() != windowBlocks)) hostEnds.push_back(windowBlocks);
+        }
+        if (items.empty()) { relayBlocksMark = blocksNow; hostBlockEnds.clear(); return kOk; }
         const size_t need = items.size() * kRecDwords * 4;
         if (need > relayBytes) {
             const size_t cap = std::max<size_t>(need * 2, 16384);
@@ -1257,8 +1266,15 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
     std::vector<Ev> evs;
     struct Wb { Node* n; uint32_t dword; uint32_t value; };
     std::vector<Wb> writeBack;
-    const uint64_t lastBlock = windowBlocks ? windowBlocks - 1 : 0;
-    auto blockOf = [&](uint64_t fromEnd) -> uint64_t { return fromEnd > lastBlock ? 0 : lastBlock - fromEnd; };
+    const uint64_t lastSlice = windowBlocks ? windowBlocks - 1 : 0;
+    // the HOST block (of this relay window) an engine block `fromEnd` blocks before the newest belongs to
+    auto blockOf = [&](uint64_t fromEnd) -> uint64_t {
+        const uint64_t s_ = fromEnd > lastSlice ? 0 : lastSlice - fromEnd;
+        return sliced ? (uint64_t)(std::upper_bound(hostEnds.begin(), hostEnds.end(), s_) - hostEnds.begin()) : s_;
+    };
+    const uint64_t hostBlocks = sliced ? hostEnds.size() : windowBlocks;            // host blocks in the window
+    const uint64_t lastBlock = hostBlocks ? hostBlocks - 1 : 0;
+    const uint32_t hostFrames = (uint32_t)hostBlockSize;
     for (const Item& it : items) {
         Node& n = *it.n;
         const uint32_t* rc_ = reinterpret_cast<const uint32_t*>(hRelay + it.recOff);
@@ -1270,13 +1286,13 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
             uint32_t r = rc_[rec::SCP_READ];
             if (!n.ring.ptr || size == 0 || size >= cap) continue;
             // blockwise: the write position after each block of the window (whole blocks of blockSize frames), oldest first
-            const uint64_t steps = blockwise ? std::max<uint64_t>(1, std::min<uint64_t>(windowBlocks, (cap - 1) / (uint32_t)blockSize)) : 1;
-            std::vector<std::pair<uint64_t, uint32_t>> emits;            // (block, read position of the emitted frame)
+            const uint64_t steps = blockwise ? std::max<uint64_t>(1, std::min<uint64_t>(hostBlocks, (cap - 1) / hostFrames)) : 1;
+            std::vector<std::pair<uint64_t, uint32_t>> emits;            // (host block, read position of the emitted frame)
             for (uint64_t s_ = 0; s_ < steps; ++s_) {
-                const uint32_t w = (wEnd - (uint32_t)((steps - 1 - s_) * (uint64_t)blockSize)) & mask;
+                const uint32_t w = (wEnd - (uint32_t)((steps - 1 - s_) * (uint64_t)hostFrames)) & mask;
                 const uint32_t full = w > r ? w - r : ((cap - (r - w)) & mask);
                 if (!(full > size)) continue;
-                emits.emplace_back(blockOf(steps - 1 - s_), r);
+                emits.emplace_back(lastBlock - std::min<uint64_t>(lastBlock, steps - 1 - s_), r);
                 r = (uint32_t)((r + size) & mask);
             }
             if (emits.empty()) continue;
@@ -1344,15 +1360,23 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
         if (n.op == OP_METER) {                                           // Analyzers.h:23-62
             const uint32_t fresh = count - n.eventCount;
             if (!fresh) continue;
-            if (blockwise && n.ring.ptr && fresh > 1u) {
+            if (n.ring.ptr && (sliced || (blockwise && fresh > 1u))) {
                 const uint32_t take = std::min(fresh, lcap);
                 std::vector<uint32_t> e((size_t)take * 4);
                 if (!fetchRing((const float*)n.ring.ptr, lcap, count - take, take, 4, reinterpret_cast<float*>(e.data()))) return kHipError;
                 const std::string src = srcOf(n);
+                // one readout per HOST block: the slices of a host block folded into one min / max (unsliced: every group is one entry)
+                struct G { uint64_t block; float mn, mx; };
+                std::vector<G> groups;
                 for (uint32_t k = 0; k < take; ++k) {
                     float mn, mx; std::memcpy(&mn, &e[4 * k + 1], 4); std::memcpy(&mx, &e[4 * k + 2], 4);
-                    evs.push_back({blockOf(take - 1 - k), it.order, "meter", "{\"min\": " + numStr(mn) + ", \"max\": " + numStr(mx) + ", \"source\": " + src + "}"});
+                    const uint64_t b = blockOf(take - 1 - k);
+                    if (!groups.empty() && groups.back().block == b) { G& g = groups.back(); if (mn < g.mn) g.mn = mn; if (mx > g.mx) g.mx = mx; }
+                    else groups.push_back({b, mn, mx});
                 }
+                auto emit = [&](const G& g) { evs.push_back({g.block, it.order, "meter", "{\"min\": " + numStr(g.mn) + ", \"max\": " + numStr(g.mx) + ", \"source\": " + src + "}"}); };
+                if (blockwise) for (const G& g : groups) emit(g);
+                else if (!groups.empty() && !wrapsToEmpty((uint32_t)groups.size())) emit(groups.back());   // (the reference queued one readout per host block)
             } else if (!wrapsToEmpty(fresh)) evs.push_back({lastBlock, it.order, "meter", "{\"min\": " + numStr(fa) + ", \"max\": " + numStr(fb) + ", \"source\": " + srcOf(n) + "}"});
             n.eventCount = count;
         } else {                                                          // Analyzers.h:83-131
@@ -1364,10 +1388,13 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
                 std::vector<uint32_t> e((size_t)take * 4);
                 if (!fetchRing((const float*)n.ring.ptr, lcap, logn - take, take, 4, reinterpret_cast<float*>(e.data()))) return kHipError;
                 const std::string src = srcOf(n);
-                for (uint32_t k = 0; k < take; ++k) {
-                    float v; std::memcpy(&v, &e[4 * k + 1], 4);
-                    if (wrapsToEmpty(e[4 * k + 2])) continue;             // (per-block relay: the pushes of that block alone)
-                    evs.push_back({blockOf((uint64_t)(blk - 1u - e[4 * k])), it.order, "snapshot", "{\"source\": " + src + ", \"data\": " + numStr(v) + "}"});
+                for (uint32_t k = 0; k < take;) {                        // (the log entries of one HOST block: its newest latch, its pushes summed)
+                    const uint64_t b = blockOf((uint64_t)(blk - 1u - e[4 * k]));
+                    uint32_t pushes = 0, last = k;
+                    for (; k < take && blockOf((uint64_t)(blk - 1u - e[4 * k])) == b; ++k) { pushes += e[4 * k + 2]; last = k; }
+                    float v; std::memcpy(&v, &e[4 * last + 1], 4);
+                    if (wrapsToEmpty(pushes)) continue;                   // (per-block relay: the pushes of that block alone)
+                    evs.push_back({b, it.order, "snapshot", "{\"source\": " + src + ", \"data\": " + numStr(v) + "}"});
                 }
             } else if (!wrapsToEmpty(count - n.eventCount)) evs.push_back({lastBlock, it.order, "snapshot", "{\"source\": " + srcOf(n) + ", \"data\": " + numStr(fb) + "}"});
             n.eventCount = count; n.logRelayed = logn;
@@ -1377,6 +1404,7 @@ int Engine::processQueuedEvents(void (*cb)(const char*, const char*, void*), voi
         RenderGuard lock(*this);
         for (const Wb& w : writeBack) writeParam(*w.n, w.dword, w.value);
         relayBlocksMark = blocksNow;
+        while (!hostBlockEnds.empty() && hostBlockEnds.front() <= blocksNow) hostBlockEnds.pop_front();
         if (!writeBack.empty()) { const int rc = flushPending(); if (rc != kOk) return rc; }
     }
     // ---- (d) the host's callbacks, in block order (stable: nodes stay in render order inside a block) ----
@@ -1392,7 +1420,9 @@ uint32_t Engine::eventWindowBlocks() {
     std::lock_guard<std::mutex> control(ctl);
     RenderGuard lock(*this);
     const std::shared_ptr<Plan> pl = pending ? pending : current;
-    uint32_t w = kEventLogEntries;
+    // in HOST blocks (what the caller counts in): a host block of k slices fills k entries of the per-block readout logs
+    const uint32_t perHost = (uint32_t)((hostBlockSize + blockSize - 1) / blockSize);
+    uint32_t w = std::max(1u, kEventLogEntries / std::max(1u, perHost));
     if (!pl) return w;
     for (auto& en : pl->eventNodes) {
         auto nit = nodes.find(en.first);
@@ -1404,9 +1434,9 @@ uint32_t Engine::eventWindowBlocks() {
             const double size = (q != n.props.end() && q->second.isNumber()) ? q->second.num : 512.0;
             // a scope whose `size` is below the block hands on less per relay than a block brings: its ring overruns under a per-block
             // relay too, and where it does depends on every single relay — only a relay per block reproduces that
-            if (size < (double)blockSize) return 1u;
+            if (size < (double)hostBlockSize) return 1u;
             const double room = 8192.0 - 1.0 - std::max(1.0, size);
-            w = std::min<uint32_t>(w, (uint32_t)std::max(1.0, std::floor(room / (double)blockSize)));
+            w = std::min<uint32_t>(w, (uint32_t)std::max(1.0, std::floor(room / (double)hostBlockSize)));
         }
     }
     return w;
@@ -1452,6 +1482,7 @@ size_t Engine::gc(int32_t* out, size_t cap) {   // Runtime.h:220-272
             freeRecs.push_back(cr);
         }
         if (n.op == OP_TAPIN || n.op == OP_TAPOUT) tapNodeIds.erase(std::remove(tapNodeIds.begin(), tapNodeIds.end(), id), tapNodeIds.end());
+        convStaleNodes.erase(id);
         nodes.erase(id);
     }
     if (!pruned.empty()) { if (++nodesEpoch == 0u) nodesEpoch = 1u; }      // (Inlet::src memos name erased nodes now)
@@ -1843,6 +1874,7 @@ int Engine::process(const float* const* in, size_t nIn, float* const* out, size_
         const int rc = processSliceLocked(ip.data(), nIn, op.data(), nOut, std::min((size_t)blockSize, n - off), sampleTime + (int64_t)off, off == 0);
         if (rc != kOk) return rc;
     }
+    noteHostBlockEnd();
     return kOk;
 }
 
@@ -1925,7 +1957,9 @@ int Engine::processSliceLocked(const float* const* in, size_t nIn, float* const*
             HIP_OK(hipStreamSynchronize(stream));
             if (hOut) (void)hipHostFree(hOut);
             hOut = nullptr; hOutFloats = 0; hOutDev = nullptr;
-            HIP_OK(hipHostMalloc((void**)&hOut, floats * sizeof(float), hipHostMallocDefault));
+            // mapped AND coherent, said out loud: with `sync_poll` the host reads this block when the epilogue's word arrives, before the
+            // kernel has ended — no kernel-end release stands behind the samples, only the epilogue's own system-scope fence
+            HIP_OK(hipHostMalloc((void**)&hOut, floats * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
             hOutFloats = floats;
             if (hipHostGetDevicePointer((void**)&hOutDev, hOut, 0) != hipSuccess) hOutDev = nullptr;
         }
@@ -1987,10 +2021,13 @@ int Engine::processSliceLocked(const float* const* in, size_t nIn, float* const*
         syncPolls++;
         if (!arrived) syncPollFallbacks++;
     }
-    // (every 256th call still synchronises: the runtime retires its launch bookkeeping there)
-    if (!arrived || (++unsyncedCalls & 255u) == 0u) {
+    // (every 256th call still synchronises: the runtime retires its launch bookkeeping there; so does a call with plans / buffers
+    //  waiting to be released — freeDeferred's contract is a REAL synchronise of the stream, not the polled word)
+    bool synced = false;
+    if (!arrived || !deferredFree.empty() || !retiredPlans.empty() || (++unsyncedCalls & 255u) == 0u) {
         HIP_OK(hipStreamSynchronize(stream));
         HIP_OK(hipGetLastError());
+        synced = true;
     }
     if (profUsed) profCollect();
     for (size_t c = 0; c < nOut; ++c) std::memcpy(out[c], hOut + c * blockSize, n * sizeof(float));
@@ -1998,7 +2035,9 @@ int Engine::processSliceLocked(const float* const* in, size_t nIn, float* const*
     hGlobals.sampleTime += (int64_t)n;
     st.blocksRendered++;
     promoteDeferredShapes();
-    freeDeferred();
+    // the word arrived: the armed epilogue is the last work of this call on `stream`, which is in order and joined every side stream
+    // in front of it — the patch uploads of this call have been consumed, so the staging cursor may start over; nothing is freed
+    if (synced) freeDeferred(); else patchCursor = 0;
     return kOk;
 }
 
@@ -2431,7 +2470,15 @@ void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32
     }
     const uint32_t longRows = (convLong && convMaxQp) ? convMaxQp - 1u : 0u;
     const bool longSet = longRows && batch >= 8u && (batch & 7u) == 0u;
-    if (longSet && stateBlocks > 1u) { convLongSets++; convOverlapStale = true; }
+    if (longSet && stateBlocks > 1u) {
+        convLongSets++;
+        // staleness is a fact of a NODE (its header's H_OVL_STALE), not of the engine: a plan without this node may render
+        // block-at-a-time in between, and the node must still be repaired when a later plan brings it back
+        for (uint32_t k = 0; k < mains; ++k) {
+            const uint32_t ci = p.convWork[cb + k] & 0xFFFFu;
+            if (ci < p.convNodeIds.size()) convStaleNodes.insert(p.convNodeIds[ci]);
+        }
+    }
     if (!longSet) fixConvOverlaps(p);
     launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks, (uint32_t)convMfma,
                           convMinP <= convolve_mfma_max_partitions(), convMaxP > convolve_mfma_max_partitions(), longRows, anyShortPath, stateBlocks, convLongMacLds,
@@ -2468,10 +2515,12 @@ void Engine::chooseConvDirectIo(const Plan& p, size_t nIn, size_t nOut, uint32_t
 }
 
 void Engine::fixConvOverlaps(const Plan& p) {
-    if (!convOverlapStale || p.convs.empty() || !dConvScratch) return;
+    if (convStaleNodes.empty() || p.convs.empty() || !dConvScratch) return;
+    bool any = false;
+    for (int32_t id : p.convNodeIds) any = convStaleNodes.erase(id) > 0 || any;      // (the kernels return early for nodes whose header is not stale)
+    if (!any) return;
     launch_convolve_fix_overlap(stream, p.view, dRecs, dHbm, dGlobals, 0u, (uint32_t)p.convWork.size(), dConvScratch, (uint32_t)batchBlocks,
                                 (convLong && convMaxQp) ? convMaxQp - 1u : 0u, convMaxP);
-    convOverlapStale = false;
 }
 
 void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
@@ -2816,6 +2865,10 @@ int Engine::processBlocksHost(const float* const* in, size_t nIn, float* const* 
             int rc = enqueueBlocks(nIn ? dStageIn[half] : nullptr, nIn, nOut ? dStageOut[half] : nullptr, nOut, nb,
                                    sampleTime + (int64_t)(b0 * bs));
             if (rc != kOk) { result = rc; break; }
+            if (hb > bs) {                                      // (whole host blocks of hb / bs slices each: where each one ended, for the event relay)
+                const uint64_t per = hb / bs, base = st.blocksRendered - nb;
+                for (uint64_t e = per; e <= nb; e += per) { if (hostBlockEnds.size() >= 65536) hostBlockEnds.pop_front(); hostBlockEnds.push_back(base + e); }
+            }
             HOST_TRY(hipEventRecord(evRendered[half], stream));
             HOST_TRY(hipStreamWaitEvent(ioStream, evRendered[half], 0));
             if (nOut) HOST_TRY(hipMemcpyAsync(hStageOut[half], dStageOut[half], nb * nOut * bs * sizeof(float), hipMemcpyDeviceToHost, ioStream));

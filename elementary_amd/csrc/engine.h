@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <set>
@@ -302,6 +303,11 @@ private:
     hipStream_t relayStream = nullptr; hipEvent_t evRelay = nullptr;
     uint8_t* dRelay = nullptr; uint8_t* hRelay = nullptr; size_t relayBytes = 0;
     uint64_t relayBlocksMark = 0;          // Stats::blocksRendered at the last relay: a blockwise relay's window starts here
+    // A host block longer than the engine's is k slices = k engine blocks, and the reference's nodes queue their readouts per HOST block
+    // (one meter readout over all its frames, Analyzers.h:38-39): Stats::blocksRendered at the end of every host block rendered since the
+    // last relay (kept only while hostBlockSize != blockSize; `mu` held), so that a relay can put the slices back together.
+    std::deque<uint64_t> hostBlockEnds;
+    void noteHostBlockEnd() { if (hostBlockSize != blockSize) { if (hostBlockEnds.size() >= 65536) hostBlockEnds.pop_front(); hostBlockEnds.push_back(st.blocksRendered); } }
     std::vector<std::shared_ptr<Plan>> retiredPlans;   // replaced plans whose launches may still be in flight; released by freeDeferred()
 
     // host-buffer launch sets (processBlocksHost): copy stream, pinned + device staging halves, hand-over events
@@ -348,7 +354,7 @@ private:
     bool hostOutDirect = true;             // process(): the epilogue kernel writes into the mapped pinned output block
     uint32_t convMinP = 0xFFFFFFFFu, convMaxP = 0;   // fewest / most partitions of any impulse response set so far
     bool convLong = true;                  // option "conv_long": launch sets of a multiple of 8 blocks render IRs of >= 32 partitions with 4096-sample partitions (conv_long.inc)
-    bool convOverlapStale = false;         // some convolve node was last rendered by a long-partition set: its `overlap` is made on demand (fixConvOverlaps)
+    std::set<int32_t> convStaleNodes;      // convolve nodes last rendered by a long-partition set: their `overlap` is made on demand (fixConvOverlaps), per node
     void fixConvOverlaps(const Plan& p);   // ... before the next 512-partition evaluation (block-at-a-time launches, sets that are no multiple of 8 blocks)
     bool convLongMacLds = false;           // option "conv_long_mac_lds": the LDS-tiled partition sums (measured slower than the register kernel over L2: 36.6 vs 27.4 us per C3 set)
     bool convDirectIo = true;              // option "conv_direct_io": a plan of long-partition convolvers only reads the caller's input / writes the caller's output in place

@@ -48,6 +48,47 @@ static uint64_t fnv1a(const std::string& s, uint64_t h) {
     return h;
 }
 
+// ---- the on-disk cache holds code this process will RUN: only a directory that is ours is read from or written to ----
+// The directory must be a real directory (no symlink) owned by this user (or root) that nobody else may write to; it is created 0700.
+static bool trustedCacheDir(const std::string& dir) {
+    (void)mkdir(dir.c_str(), 0700);
+    struct stat sb;
+    if (::lstat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) return false;
+    if (sb.st_uid != geteuid() && sb.st_uid != 0) return false;
+    return (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+// a gfx code object as hiprtc hands it out: a 64-bit little-endian ELF for EM_AMDGPU (224), or a clang offload bundle of such
+static bool looksLikeCodeObject(const std::vector<char>& c) {
+    static const char kBundle[] = "__CLANG_OFFLOAD_BUNDLE__";
+    if (c.size() >= sizeof(kBundle) - 1 + 8 && std::memcmp(c.data(), kBundle, sizeof(kBundle) - 1) == 0) return true;
+    if (c.size() < 64) return false;
+    const unsigned char* u = reinterpret_cast<const unsigned char*>(c.data());
+    return u[0] == 0x7f && u[1] == 'E' && u[2] == 'L' && u[3] == 'F' && u[4] == 2 /* ELFCLASS64 */ && u[5] == 1 /* little endian */
+        && (unsigned)(u[18] | (u[19] << 8)) == 224u;
+}
+// a cached code object: a regular file (never through a symlink) owned by this user or root
+static bool readTrustedFile(const std::string& path, std::vector<char>& out) {
+    const int fd = ::open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat sb;
+    bool ok = ::fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && (sb.st_uid == geteuid() || sb.st_uid == 0) && sb.st_size > 64 && sb.st_size < (64 << 20);
+    if (ok) {
+        out.resize((size_t)sb.st_size);
+        size_t got = 0;
+        while (got < out.size()) { const ssize_t r = ::read(fd, out.data() + got, out.size() - got); if (r <= 0) break; got += (size_t)r; }
+        ok = got == out.size();
+    }
+    ::close(fd);
+    return ok && looksLikeCodeObject(out);
+}
+static bool writeNewFile(const std::string& path, const char* data, size_t n) {      // O_EXCL | O_NOFOLLOW: never onto something pre-placed
+    const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return false;
+    size_t put = 0;
+    while (put < n) { const ssize_t r = ::write(fd, data + put, n - put); if (r <= 0) break; put += (size_t)r; }
+    return ::close(fd) == 0 && put == n;
+}
+
 static std::string libraryDir() {
     Dl_info info;
     if (dladdr(reinterpret_cast<const void*>(&libraryDir), &info) && info.dli_fname) {
@@ -92,6 +133,7 @@ struct Jit::Impl {
     std::string versionTag;
     bool keepSource = false;
     std::string helper;                     // elemhip_jitc next to the library: one compiler process per worker ("" = compile in-process)
+    bool diskOk = true;                     // the on-disk cache is ours to trust (trustedCacheDir); false: compile, never read or publish files
     uint32_t entryCap = 256;
     uint64_t diskCapBytes = 512ull << 20;
     int64_t diskBytes = -1;                 // -1: not scanned yet
@@ -103,6 +145,8 @@ struct Jit::Impl {
         exitHookTarget = this;
         const char* env = std::getenv("ELEMHIP_KCACHE");
         cacheDir = env && env[0] ? env : libraryDir() + "/kcache";
+        diskOk = trustedCacheDir(cacheDir);
+        if (!diskOk) std::fprintf(stderr, "[elemhip] jit: %s is not a directory of this user that only they can write to: the on-disk kernel cache is off\n", cacheDir.c_str());
         if (const char* k = std::getenv("ELEMHIP_JIT_KEEP_SOURCE")) keepSource = std::atoi(k) != 0;
         if (const char* k = std::getenv("ELEMHIP_JIT_CACHE_ENTRIES")) entryCap = (uint32_t)std::max(4, std::atoi(k));
         if (const char* k = std::getenv("ELEMHIP_KCACHE_MAX_MB")) diskCapBytes = (uint64_t)std::max(1, std::atoi(k)) << 20;
@@ -206,16 +250,13 @@ struct Jit::Impl {
 
     void compile(SpecEntry& e) {
         const std::string path = cacheDir + "/" + e.key + ".hsaco";
-        {   // disk cache
-            std::ifstream f(path, std::ios::binary);
-            if (f) {
-                std::vector<char> code((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-                if (code.size() > 64) {
-                    e.code.swap(code); e.fromDisk = true;
-                    (void)utimensat(AT_FDCWD, path.c_str(), nullptr, 0);      // a hit keeps the file young (the cap removes oldest first)
-                    e.state.store(1, std::memory_order_release);
-                    return;
-                }
+        if (diskOk) {   // disk cache
+            std::vector<char> code;
+            if (readTrustedFile(path, code)) {
+                e.code.swap(code); e.fromDisk = true;
+                (void)utimensat(AT_FDCWD, path.c_str(), nullptr, AT_SYMLINK_NOFOLLOW);      // a hit keeps the file young (the cap removes oldest first)
+                e.state.store(1, std::memory_order_release);
+                return;
             }
         }
         const auto t0 = std::chrono::steady_clock::now();
@@ -223,17 +264,18 @@ struct Jit::Impl {
         const std::string src = Jit::fullSource(e.generated, e.ldsWords, e.block);
         if (keepSource) { std::lock_guard<std::mutex> l(e.mu); e.source = src; }
         if (!helper.empty()) {
-            // out of process: source -> <key>.<pid>.src, the helper writes <key>.<pid>.tmp (+ its log), renamed into place on success
-            (void)mkdir(cacheDir.c_str(), 0755);
-            const std::string stem = cacheDir + "/" + e.key + "." + std::to_string((long)getpid());
-            const std::string srcPath = stem + ".src", outPath = stem + ".tmp", logPath = stem + ".log";
-            bool ok = false;
-            { std::ofstream sf(srcPath, std::ios::binary); if (sf) { sf.write(src.data(), (std::streamsize)src.size()); ok = (bool)sf; } }
+            // out of process, in a scratch directory of this compile alone (mkdtemp: mode 0700, a name nobody can pre-place): the source
+            // goes in, the helper writes its code object and its log beside it; the code object is checked (an ELF for gfx) and renamed
+            // into the shared cache only then
+            std::string scratch = (diskOk ? cacheDir : std::string("/tmp")) + "/.jit.XXXXXX";
+            const bool haveScratch = mkdtemp(&scratch[0]) != nullptr;
+            const std::string srcPath = scratch + "/k.src", outPath = scratch + "/k.hsaco", logPath = scratch + "/k.log";
+            bool ok = haveScratch && writeNewFile(srcPath, src.data(), src.size());
             int status = -1;
             if (ok) {
                 posix_spawn_file_actions_t fa;
                 posix_spawn_file_actions_init(&fa);
-                posix_spawn_file_actions_addopen(&fa, 2, logPath.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+                posix_spawn_file_actions_addopen(&fa, 2, logPath.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
                 posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0644);
                 char* const argv[] = {const_cast<char*>(helper.c_str()), const_cast<char*>(srcPath.c_str()), const_cast<char*>(outPath.c_str()), nullptr};
                 pid_t pid = 0;
@@ -241,21 +283,23 @@ struct Jit::Impl {
                 posix_spawn_file_actions_destroy(&fa);
             }
             { std::ifstream lf(logPath, std::ios::binary); if (lf) e.log.assign((std::istreambuf_iterator<char>(lf)), std::istreambuf_iterator<char>()); }
-            (void)std::remove(srcPath.c_str()); (void)std::remove(logPath.c_str());
+            bool done = false;
             if (ok && WIFEXITED(status) && WEXITSTATUS(status) == 0) {
-                std::ifstream cf(outPath, std::ios::binary);
-                std::vector<char> code((std::istreambuf_iterator<char>(cf)), std::istreambuf_iterator<char>());
-                if (code.size() > 64) {
+                std::vector<char> code;
+                if (readTrustedFile(outPath, code)) {
                     e.code.swap(code);
                     e.compileMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                    const bool written = std::rename(outPath.c_str(), path.c_str()) == 0;
-                    if (!written) (void)std::remove(outPath.c_str());
+                    const bool written = diskOk && std::rename(outPath.c_str(), path.c_str()) == 0;
                     e.state.store(1, std::memory_order_release);
                     if (written) trimDisk((int64_t)e.code.size());
-                    return;
-                }
+                    done = true;
+                } else e.log += "\n(the helper's output is not a gfx code object)";
             }
-            (void)std::remove(outPath.c_str());
+            if (haveScratch) {
+                (void)std::remove(srcPath.c_str()); (void)std::remove(logPath.c_str()); (void)std::remove(outPath.c_str());
+                (void)rmdir(scratch.c_str());
+            }
+            if (done) return;
             std::fprintf(stderr, "[elemhip] jit: compilation of shape %s failed (helper status %d):\n%.3000s\n", e.key.c_str(), status, e.log.c_str());
             e.state.store(-1, std::memory_order_release);
             return;
@@ -281,14 +325,11 @@ struct Jit::Impl {
         (void)hiprtcGetCode(prog, e.code.data());
         (void)hiprtcDestroyProgram(&prog);
         e.compileMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        // disk cache: best effort, atomic rename
-        (void)mkdir(cacheDir.c_str(), 0755);
-        const std::string tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
+        // disk cache: best effort, a new file of our own (O_EXCL) renamed into place
         bool written = false;
-        {
-            std::ofstream f(tmp, std::ios::binary);
-            if (f) {
-                f.write(e.code.data(), (std::streamsize)e.code.size()); f.close();
+        if (diskOk) {
+            const std::string tmp = path + "." + std::to_string((long)getpid()) + "." + std::to_string((unsigned long long)tick.fetch_add(1)) + ".tmp";
+            if (writeNewFile(tmp, e.code.data(), e.code.size())) {
                 if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str()); else written = true;
             }
         }
@@ -456,7 +497,7 @@ bool Jit::knownKey(const std::string& key) {
     // (asked on every re-plan of a live graph for the one-island shapes of a voice that is fading out: the answer from the
     //  file system — 100 us and more on a network mount — is remembered; a key that gets compiled later is found in `entries`)
     struct stat st;
-    const bool there = ::stat((impl->cacheDir + "/" + key + ".hsaco").c_str(), &st) == 0;
+    const bool there = impl->diskOk && ::lstat((impl->cacheDir + "/" + key + ".hsaco").c_str(), &st) == 0 && S_ISREG(st.st_mode);
     if (!there) { std::lock_guard<std::mutex> l(impl->mu); if (impl->notOnDisk.size() > 4096) impl->notOnDisk.clear(); impl->notOnDisk.insert(key); }
     return there;
 }

@@ -225,6 +225,42 @@ def test_long_partition_sets_interleave_with_every_other_path(gpu_required, taps
     assert float(np.abs(outs[1].astype(np.float64) - outs[0]).max()) <= 5e-7
 
 
+def test_a_convolver_that_sits_out_a_plan_is_repaired_when_it_comes_back(gpu_required):
+    """ADVICE r05 (engine.cpp, one engine-wide `convOverlapStale` flag): a long-partition launch set leaves a convolver's `overlap`
+    and 512-partition spectra ring to be rebuilt on demand. The node may then sit out a plan in which OTHER convolvers render
+    block-at-a-time (their repair must not clear X's debt) and come back later onto the block-at-a-time path: staleness is kept
+    per node. Every stretch against the restatement driven through the same commits (a fading-out root keeps its convolver
+    running for the blocks of the fade, GraphRenderSequence.h:239-262)."""
+    from elementary_amd import el
+    ir_x, ir_y, ir_w = graphs.c3_impulse_response(0, 20000), graphs.c3_impulse_response(1, 18000), graphs.c3_impulse_response(2, 3000)
+    X = el.convolve({"path": "irx", "key": "x"}, el.in_({"channel": 0}))
+    Y = el.convolve({"path": "iry", "key": "y"}, el.in_({"channel": 0}))
+    W = el.convolve({"path": "irw", "key": "w"}, el.in_({"channel": 1}))
+    steps = [("render", (X,)), ("blocks", 16),              # X through a long-partition set: stale
+             ("render", (Y,)), ("blocks", 16),              # X fades out under Y's plan (another long set), then stops running
+             ("render", (Y, W)), ("one", 3),                # a plan WITHOUT X, block at a time: Y is repaired — X's debt must survive
+             ("render", (X, W)), ("one", 6),                # X back, block at a time: its overlap has to be rebuilt now
+             ("blocks", 8), ("one", 2)]
+    total = sum(n for kind, n in steps if kind != "render")
+    x = graphs.c3_input(2, total * 512)
+    a, c = hip(48000.0, 512), oracle.PortRuntime(48000.0, 512)
+    for rt in (a, c):
+        assert rt.add_shared_resource("irx", ir_x) and rt.add_shared_resource("iry", ir_y) and rt.add_shared_resource("irw", ir_w)
+    k = 0
+    for kind, arg in steps:
+        if kind == "render":
+            for rt in (a, c):
+                assert rt.render(*arg)["result"] == 0
+            continue
+        n = arg
+        ref = np.stack([c.process(x[:, (k + i) * 512:(k + i + 1) * 512], 2, 512) for i in range(n)])
+        got = _blocks(a, x, k, n, 2) if kind == "blocks" else np.stack([a.process(x[:, (k + i) * 512:(k + i + 1) * 512], 2, 512) for i in range(n)])
+        err = np.abs(got.astype(np.float64) - ref).max(axis=(1, 2))
+        assert float(err.max()) <= TOL, (kind, n, k, int(err.argmax()), float(err.max()))
+        k += n
+    assert a.describe_plan()["conv_long_sets"] >= 3
+
+
 def test_partial_blocks_switch_the_multi_block_path_off(gpu_required):
     """After a call of fewer than 512 frames a convolver's input block may be partly filled at a call boundary: the
     engine goes back to block-at-a-time launches for plans with convolvers (still the same samples)."""

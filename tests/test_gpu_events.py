@@ -99,6 +99,50 @@ def test_300_block_meter_graph_blockwise_equals_per_block_relay(gpu_required, sp
         assert st["spec_launches"] > 0
 
 
+@pytest.mark.parametrize("bs", [1024, 700, 521])
+def test_listeners_on_a_sliced_host_block(gpu_required, bs):
+    """a host block above 512 frames renders as k slices (1024 = 2 x 512, 700 = 2 x 350, 521 = 512 + 9), each an engine
+    block with readout-log entries of its own — but the reference's nodes see ONE block: a meter reports min / max over all its
+    frames once (Analyzers.h:38-39), a snapshot's relay hands on the newest latch of the host block, the 32-slot queue quirk counts
+    the pushes of the whole host block (a 1.5 kHz train latches 32 times per 1024 frames at 48 kHz), a scope compares its ring with
+    `size` once per host block. The relay puts the slices back together: same events, same order, same numbers as the reference
+    engine created with that block size and relayed after every block; the window is counted in HOST blocks."""
+    def roots():
+        x = el.in_({"channel": 0})
+        y = el.lowpass(900.0, 0.7, x)
+        return [el.meter({"name": "dry"}, x), el.snapshot({"name": "slow"}, el.train(37.0), el.mul(2.0, y)),
+                el.meter({"name": "wet"}, y), el.snapshot({"name": "fast"}, el.train(2900.0), x),
+                el.snapshot({"name": "wraps1024"}, el.train(1500.0), x)]
+    frames = 90 * bs
+    a, ya, core = _collect(_hip, roots, frames, 1, 5, bs=bs, kinds=("meter", "snapshot"), options={"batch_blocks": 1024})
+    b, yb, _ = _collect(_ref, roots, frames, 1, 5, bs=bs, kinds=("meter", "snapshot"))
+    assert float(np.abs(ya - yb).max()) <= TOL
+    assert len([1 for k, _ in b if k == "meter"]) == 180                     # ONE readout per meter and HOST block
+    if bs == 1024:
+        assert len([1 for k, p in b if p.get("source") == "wraps1024"]) == 0  # 32 latches per host block: the reference reports nothing
+    _same_events(a, b)
+    assert core.runtime.event_window_blocks() == 1024 // ((bs + 511) // 512)
+    # ... and with a scope: its ring is compared with `size` once per HOST block
+    def roots2():
+        x = el.in_({"channel": 0})
+        return [el.scope({"name": "sc", "size": 2048, "channels": 2}, x, el.mul(0.5, x)), el.meter({"name": "m"}, el.mul(0.5, x))]
+    a, ya, core = _collect(_hip, roots2, 40 * bs, 1, 2, bs=bs)
+    b, yb, _ = _collect(_ref, roots2, 40 * bs, 1, 2, bs=bs)
+    assert float(np.abs(ya - yb).max()) <= TOL
+    assert len([1 for k, _ in b if k == "scope"]) >= 8
+    _same_events(a, b)
+    # the plain relay (newest readout since the last relay) after single host-block calls: the meter's min / max cover the whole host block
+    rt, ref = _hip(48000.0, bs), _ref(48000.0, bs)
+    for r in (rt, ref):
+        assert r.render(el.meter({"name": "m"}, el.in_({"channel": 0})))["result"] == 0
+    x = lcg_noise_fast(6 * bs, 5, 0.5)
+    for k in range(6):
+        blk = x[None, k * bs:(k + 1) * bs]
+        rt.process(blk, 1, bs); ref.process(blk, 1, bs)
+        if k % 2:
+            _same_events(list(rt.process_queued_events()), list(ref.process_queued_events()))
+
+
 def test_blockwise_relay_with_a_scope_and_a_rerender(gpu_required):
     """A scope (size 1024, two channels: an event every other block) beside a meter: the engine limits the relay window so that the
     8192-frame ring cannot overrun inside it, and emits `size` frames at the blocks where the reference's per-block relay does;
