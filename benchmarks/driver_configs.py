@@ -51,6 +51,19 @@ def _roofline(alg_bytes_per_block, us_per_block, basis, **extra):
     return d
 
 
+def _traffic(name, **match):
+    """`roofline.traffic` of configuration `name`: HBM bytes per launch (PMC passes of this configuration's GPU leg, 2 x FETCH_SIZE +
+    WRITE_SIZE as MI355X_MICROARCH.md prescribes; committed under profiles/, not re-measured in this run) when the committed
+    geometry matches, else None."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_cfgs.json")))[name]
+        if all(tj.get(k) == v for k, v in match.items()):
+            return tj.get("hbm_bytes_per_launch"), "profiles/traffic_cfgs.json (rocprofv3 PMC passes of this configuration, committed): " + str(tj.get("round", "")) + "; per " + str(tj.get("per", "launch"))
+    except Exception:
+        pass
+    return None, None
+
+
 def _ref_engine(sr):
     import oracle
     if oracle.have_ref():
@@ -62,7 +75,7 @@ def _ref_engine(sr):
 # C1 — BASELINE configs[0]: the cli benchmark's own graph and its own protocol (cli/Benchmark.cpp:70-101: one warm-up block,
 # N timed synchronous process() calls of 512 frames from a native host)
 # ------------------------------------------------------------------------------------------------------------------------------
-def _native_run(roots, sr, blocks, spec, dump, resident=False):
+def _native_run(roots, sr, blocks, spec, dump, resident=False, env_extra=None):
     """examples/bench_cli (C++ over include/elemhip/Runtime.hpp): `blocks` timed calls; every rendered block lands in `dump`."""
     import subprocess
     import tempfile
@@ -76,7 +89,7 @@ def _native_run(roots, sr, blocks, spec, dump, resident=False):
         bpath = os.path.join(d, "batch.json")
         open(bpath, "w").write(batch_to_json(sent[0]))
         res = subprocess.run([exe, bpath, str(blocks), str(sr), os.path.join(d, "last.f32"), dump], capture_output=True, text=True, timeout=300,
-                             env=dict(os.environ, ELEMHIP_SPECIALIZE=str(spec), ELEMHIP_RESIDENT="1" if resident else "0"))
+                             env=dict(os.environ, ELEMHIP_SPECIALIZE=str(spec), ELEMHIP_RESIDENT="1" if resident else "0", **(env_extra or {})))
     if res.returncode != 0:
         return {"error": res.stderr[-300:]}
     line = [l for l in res.stderr.splitlines() if l.startswith("{")]
@@ -156,7 +169,8 @@ def c1(calls: int = 4000):
                                      "the GPU spins on a word in mapped host memory while the host is away (leaves after `resident_idle_us`, default 2000)"),
         "launch_sets": {"us_per_block": sets_us, "samples_per_s": BLOCK / (sets_us * 1e-6), "blocks_per_set": B, "sets_timed": nset,
                         "parity": _parity(keep, ref_sets, f"the last timed set ({B} blocks) vs the {kind} engine advanced through all {(nset + 1) * B} blocks")},
-        "roofline": _roofline(alg, us, "algorithmic bytes per block / mean call time; a lone serial phasor -> sin -> svf chain per channel: latency-bound by construction") if us else None,
+        "roofline": _roofline(alg, us, "algorithmic bytes per block / mean call time; a lone serial phasor -> sin -> svf chain per channel: latency-bound by construction",
+                              **dict(zip(("traffic", "traffic_source"), _traffic("c1")))) if us else None,
         "cpu_baseline": {"value": BLOCK / (cpu_us * 1e-6), "unit": "samples/s", "cores": 1, "kind": kind,
                          "sample": f"{calls} synchronous process() calls of the same graph after 1 warm-up block", "us_per_call_mean": cpu_us,
                          "us_per_call_p50": 1e6 * _pct(lat, 0.5)},
@@ -192,22 +206,29 @@ def _c3_oracle_channel(args):
     return time.perf_counter() - t0, np.stack(first) if first else None, np.stack(last) if last else None
 
 
-def _c3_roofline(alg, us, set_blocks, ch, parts):
-    r = _roofline(alg, us, "SURVEY 8(d) C3 bytes (the REFERENCE's two-stage partitioning: 16 x 513 + 22 x 4097 / 8 bins of 8 B per channel-block + block I/O) "
-                           "over the timed region", mac_flops_per_step_uniform_512=8.0 * ch * parts * 513 * set_blocks,
-                  mac_flops_per_step_long_partitions=8.0 * ch * ((parts * 512 + 4095) // 4096) * 4097 * (set_blocks // 8))
-    tpath = os.path.join(ROOT, "profiles", "traffic_c3.json")
-    try:
-        tj = json.load(open(tpath))
-        if int(tj.get("blocks_per_launch", 0)) == set_blocks:
-            r["traffic"] = tj.get("hbm_bytes_per_launch_set")
-            r["traffic_source"] = "profiles/traffic_c3.json (rocprofv3 PMC passes of this configuration, committed; not re-measured in this run): " + str(tj.get("round", ""))
-    except Exception:
-        pass
-    if r["frac"] > 1.0:
-        r["note"] = ("frac > 1 is not a measurement error: `achieved` prices the REFERENCE's traffic model (every partition spectrum of its two-stage "
-                     "convolver read once per channel and block, 1.28 MB per block) against 8 TB/s, and this path does not move those bytes — the whole IR in "
-                     "4096-sample partitions, each spectrum row shared by 16 chunks in registers: `traffic` (PMC) is the HBM traffic of one launch set")
+def _c3_roofline(alg_ref_model, us, set_blocks, ch, parts):
+    """C3's roofline, honestly (a fraction above 1 prices a model the kernels do not follow):
+      achieved / frac   = the HBM traffic the three kernels of a launch set really move (PMC counters, committed pass of this geometry)
+                          / the set's time / 8 TB/s — how busy the memory system is;
+      frac_compulsory   = the bytes the long-partition ALGORITHM cannot avoid (input blocks + output blocks + the IR spectra once per
+                          set) / time / 8 TB/s — how far the path is from an implementation that moved nothing else;
+      reference_model   = SURVEY 8(d)'s figure for the REFERENCE's two-stage convolver (every partition spectrum read once per
+                          channel and block) — an aside: this path does not move those bytes."""
+    Q = (parts * 512 + 4095) // 4096
+    compulsory = 2 * ch * set_blocks * BLOCK * 4 + ch * Q * 4097 * 8          # per launch set
+    set_s = us * 1e-6 * set_blocks
+    traffic, src = _traffic("c3", blocks_per_launch=set_blocks, channels=ch)
+    basis_bytes = traffic if traffic else compulsory
+    ach = basis_bytes / set_s / 1e9
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,
+         "basis": ("PMC HBM bytes of one launch set (the three long-partition kernels) / the set's wall time" if traffic else
+                   "no committed PMC pass matches this geometry: compulsory bytes of one launch set / the set's wall time"),
+         "compulsory_bytes_per_launch_set": compulsory, "frac_compulsory": compulsory / set_s / 1e9 / HBM_PEAK_GBPS,
+         "traffic_over_compulsory": (traffic / compulsory) if traffic else None,
+         "flops_per_launch_set": {"partition_mac": 8.0 * ch * Q * 4097 * (set_blocks // 8), "transforms_estimate": 2 * ch * (set_blocks // 8) * 5.0 * 4096 * 12},
+         "reference_model": {"bytes_per_block": alg_ref_model, "frac_if_priced_against_it": alg_ref_model / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                             "note": "SURVEY 8(d) C3 bytes of the REFERENCE's two-stage partitioning (16 x 513 + 22 x 4097 / 8 bins of 8 B per channel-block + block I/O); "
+                                     "not a roofline of these kernels"}}
     return r
 
 
@@ -265,6 +286,45 @@ def c3(steps: int = 16, warmup: int = 2, set_blocks: int = 1024, gpu_only: bool 
     sets = max(1, prof["launch_sets"])
     plan = rt.describe_plan()
     parts = (graphs.C3_IR_LEN + BLOCK - 1) // BLOCK
+    # ---- the same graph through the host boundary (VERDICT r05 missing #4): (a) every block delivered to host arrays
+    # (elemhip_process_blocks_host, 8 x 2 KB in + out per block over PCIe), (b) one synchronous elemhip_process call per 512-frame block
+    # from a native host — what the reference's convolver answers (wasm/Convolve.h:73-84, wasm/Main.cpp:194-216)
+    host = {}
+    try:
+        hb = 4 * set_blocks
+        xh = np.ascontiguousarray(np.tile(x, (1, hb // 64)))
+        rt.process_blocks_host(xh[:, :set_blocks * BLOCK], ch, set_blocks * BLOCK)                      # warm the staging buffers
+        t1 = time.perf_counter()
+        yh = rt.process_blocks_host(xh, ch, hb * BLOCK)
+        dth = time.perf_counter() - t1
+        host["process_blocks_host"] = {"samples_per_s": hb * BLOCK / dth, "us_per_block": 1e6 * dth / hb, "blocks": hb,
+                                       "pcie_bytes_per_block": 2 * ch * BLOCK * 4, "delivered_GBps": 2 * ch * BLOCK * 4 * hb / dth / 1e9,
+                                       "finite": bool(np.isfinite(yh).all())}
+    except Exception as e:      # noqa: BLE001
+        host["process_blocks_host"] = {"error": repr(e)[:200]}
+    try:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            res = []
+            for c in range(ch):
+                pth = os.path.join(d, f"ir{c}.f32")
+                graphs.c3_impulse_response(c).astype(np.float32).tofile(pth)
+                res.append(f"ir{c}={pth}")
+            r = _native_run(graphs.c3_graph(ch), graphs.C3_SAMPLE_RATE, 2000, 1, os.path.join(d, "all.f32"),
+                            env_extra={"ELEMHIP_BENCH_RES": ";".join(res), "ELEMHIP_BENCH_IO": f"{ch},{ch}"})
+        host["sync_process_native_host"] = r
+    except Exception as e:      # noqa: BLE001
+        host["sync_process_native_host"] = {"error": repr(e)[:200]}
+    wasm = None
+    try:
+        wj = json.load(open(os.path.join(ROOT, "profiles", "r06", "c3_wasm_reference_cpu.json")))
+        wasm = {"value": BLOCK / (wj["us_per_block_mean"] * 1e-6), "unit": "samples/s", "cores": 1, "kind": "reference-wasm", "us_per_block": wj["us_per_block_mean"],
+                "sample": f"{wj['blocks_timed']} blocks of the same 8-channel graph on the reference's own wasm engine under Node (benchmarks/c3_wasm_baseline.js)",
+                "measured_on": wj.get("measured_on"), "host_cpu": wj.get("host_cpu"),
+                "note": "committed figure (profiles/r06/c3_wasm_reference_cpu.json): the reference's wasm build exists only where /root/reference does — not on the GPU box"}
+    except Exception:
+        pass
+    sn = host.get("sync_process_native_host") or {}
     return {
         "config": "BASELINE configs[2] (C3): 8-channel convolution reverb, root(convolve{ir<ch>}(in{ch})), 96 000-tap IRs (2 s at 48 kHz), blockSize 512",
         "protocol": f"elemhip_process_blocks, ONE call for the {steps} timed steps, one step = one launch set of {set_blocks} blocks of all 8 channels; inputs and outputs resident in HBM "
@@ -281,6 +341,11 @@ def c3(steps: int = 16, warmup: int = 2, set_blocks: int = 1024, gpu_only: bool 
                                    "partitioning with a plain radix-2 FFT, not Ooura's), channel after channel as one core would; convolve is not in the natively "
                                    "compiled reference (un-vendored FFTConvolver submodule)", "us_per_block": 1e6 * cpu_s_per_block},
         "speedup_vs_cpu_baseline": 1e6 * cpu_s_per_block / us,
+        "cpu_baseline_reference_wasm": wasm,
+        "host_boundary": host,
+        "sync_process_us_per_call": sn.get("us_p50"), "host_delivered_samples_per_s": (host.get("process_blocks_host") or {}).get("samples_per_s"),
+        "partition_mac": "vector FMA in registers (elemhip_convolve_long_mac, 0.8 GFLOP per set); the matrix-core Toeplitz kernel "
+                         "(elemhip_convolve_batch_mac_mfma, v_mfma_f32_4x4x1) serves sets that are no multiple of 8 blocks and IRs below 32 partitions",
         "parity": {"ok": bool(p_head["ok"] and p_tail["ok"]), "max_abs_err": max(p_head["max_abs_err"], p_tail["max_abs_err"]),
                    "tolerance": min(p_head["tolerance"], p_tail["tolerance"]), "head": p_head, "tail": p_tail,
                    "checker": "restatement, itself pinned to recordings of the reference's wasm engine (tests/golden/convolve_wasm*.f32)"},
@@ -301,7 +366,7 @@ def _tap_graph():
     return [el.add(*[loop(k, x) for k in range(0, 8, 2)]), el.add(*[loop(k, x) for k in range(1, 8, 2)])]
 
 
-def taps(steps: int = 8, warmup: int = 1, set_blocks: int = 256):
+def taps(steps: int = 8, warmup: int = 1, set_blocks: int = 256, gpu_only: bool = False):
     import numpy as np
     import torch
     from elementary_amd.runtime import Runtime
@@ -327,6 +392,9 @@ def taps(steps: int = 8, warmup: int = 1, set_blocks: int = 256):
     dt = time.perf_counter() - t0
     total = (warmup + steps) * set_blocks
     us = 1e6 * dt / (steps * set_blocks)
+    if gpu_only:      # (profiling passes: the GPU leg only, same launches)
+        return {"config": "taps (GPU leg only)", "value": BLOCK / (us * 1e-6), "unit": "samples/s", "steps": steps, "ms_per_step": 1e3 * dt / steps, "us_per_block": us,
+                "blocks_per_step": set_blocks, "launch_sets": steps + warmup}
     got = outs.cpu().numpy()
     cpu, kind = _ref_engine(sr)
     assert cpu.render(*_tap_graph())["result"] == 0
@@ -348,7 +416,8 @@ def taps(steps: int = 8, warmup: int = 1, set_blocks: int = 256):
         "protocol": f"elemhip_process_blocks, one step = one launch set of {set_blocks} blocks; input and outputs resident in HBM",
         "value": BLOCK / (us * 1e-6), "unit": "samples/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "us_per_block": us,
         "taps_in_sets": plan.get("taps_in_sets"), "spec_launches": st["spec_launches"], "batch_launches": st["batch_launches"],
-        "roofline": _roofline(alg, us, "sum(fanIn + outs) x 2 KB per block over the timed region; a tap loop keeps ONE block in flight per island: bound by the serial block-to-block hand-over"),
+        "roofline": _roofline(alg, us, "sum(fanIn + outs) x 2 KB per block over the timed region; a tap loop keeps ONE block in flight per island: bound by the serial block-to-block hand-over",
+                              **dict(zip(("traffic", "traffic_source"), _traffic("taps", blocks_per_launch=set_blocks)))),
         "cpu_baseline": {"value": BLOCK / (cpu_us * 1e-6), "unit": "samples/s", "cores": 1, "kind": kind,
                          "sample": f"all {total} blocks of the same graph and input, one process() call per block", "us_per_block": cpu_us},
         "speedup_vs_cpu_baseline": cpu_us / us,
@@ -478,7 +547,7 @@ def _c5_reference_worker(args):
     return stats, out, kind
 
 
-def c5(commits: int = 520, blocks_after: int = 8, rate: float = 28.0, churn: bool = False, seconds: float = 6.0):
+def c5(commits: int = 520, blocks_after: int = 8, rate: float = 28.0, churn: bool = False, seconds: float = 6.0, gpu_only: bool = False):
     import multiprocessing as mp
     import numpy as np
     import torch
@@ -494,6 +563,9 @@ def c5(commits: int = 520, blocks_after: int = 8, rate: float = 28.0, churn: boo
     plan_mid = rt.describe_plan()
     out = torch.empty((64, 2, BLOCK), dtype=torch.float32, device="cuda")
     free = _c5_free_running(rt, texts, lambda k: rt.process_blocks(k, 2, out_ptr=out.data_ptr()), seconds, rate, first=commits + 1)
+    if gpu_only:      # (profiling passes: the GPU legs only, same launches)
+        return {"config": "C5 (GPU legs only)", "value": free["mutating_samples_per_s"], "unit": "samples/s", "free_running": free, "counted": counted,
+                "blocks_rendered": rt.stats()["blocks_rendered"]}
     st = rt.stats()
     plan = rt.describe_plan()
     # the reference engine through the same schedule AFTER the GPU legs (a latency measurement: nothing else of this script runs
@@ -529,7 +601,8 @@ def c5(commits: int = 520, blocks_after: int = 8, rate: float = 28.0, churn: boo
                     "interpreter_block_fraction_counted_leg": plan_mid.get("interp_block_fraction"),
                     "interpreter_block_fraction_whole_run": plan.get("interp_block_fraction"),
                     "spec_launches_counted_leg": st_mid["spec_launches"]},
-        "roofline": _roofline(alg, us_mut, "algorithmic bytes of the 128-voice graph per block / block time of the free-running leg under mutation"),
+        "roofline": _roofline(alg, us_mut, "algorithmic bytes of the 128-voice graph per block / block time of the free-running leg under mutation",
+                              **dict(zip(("traffic", "traffic_source"), _traffic("c5_churn" if churn else "c5")))),
         "cpu_baseline": {"value": BLOCK / (ref_us_block * 1e-6), "unit": "samples/s", "cores": 1, "kind": kind,
                          "sample": f"the counted leg on the reference engine: {commits} commits x {blocks_after} blocks, unpaced (it cannot keep up with {rate:g} commits/s + rendering in real time "
                                    "at this size: commit + blocks take longer than the pacing interval)" if ref_stats["wall_s"] > commits / rate else
@@ -547,7 +620,9 @@ def main():
     assert torch.cuda.is_available(), "needs a GPU: the HIP engine has no CPU fallback"
     torch.cuda.init()
     name = sys.argv[1]
-    fn = {"c1": c1, "c3": (lambda: c3(gpu_only="--gpu-only" in sys.argv)), "taps": taps, "c5": c5, "c5_churn": lambda: c5(commits=160, churn=True, seconds=4.0)}[name]
+    go = "--gpu-only" in sys.argv
+    fn = {"c1": c1, "c3": (lambda: c3(gpu_only=go)), "taps": (lambda: taps(gpu_only=go)), "c5": (lambda: c5(commits=160, seconds=3.0, gpu_only=True) if go else c5()),
+          "c5_churn": lambda: c5(commits=160, churn=True, seconds=4.0)}[name]
     print(json.dumps(fn()), flush=True)
 
 

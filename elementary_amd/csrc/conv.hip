@@ -801,7 +801,7 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
         if (macLds <= 64u * 1024u && longMacLds)
             hipLaunchKernelGGL(elemhip_convolve_long_mac_lds, dim3(numNodes, (lfft::kBins + kLongTile - 1u) / kLongTile), block, macLds, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
         else
-        hipLaunchKernelGGL(elemhip_convolve_long_mac, dim3(numNodes, (lfft::kBins + 255u) / 256u, (chunks + kLongRun - 1u) / kLongRun), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
+        hipLaunchKernelGGL(elemhip_convolve_long_mac, dim3(numNodes, lfft::M / 256u, (chunks + kLongRun - 1u) / kLongRun), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
         hipLaunchKernelGGL(elemhip_convolve_long_ifft, dim3(numNodes, chunks), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode, inDirect, numInCh, outDirect, numOutCh);
         (void)longStateBlocks;      // (the 512-partition state — spectra ring, overlap — is made on demand: launch_convolve_fix_overlap)
     }

@@ -21,6 +21,7 @@ enum : uint32_t {
     H_Q = 9,            // long partitions (4096 samples) of the IR, 0: the node has no long-partition spectra (conv_long.inc)
     H_HISTBLKS = 10,    // blocks of the time-domain input ring behind `overlap` (0: none)
     H_OVL_STALE = 11,   // a long-partition launch set rendered last: `overlap` is not what the next 512-partition evaluation needs (conv_long.inc)
+    H_UID = 12,         // a number no other convolver state of this engine carries (never 0): whose spectra a launch set's scratch ring holds (conv_long.inc)
     kHeaderDwords = 16,
 };
 }

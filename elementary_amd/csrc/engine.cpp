@@ -464,6 +464,8 @@ int Engine::setConvolverIr(Node& n, const ResourcePtr& res) {
     const size_t words = words512 + (size_t)R * 512 + (size_t)Qp * rowFloats;
     std::vector<uint32_t> blob(conv::kHeaderDwords + (size_t)P * 1024, 0u);
     blob[conv::H_P] = P; blob[conv::H_S] = S; blob[conv::H_Q] = Q; blob[conv::H_HISTBLKS] = R;
+    if (++convUid == 0u) convUid = 1u;
+    blob[conv::H_UID] = convUid;
     n.convQp = Qp; n.convHistBlocks = R; n.convP = P;
     convMaxQp = std::max(convMaxQp, Qp);
     convMinP = std::min(convMinP, P); convMaxP = std::max(convMaxP, P);   // (over the engine's lifetime: which MAC kernels a launch set needs)
@@ -2470,6 +2472,11 @@ void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32
     }
     const uint32_t longRows = (convLong && convMaxQp) ? convMaxQp - 1u : 0u;
     const bool longSet = longRows && batch >= 8u && (batch & 7u) == 0u;
+    {   // the scratch holds per-node headers (which convolver's spectra its ring carries from set to set, conv_long.inc): they mean
+        // something only under the layout they were written for — a new allocation or another set geometry starts from zeroed scratch
+        const uint64_t key = ((uint64_t)(uint32_t)batchBlocks << 32) | longRows;
+        if (key != convScratchKey && dConvScratch) { HIP_WARN(hipMemsetAsync(dConvScratch, 0, convScratchFloats * sizeof(float), stream)); convScratchKey = key; }
+    }
     if (longSet && stateBlocks > 1u) {
         convLongSets++;
         // staleness is a fact of a NODE (its header's H_OVL_STALE), not of the engine: a plan without this node may render
@@ -2619,6 +2626,7 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
                     dConvScratch = nullptr; convScratchFloats = 0;
                     HIP_OK(hipMalloc(&dConvScratch, need * sizeof(float)));
                     convScratchFloats = need;
+                    convScratchKey = ~0ull;        // (its per-node headers are garbage: zeroed before the first launch that reads them)
                 }
             }
             setInRing(nullptr, 0);

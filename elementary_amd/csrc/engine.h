@@ -354,6 +354,8 @@ private:
     bool hostOutDirect = true;             // process(): the epilogue kernel writes into the mapped pinned output block
     uint32_t convMinP = 0xFFFFFFFFu, convMaxP = 0;   // fewest / most partitions of any impulse response set so far
     bool convLong = true;                  // option "conv_long": launch sets of a multiple of 8 blocks render IRs of >= 32 partitions with 4096-sample partitions (conv_long.inc)
+    uint32_t convUid = 0;                  // conv::H_UID of the newest convolver state
+    uint64_t convScratchKey = ~0ull;       // (batch_blocks, long history rows) the scratch headers were zeroed for
     std::set<int32_t> convStaleNodes;      // convolve nodes last rendered by a long-partition set: their `overlap` is made on demand (fixConvOverlaps), per node
     void fixConvOverlaps(const Plan& p);   // ... before the next 512-partition evaluation (block-at-a-time launches, sets that are no multiple of 8 blocks)
     bool convLongMacLds = false;           // option "conv_long_mac_lds": the LDS-tiled partition sums (measured slower than the register kernel over L2: 36.6 vs 27.4 us per C3 set)

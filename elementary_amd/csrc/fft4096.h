@@ -31,7 +31,10 @@ constexpr uint32_t kBuf = M + M / 16;   // padded LDS buffer (c2 elements)
 constexpr uint32_t kThreads = 256;
 
 LFFT_FD c2 mk(float re, float im) { c2 v; v.x = re; v.y = im; return v; }
-LFFT_FD c2 cmul(c2 a, c2 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// complex product with two fused multiply-adds (r06: the library is compiled with -ffp-contract=off for the bit-exact node kernels, which
+// left every product here as mul, mul, sub / mul, mul, add — the transforms have a TOLERANCE (1e-6 on |y| <~ 1), not a bit pattern, to
+// meet, and the fused form is both the more accurate and a third fewer instructions of kernels that are bound by instruction issue)
+LFFT_FD c2 cmul(c2 a, c2 b) { return mk(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)); }
 LFFT_FD c2 cconj(c2 a) { return mk(a.x, -a.y); }
 LFFT_FD c2 mul_mi(c2 a) { return mk(a.y, -a.x); }      // a * -i
 LFFT_FD c2 mul_pi(c2 a) { return mk(-a.y, a.x); }      // a * +i
@@ -102,25 +105,23 @@ LFFT_FD void pass_write(c2* buf, uint32_t tid, uint32_t s, const c2 (&v)[16]) {
 
 // ---- real forward: the two spectrum bins k and 4096 - k from the complex transform Z of z[n] = x[2n] + i x[2n + 1] ----
 // U[k] = (Z[k] + conj Z[M-k]) - i w^k (Z[k] - conj Z[M-k]);  k in [0, 2048]; for k = 0 the partner bin is U[4096].
+// One complex product serves both bins: with t = w^k (Z[k] - conj Z[M-k]) the partner is U[M-k] = conj((Z[k] + conj Z[M-k]) + i t)
+// (w^(M-k) = -conj(w^k); r06 — the first build formed the second product separately).
 template <class WP>
 LFFT_FD void split_forward(const c2* buf, uint32_t k, WP W, c2& Uk, c2& Umk) {
     const c2 A = buf[pad(k)], B = buf[pad((M - k) & (M - 1u))];
-    const c2 wk = W[k];
-    const c2 s = A + cconj(B), d = A - cconj(B);
-    Uk = s - mul_pi(cmul(wk, d));
-    // U[M - k] = (B + conj A) - i w^(M-k) (B - conj A), w^(M-k) = -conj(w^k)
-    const c2 s2 = B + cconj(A), d2 = B - cconj(A);
-    Umk = s2 + mul_pi(cmul(cconj(wk), d2));
+    const c2 s = A + cconj(B), it = mul_pi(cmul(W[k], A - cconj(B)));
+    Uk = s - it;
+    Umk = cconj(s + it);
 }
 // ---- real inverse: the transform input conj(Zt[k]), conj(Zt[M-k]) from Y[k], Y[M-k] ----
 // Zt[k] = (Y[k] + conj Y[M-k]) + i conj(w^k) (Y[k] - conj Y[M-k]); the inverse runs as conj(FFT(conj Zt)): out[2n] = Re F[n], out[2n+1] = -Im F[n]
+// (again one product: conj(Zt[M-k]) = (Y[k] + conj Y[M-k]) - i t, t = conj(w^k) (Y[k] - conj Y[M-k]))
 template <class WP>
 LFFT_FD void split_inverse(c2 Yk, c2 Ymk, uint32_t k, WP W, c2& Zk, c2& Zmk) {
-    const c2 wk = W[k];
-    const c2 s = Yk + cconj(Ymk), d = Yk - cconj(Ymk);
-    Zk = cconj(s + mul_pi(cmul(cconj(wk), d)));
-    const c2 s2 = Ymk + cconj(Yk), d2 = Ymk - cconj(Yk);
-    Zmk = cconj(s2 - mul_pi(cmul(wk, d2)));                  // conj(w^(M-k)) = -w^k
+    const c2 s = Yk + cconj(Ymk), it = mul_pi(cmul(cconj(W[k]), Yk - cconj(Ymk)));
+    Zk = cconj(s + it);
+    Zmk = s - it;
 }
 
 } // namespace lfft
