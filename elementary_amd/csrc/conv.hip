@@ -771,7 +771,7 @@ size_t convolve_batch_scratch_floats(uint32_t maxBatch, uint32_t longHistRows) {
 // `anyShortPath`: some node of the level (or this set's size) still needs the 512-partition kernels.
 void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
                            uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch, uint32_t macMode,
-                           bool anyShortIr, bool anyLongIr, uint32_t longHistRows, bool anyShortPath, uint32_t longStateBlocks, bool longMacLds,
+                           bool anyShortIr, bool anyLongIr, uint32_t longHistRows, bool anyShortPath, uint32_t longStateBlocks, uint32_t longMacMode,
                            const float* inDirect, uint32_t numInCh, float* outDirect, uint32_t numOutCh) {
     const dim3 grid(numNodes, batch), block(256);
     const size_t perNode = convolve_batch_scratch_floats(maxBatch, longHistRows);
@@ -798,10 +798,12 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
         hipLaunchKernelGGL(elemhip_convolve_long_fft, dim3(numNodes, longHistRows + chunks), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode, inDirect, numInCh);
         // the partition sums: LDS-tiled while a tile's rows fit 64 KB of LDS (C3: 44.8 KB), else the register kernel over L2
         const size_t macLds = ((size_t)(2u * longHistRows + 1u) + chunks + kLongTaps) * kLongTile * sizeof(c2);     // rows <= histRows + chunks, Qp <= histRows + 1 (+ rounding)
-        if (macLds <= 64u * 1024u && longMacLds)
+        if (macLds <= 64u * 1024u && longMacMode == 1u)
             hipLaunchKernelGGL(elemhip_convolve_long_mac_lds, dim3(numNodes, (lfft::kBins + kLongTile - 1u) / kLongTile), block, macLds, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
+        else if (longMacMode == 2u)      // (A/B: runs of 32 chunks per thread — every spectrum row is read by 1.7 workgroups instead of 2.4, at two waves per SIMD)
+        hipLaunchKernelGGL(elemhip_convolve_long_mac<32u>, dim3(numNodes, lfft::M / 256u, (chunks + 31u) / 32u), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
         else
-        hipLaunchKernelGGL(elemhip_convolve_long_mac, dim3(numNodes, lfft::M / 256u, (chunks + kLongRun - 1u) / kLongRun), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
+        hipLaunchKernelGGL(elemhip_convolve_long_mac<kLongRun>, dim3(numNodes, lfft::M / 256u, (chunks + kLongRun - 1u) / kLongRun), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
         hipLaunchKernelGGL(elemhip_convolve_long_ifft, dim3(numNodes, chunks), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode, inDirect, numInCh, outDirect, numOutCh);
         (void)longStateBlocks;      // (the 512-partition state — spectra ring, overlap — is made on demand: launch_convolve_fix_overlap)
     }

@@ -1612,7 +1612,7 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "resident_after") { residentAfter = (uint32_t)std::max(1.0, std::min(1e6, value)); return kOk; }
     if (key == "host_out_direct") { hostOutDirect = value != 0; return kOk; }   // elemhip_process: epilogue writes the pinned host block itself
     if (key == "conv_direct_io") { convDirectIo = value != 0; return kOk; }
-    if (key == "conv_long_mac_lds") { convLongMacLds = value != 0; return kOk; }   // long-partition sums: LDS-tiled kernel (1) or the register kernel over L2 (0)
+    if (key == "conv_long_mac_lds") { convLongMacMode = (uint32_t)std::max(0.0, std::min(2.0, value)); return kOk; }   // long-partition sums: 0 the register kernel over L2 (runs of 16 chunks), 1 the LDS-tiled kernel, 2 the register kernel with runs of 32 chunks
     if (key == "conv_long") { convLong = value != 0; return kOk; }   // IRs set from now on get (or do not get) long-partition spectra; sets of older IRs keep theirs
     if (key == "conv_mfma") { convMfma = std::max(0, std::min(1, (int)value)); return kOk; }   // partition MAC of launch sets: 1 matrix cores (default), 0 packed vector FMAs
     if (key == "skip_idle_launches") { skipIdleLaunches = value != 0; dropGraphs(); return kOk; }
@@ -1699,6 +1699,12 @@ int Engine::flushPending() {
         }
         for (uint32_t r : freshRecs) freshFlag[r] = 0;
         freshRecs.clear();
+    }
+    if (deviceClockBehind && !nextSetDirect) {      // (enqueueBatch: direct-I/O convolver sets leave the device's sample clock to be caught up here)
+        const uint64_t t = (uint64_t)hGlobals.sampleTime;
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, sampleTime) / 4), (uint32_t)(t & 0xFFFFFFFFu), 0u});
+        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, sampleTime) / 4 + 1), (uint32_t)(t >> 32), 0u});
+        deviceClockBehind = false;
     }
     size_t off = 0;
     while (off < patches.size()) {
@@ -2488,7 +2494,7 @@ void Engine::launchConvolveBatch(const Plan& p, size_t l, uint32_t batch, uint32
     }
     if (!longSet) fixConvOverlaps(p);
     launch_convolve_batch(stream, p.view, dRecs, dHbm, dGlobals, cb, mains, batch, arenaFloats, dConvScratch, (uint32_t)batchBlocks, (uint32_t)convMfma,
-                          convMinP <= convolve_mfma_max_partitions(), convMaxP > convolve_mfma_max_partitions(), longRows, anyShortPath, stateBlocks, convLongMacLds,
+                          convMinP <= convolve_mfma_max_partitions(), convMaxP > convolve_mfma_max_partitions(), longRows, anyShortPath, stateBlocks, convLongMacMode,
                           longSet ? setInDirect : nullptr, setNumIn, longSet ? setOutDirect : nullptr, setNumOut);
 }
 
@@ -2550,9 +2556,10 @@ void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
     if (setOutDirect) {
         // the convolvers wrote the caller's buffer themselves (chooseConvDirectIo): what is left of the epilogue is the device's sample
         // clock, moved on by a parameter patch (applied in stream order with the next call's patches)
-        const int64_t t = hGlobals.sampleTime + (int64_t)blockSize * (int64_t)batch;
-        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, sampleTime) / 4), (uint32_t)((uint64_t)t & 0xFFFFFFFFu), 0u});
-        patches.push_back(Patch{2u, (uint32_t)(offsetof(Globals, sampleTime) / 4 + 1), (uint32_t)((uint64_t)t >> 32), 0u});
+        // (r06: ... and only once something is about to READ it — a stream of such sets has no island, no epilogue and no other
+        //  reader of the clock, and a patch launch per set was 4 us of kernel plus its launch gap in front of every 70 us of work:
+        //  flushPending brings the device's clock up to the host's before the first launch that is not another direct set)
+        deviceClockBehind = true;
     } else if (!fused) {
         launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, outRing, batch, arenaFloats, armFlag, armValue);
         if (armFlag && batch == 1u) flagArmed = true;
@@ -2637,10 +2644,12 @@ int Engine::enqueueBlocks(const float* inDev, size_t nIn, float* outDev, size_t 
             setInDirect = dIn ? inDev + done * nIn * bs : nullptr; setNumIn = (uint32_t)nIn;
             setOutDirect = dOut ? (outTarget ? outTarget : dOutRing) : nullptr; setNumOut = (uint32_t)nOut;
             if (dIn || dOut) convDirectSets++;
+            nextSetDirect = dOut;
             if (haveIn && !dIn)   // host inputs of block b -> arena buffers 0..nIn-1 of block b's arena
                 HIP_OK(hipMemcpy2DAsync(dHbm, (size_t)p.numHbmBuffers * bs * sizeof(float), inDev + done * nIn * bs, nIn * bs * sizeof(float),
                                         nIn * bs * sizeof(float), chunk, hipMemcpyDeviceToDevice, stream));
             rc = flushPending();
+            nextSetDirect = false;
             if (rc != kOk) return rc;
             // the set's epilogue sums the roots straight into the caller's [block][channel][frame] buffer (r04: into the engine's ring and
             // a device-to-device copy behind it — 5.6 us of a 135 us C3 set, 100 us of a C4 set)

@@ -354,11 +354,13 @@ private:
     bool hostOutDirect = true;             // process(): the epilogue kernel writes into the mapped pinned output block
     uint32_t convMinP = 0xFFFFFFFFu, convMaxP = 0;   // fewest / most partitions of any impulse response set so far
     bool convLong = true;                  // option "conv_long": launch sets of a multiple of 8 blocks render IRs of >= 32 partitions with 4096-sample partitions (conv_long.inc)
+    bool deviceClockBehind = false;        // direct-I/O convolver sets moved hGlobals.sampleTime on without patching the device's copy (flushPending catches it up)
+    bool nextSetDirect = false;            // ... unless the launch being prepared is another such set
     uint32_t convUid = 0;                  // conv::H_UID of the newest convolver state
     uint64_t convScratchKey = ~0ull;       // (batch_blocks, long history rows) the scratch headers were zeroed for
     std::set<int32_t> convStaleNodes;      // convolve nodes last rendered by a long-partition set: their `overlap` is made on demand (fixConvOverlaps), per node
     void fixConvOverlaps(const Plan& p);   // ... before the next 512-partition evaluation (block-at-a-time launches, sets that are no multiple of 8 blocks)
-    bool convLongMacLds = false;           // option "conv_long_mac_lds": the LDS-tiled partition sums (measured slower than the register kernel over L2: 36.6 vs 27.4 us per C3 set)
+    uint32_t convLongMacMode = 0;          // option "conv_long_mac_lds": the LDS-tiled partition sums (measured slower than the register kernel over L2: 36.6 vs 27.4 us per C3 set)
     bool convDirectIo = true;              // option "conv_direct_io": a plan of long-partition convolvers only reads the caller's input / writes the caller's output in place
     // the launch set being enqueued (enqueueBlocks -> enqueueBatch -> launchConvolveBatch): where its convolvers read / write directly
     const float* setInDirect = nullptr; float* setOutDirect = nullptr; uint32_t setNumIn = 0, setNumOut = 0;

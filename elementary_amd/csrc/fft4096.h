@@ -73,8 +73,9 @@ LFFT_FD void dft16(c2 (&v)[16]) {
 
 // ---- one Stockham radix-16 pass of thread `tid` (pass s = 0, 1, 2; Ns = 16^s), in three phases with a barrier between them ----
 LFFT_FD void pass_read(const c2* buf, uint32_t tid, c2 (&v)[16]) {
+    const uint32_t p0 = pad(tid);                                   // pad(tid + 256 r) = pad(tid) + 272 r
 #pragma unroll
-    for (uint32_t r = 0; r < 16; ++r) v[r] = buf[pad(tid + kThreads * r)];
+    for (uint32_t r = 0; r < 16; ++r) v[r] = buf[p0 + r * (kThreads + kThreads / 16u)];
 }
 // v[r] *= exp(-2 pi i r k / (16 Ns)), k = tid mod Ns. The factors come from three small tables (LDS on the device: 3 KB; the first
 // build read them from the 8192-entry table in global memory, 15 scattered 8-byte loads per thread and pass):
@@ -83,10 +84,12 @@ LFFT_FD void pass_read(const c2* buf, uint32_t tid, c2 (&v)[16]) {
 constexpr uint32_t kTabT = 0, kTabA = 256, kTabB = 320, kTabSize = 384;
 // table entry i (0 .. kTabSize) as an index into the 8192-entry table w^j
 LFFT_FD uint32_t tab_source(uint32_t i) { return i < kTabA ? 32u * i : (i < kTabB ? 128u * (i - kTabA) : 2u * (i - kTabB)); }
-template <class TP>
-LFFT_FD void pass_twiddle(c2 (&v)[16], uint32_t tid, uint32_t s, TP tab) {
-    if (s == 0u) return;
-    if (s == 1u) {
+// (the pass number as a template argument: strides, masks and LDS offsets fold into the instructions — with a run-time `s` the r05
+//  kernels spent about a fifth of their instructions on index arithmetic; the run-time forms below dispatch to these)
+template <uint32_t S, class TP>
+LFFT_FD void pass_twiddle_s(c2 (&v)[16], uint32_t tid, TP tab) {
+    if (S == 0u) return;
+    if (S == 1u) {
         const uint32_t k = tid & 15u;
 #pragma unroll
         for (uint32_t r = 1; r < 16; ++r) v[r] = cmul(v[r], tab[kTabT + r * k]);
@@ -96,11 +99,23 @@ LFFT_FD void pass_twiddle(c2 (&v)[16], uint32_t tid, uint32_t s, TP tab) {
         for (uint32_t r = 1; r < 16; ++r) { const uint32_t j = r * k; v[r] = cmul(v[r], cmul(tab[kTabA + (j >> 6)], tab[kTabB + (j & 63u)])); }
     }
 }
-LFFT_FD void pass_write(c2* buf, uint32_t tid, uint32_t s, const c2 (&v)[16]) {
-    const uint32_t Ns = s == 0u ? 1u : (s == 1u ? 16u : 256u), k = tid & (Ns - 1u);
+template <uint32_t S>
+LFFT_FD void pass_write_s(c2* buf, uint32_t tid, const c2 (&v)[16]) {
+    constexpr uint32_t Ns = S == 0u ? 1u : (S == 1u ? 16u : 256u);
+    const uint32_t k = tid & (Ns - 1u);
     const uint32_t base = ((tid - k) << 4) + k;
+    // pad(base + r Ns) = pad(base) + r (Ns + Ns / 16) for Ns >= 16 (r Ns is a multiple of 16), = pad(base) + r for Ns = 1 (base is)
+    const uint32_t p0 = pad(base);
+    constexpr uint32_t step = Ns == 1u ? 1u : Ns + Ns / 16u;
 #pragma unroll
-    for (uint32_t r = 0; r < 16; ++r) buf[pad(base + r * Ns)] = v[r];
+    for (uint32_t r = 0; r < 16; ++r) buf[p0 + r * step] = v[r];
+}
+template <class TP>
+LFFT_FD void pass_twiddle(c2 (&v)[16], uint32_t tid, uint32_t s, TP tab) {
+    if (s == 1u) pass_twiddle_s<1u>(v, tid, tab); else if (s == 2u) pass_twiddle_s<2u>(v, tid, tab);
+}
+LFFT_FD void pass_write(c2* buf, uint32_t tid, uint32_t s, const c2 (&v)[16]) {
+    if (s == 0u) pass_write_s<0u>(buf, tid, v); else if (s == 1u) pass_write_s<1u>(buf, tid, v); else pass_write_s<2u>(buf, tid, v);
 }
 
 // ---- real forward: the two spectrum bins k and 4096 - k from the complex transform Z of z[n] = x[2n] + i x[2n + 1] ----

@@ -451,7 +451,7 @@ std::string Jit::fullSource(const std::string& generated, uint32_t ldsWords, uin
 // The key is a hash of the whole translation unit; its first ~300 KB are the same for every shape of one LDS size, so the hash
 // state behind them is kept (FNV-1a runs front to back: same keys as hashing the full source, a tenth of the time).
 bool Jit::setTuning(const std::string& name, int value) {
-    const bool ok = (name == "ELEMHIP_BIQUAD_FORM" && value >= 0 && value <= 2) ||
+    const bool ok = (name == "ELEMHIP_BIQUAD_FORM" && value >= 0 && value <= 5) ||
                     (name == "ELEMHIP_WIDE_CHAIN_DEPTH" && (value == 2 || value == 4 || value == 8));
     if (!ok) return false;
     std::lock_guard<std::mutex> l(gTuningMu);

@@ -45,7 +45,7 @@ void launch_convolve(hipStream_t s, const PlanView& pv, uint32_t* recs, float* h
 size_t convolve_batch_scratch_floats(uint32_t maxBatch, uint32_t longHistRows);   // per convolve node (longHistRows: 0 = no long-partition area)
 void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
                            uint32_t numNodes, uint32_t batch, uint32_t arenaFloats, float* scratch, uint32_t maxBatch, uint32_t macMode,
-                           bool anyShortIr, bool anyLongIr, uint32_t longHistRows, bool anyShortPath, uint32_t longStateBlocks, bool longMacLds,
+                           bool anyShortIr, bool anyLongIr, uint32_t longHistRows, bool anyShortPath, uint32_t longStateBlocks, uint32_t longMacMode,
                            const float* inDirect, uint32_t numInCh, float* outDirect, uint32_t numOutCh);
 void launch_convolve_fix_overlap(hipStream_t s, const PlanView& pv, uint32_t* recs, float* hbm, const Globals* g, uint32_t workBegin,
                                  uint32_t numWork, float* scratch, uint32_t maxBatch, uint32_t longHistRows, uint32_t maxPartitions);
