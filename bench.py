@@ -300,7 +300,10 @@ def main_c4(args) -> None:
     assert rt.render(*[graphs.c4_instance(inst * rank + k) for k in range(inst)])["result"] == 0
     build_ms = 1e3 * (time.perf_counter() - t0)
     spc = max(1, args.steps_per_call)
-    host_mode = world == 1 and not args.device_resident
+    # r06: the timed region leaves the jobs' samples in HBM at every N (`value` is never a PCIe-inclusive rate: 128 jobs x 2 KB per
+    # block-step are 268 MB per launch set, which the host link — not the kernels — bounds at ~11.7 ms); the delivery into the
+    # caller's host arrays (elemhip_process_blocks_host, r03-r05's `value`) is measured right after and reported as `host_delivered`
+    host_mode = world == 1 and args.host_delivered
     out = torch.zeros((spc * B, inst, BLOCK), dtype=torch.float32, device="cuda")
     gathered_elems = 0
 
@@ -341,7 +344,53 @@ def main_c4(args) -> None:
         dt = float(t.item())
     if rank == 0:
         blocks = args.steps * B
-        parity = c4_parity(timed_host, inst, inst * rank, (args.warmup + args.steps) * B) if host_mode else None
+        total_blocks = (args.warmup + args.steps) * B
+        if host_mode:
+            parity = c4_parity(timed_host, inst, inst * rank, total_blocks)
+        elif world == 1:
+            # the last timed step is still in the device buffer [block][job][frame]: its last blocks, job by job, against reference engines
+            # advanced through the whole run
+            tail_blocks = min(64, B)
+            last = out[((args.steps - 1) % spc) * B:((args.steps - 1) % spc + 1) * B][-tail_blocks:].permute(1, 0, 2).reshape(inst, tail_blocks * BLOCK).cpu().numpy()
+            parity = c4_parity(last, inst, inst * rank, total_blocks, tail=tail_blocks)
+        else:
+            parity = None
+        host_delivered = None
+        if world == 1 and not host_mode and not args.no_host_leg:
+            hs = max(2, min(args.steps, 8))
+            hbuf = np.zeros((inst, hs * B * BLOCK), dtype=np.float32)
+            rt.process_blocks_host(None, inst, B * BLOCK, out=hbuf[:, :B * BLOCK])      # staging buffers, pages
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            rt.process_blocks_host(None, inst, hs * B * BLOCK, out=hbuf)
+            dth = time.perf_counter() - t1
+            host_delivered = {"value": inst * BLOCK * hs * B / dth, "unit": "samples/s", "ms_per_step": 1e3 * dth / hs, "steps": hs,
+                              "bytes_per_step": inst * B * BLOCK * 4, "delivered_GBps": inst * B * BLOCK * 4 * hs / dth / 1e9,
+                              "mode": "elemhip_process_blocks_host: every job's samples delivered to the caller's planar host arrays (the host link is the bound)"}
+            del hbuf
+        full_chip = None
+        if world == 1 and args.full_chip and inst < 256 :
+            # the half-empty chip is the configuration's choice (1024 jobs over 8 GPUs = 128 per GPU, one island per CU): the same jobs at one per CU
+            try:
+                rt2 = Runtime(graphs.C4_SAMPLE_RATE, BLOCK, device=local)
+                rt2.set_option("batch_blocks", B)
+                rt2.set_option("specialize", args.specialize)
+                assert rt2.render(*[graphs.c4_instance(k) for k in range(256)])["result"] == 0
+                out2 = torch.zeros((B, 256, BLOCK), dtype=torch.float32, device="cuda")
+                for _ in range(2):
+                    rt2.process_blocks(B, 256, out_ptr=out2.data_ptr())
+                torch.cuda.synchronize()
+                fs = max(2, min(args.steps, 6))
+                t1 = time.perf_counter()
+                for _ in range(fs):
+                    rt2.process_blocks(B, 256, out_ptr=out2.data_ptr())
+                torch.cuda.synchronize()
+                dtf = time.perf_counter() - t1
+                full_chip = {"instances": 256, "value": 256 * BLOCK * fs * B / dtf, "unit": "samples/s", "ms_per_step": 1e3 * dtf / fs, "steps": fs,
+                             "mode": "device-resident; 256 jobs = one island per CU of the whole chip (not a BASELINE geometry; not parity-checked here: tests/test_gpu_baseline_sizes.py renders the same jobs)"}
+                del rt2, out2
+            except Exception as e:      # noqa: BLE001
+                full_chip = {"error": repr(e)[:200]}
         base = None if args.no_cpu_baseline else c4_cpu_baseline(inst, inst * rank)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_c4.json")
@@ -368,17 +417,18 @@ def main_c4(args) -> None:
                        "instances_per_gpu": inst, "instances_total": inst * world, "ranks_seen": ranks_seen,
                        "blocks_per_step": B, "islands": stats["num_islands"], "launch_levels": stats["num_levels"],
                        "mode": "host buffers (elemhip_process_blocks_host): every job's samples delivered to the caller's arrays" if host_mode
-                               else "device-resident render (elemhip_process_blocks)",
+                               else "device-resident render (elemhip_process_blocks): the jobs' samples stay in HBM; `host_delivered` = the same through elemhip_process_blocks_host",
                        "collectives": ("none on one GPU" if world == 1 else
                                        "RCCL gather of every chunk's per-job outputs on rank 0 inside the timed region "
                                        f"({gathered_elems * 4 / max(1, args.steps) / 1e6:.1f} MB per step); nothing is exchanged while rendering")},
-            "us_per_block_step": us, "plan_build_ms": build_ms,
+            "us_per_block_step": us, "plan_build_ms": build_ms, "host_delivered": host_delivered, "full_chip_256_jobs": full_chip,
+            "instances_256_samples_per_s": (full_chip or {}).get("value"), "host_delivered_samples_per_s": (host_delivered or {}).get("value"),
             "roofline": {"bound": "hbm", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_block_step": alg, "algorithmic_bytes_per_launch_set": alg * B,
                          "launch_us_per_step": [1e3 * x / sets for x in prof["level_ms"]],
-                         "note": "bound by the float recurrences (biquad, delay feedback) of the instances, not by bytes; `traffic` = PMC HBM "
-                                 "bytes of one launch set (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md)"},
+                         "note": "bound by the biquad recurrence wave of a job island (one lane of one wave: 8 VALU slots per frame, DESIGN 4), on 128 of "
+                                 "256 CUs; `traffic` = PMC HBM bytes of one launch set (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md)"},
             "cpu_baseline": base, "speedup_vs_cpu_baseline": (world * inst * BLOCK * blocks / dt) / base["value"] if base else None,
             "speedup_vs_cpu_baseline_note": (f"GPU rate / the reference engine on ALL {base['cores']} host cores this process may use" if base else None),
             "parity": parity,
@@ -410,6 +460,9 @@ def main() -> None:
                     help="N > 1, c2: compare the last reduced chunk on rank 0 with the reference engine rendering the whole graph")
     ap.add_argument("--device-resident", action="store_true",
                     help="time elemhip_process_blocks with the output bus left in HBM (the r01/r02 protocol) instead of the host-buffer entry")
+    ap.add_argument("--host-delivered", action="store_true", help="--workload c4: time elemhip_process_blocks_host (r03-r05's protocol) instead of the device-resident render")
+    ap.add_argument("--no-host-leg", action="store_true", help="--workload c4: skip the host-delivered sub-record")
+    ap.add_argument("--no-full-chip", dest="full_chip", action="store_false", help="--workload c4: skip the 256-job sub-record")
     ap.add_argument("--voices", type=int, default=256)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra engine option (tuning experiments), repeatable")
     ap.add_argument("--specialize", type=int, default=2, choices=[0, 1, 2],

@@ -172,9 +172,9 @@ std::string emitSpecSource(const Island& I, const std::vector<Task>& tasks, cons
     if (wavesPerEu) o << "__attribute__((amdgpu_waves_per_eu(" << wavesPerEu << ", " << wavesPerEu << "))) ";
     o << "void elemhip_spec_island(PlanView pv, uint32_t* recs, float* hbm, const Globals* g,\n"
          "        const uint32_t* lcg, const uint32_t* islandList, uint32_t batch, uint32_t arenaFloats, uint32_t streamBase, uint32_t streamSlice,\n"
-         "        uint32_t epiGroups, float* epiOut) {\n"
+         "        uint32_t epiGroups, float* epiOut, uint32_t* epiFlag, uint32_t epiValue) {\n"
          "    spec_island_main<gen::P>(pv, recs, hbm, g, lcg, islandList, batch, arenaFloats, streamBase, streamSlice);\n"
-         "    spec_epilogue_tail(pv, recs, hbm, g, epiGroups, epiOut);\n}\n";
+         "    spec_epilogue_tail(pv, recs, hbm, g, epiGroups, epiOut, epiFlag, epiValue);\n}\n";
     return o.str();
 }
 

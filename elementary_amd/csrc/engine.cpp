@@ -136,6 +136,7 @@ Engine::Engine(double sr, int bs, int dev) : sampleRate(sr), blockSize(bs), devi
     }
     if (const char* e = std::getenv("ELEMHIP_SPECIALIZE")) specialize = std::max(0, std::min(2, std::atoi(e)));
     if (const char* e = std::getenv("ELEMHIP_SYNC_POLL")) syncPoll = std::atoi(e) != 0;
+    if (const char* e = std::getenv("ELEMHIP_FUSE_EPILOGUE")) fuseEpilogue = std::atoi(e) != 0;   // (a native host without access to the options)
     if (const char* e = std::getenv("ELEMHIP_RESIDENT")) residentOpt = std::atoi(e) != 0;   // (a native host without access to the options)
     if (const char* e = std::getenv("ELEMHIP_PLAN_CACHE")) planCache = std::max(0, std::min(2, std::atoi(e)));   // 2: verify mode (tests)
     if (bs <= 0 || bs > (int)kMaxBlock) { fail(kBlockTooLarge); return; }
@@ -2438,7 +2439,9 @@ bool Engine::launchLevelBatch(const Plan& p, size_t l, uint32_t batch, uint32_t 
         uint32_t bt = batch, af = arenaFloats, sb = batch * arenaFloats, ss = p.numStreamBuffers * (uint32_t)blockSize;
         uint32_t eg = fused ? f.second->count : 0u;
         float* eo = fused ? epiOut : nullptr;
-        void* args[] = {&pv, &recs, &hbm, &g, &lcg, &list, &bt, &af, &sb, &ss, &eg, &eo};
+        uint32_t* ef = (fused && armFlag) ? armFlag : nullptr;      // the fused tail publishes elemhip_process' completion word itself
+        uint32_t ev = armValue;
+        void* args[] = {&pv, &recs, &hbm, &g, &lcg, &list, &bt, &af, &sb, &ss, &eg, &eo, &ef, &ev};
         const uint32_t gy = f.second->stateless ? std::max(1u, std::min(batch, statelessRows)) : 1u;
         HIP_WARN(hipModuleLaunchKernel(f.first, f.second->count, gy, 1, kThreads, 1, 1, 0, st_, args, nullptr));
         st.specLaunches++;
@@ -2563,7 +2566,7 @@ void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
     } else if (!fused) {
         launch_epilogue_batch(stream, p.view, dRecs, dHbm, dGlobals, outRing, batch, arenaFloats, armFlag, armValue);
         if (armFlag && batch == 1u) flagArmed = true;
-    } else st.fusedEpilogues++;
+    } else { st.fusedEpilogues++; if (armFlag && batch == 1u) flagArmed = true; }
     debugSync("set: epilogue", batch);
     if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)L); profSets++; profBlocks += batch; }
 }

@@ -11,9 +11,9 @@ for name in "$@"; do
   case $name in
     c2) CMD="python $R/bench.py --no-cpu-baseline --no-configs --steps 20 --warmup 5";;
     c3) CMD="python $R/benchmarks/driver_configs.py c3 --gpu-only";;
-    c4) CMD="python $R/bench.py --workload c4 --no-cpu-baseline --steps 12 --warmup 3";;
-    c4x64) CMD="python $R/bench.py --workload c4 --instances 64 --no-cpu-baseline --steps 12 --warmup 3";;
-    c4x256) CMD="python $R/bench.py --workload c4 --instances 256 --no-cpu-baseline --steps 12 --warmup 3";;
+    c4) CMD="python $R/bench.py --workload c4 --no-cpu-baseline --no-host-leg --no-full-chip --steps 12 --warmup 3";;
+    c4x64) CMD="python $R/bench.py --workload c4 --instances 64 --no-cpu-baseline --no-host-leg --no-full-chip --steps 12 --warmup 3";;
+    c4x256) CMD="python $R/bench.py --workload c4 --instances 256 --no-cpu-baseline --no-host-leg --no-full-chip --steps 12 --warmup 3";;
     c1) python -m elementary_amd.tools dump c1 $O/c1_batch.json > /dev/null 2>&1; CMD="$R/examples/bench_cli $O/c1_batch.json 4000 44100";;   # (the native host itself: rocprofv3 does not follow a subprocess)
     c5) CMD="python $R/benchmarks/driver_configs.py c5 --gpu-only";;
     taps) CMD="python $R/benchmarks/driver_configs.py taps --gpu-only";;

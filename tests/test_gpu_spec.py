@@ -235,8 +235,11 @@ def test_fused_epilogue_of_a_single_block_call(gpu_required, name):
                 assert rt.render(*roots[::-1])["result"] == 0          # roots swap channels: old ones fade out, new ones fade in
             ys.append(rt.process(xin, n_out + (1 if 30 <= k < 34 else 0), 512)[:n_out])
         outs[fuse] = np.stack(ys)
-        fused = rt.describe_plan()["plan_fused_epilogues"]
+        plan = rt.describe_plan()
+        fused = plan["plan_fused_epilogues"]
         assert (fused >= 20) if fuse else (fused == 0), fused
+        # r06: the fused tail publishes the call's completion word itself — a fused call ends on the polled word like any other
+        assert plan["sync_polls"] >= 38 and plan["sync_poll_fallbacks"] == 0, (plan["sync_polls"], plan["sync_poll_fallbacks"])
     assert np.array_equal(outs[1], outs[0])
     c = _checker(sr, 512)
     assert c.render(*roots)["result"] == 0

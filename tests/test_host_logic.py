@@ -422,6 +422,71 @@ print(json.dumps(rt.describe_plan()))
     assert 0.0 <= p["interp_block_fraction"] <= 1.0
 
 
+def test_kernel_cache_trusts_only_a_directory_of_its_own(tmp_path):
+    """the on-disk kernel cache holds code this process will RUN. (a) A cache directory other users may write to
+    is not used at all: the shape still compiles (the helper works in a private scratch directory) but nothing is read from or
+    published to the directory. (b) In a trusted directory a file that is not a gfx code object, and a symlink of the right name,
+    are ignored and replaced by a real compile; compile scratch directories do not stay behind; published files are ELF objects
+    for EM_AMDGPU that nobody else may write."""
+    import json
+    import stat
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import json, sys
+sys.path.insert(0, %r)
+import torch
+from elementary_amd import el
+from elementary_amd.runtime import Runtime
+rt = Runtime(44100.0, 512, device=-1)
+rt.set_option("specialize", 2)
+assert rt.render(el.tanh(el.lowpass(432.0, 0.7, el.in_({"channel": 0}))))["result"] == 0
+print(json.dumps(rt.describe_plan()))
+""" % root
+
+    def run(kc):
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, ELEMHIP_KCACHE=str(kc)))
+        assert res.returncode == 0, res.stderr[-2000:]
+        return json.loads(res.stdout.strip().splitlines()[-1]), res.stderr
+
+    # (a) a world-writable directory
+    open_dir = tmp_path / "open"
+    open_dir.mkdir()
+    os.chmod(open_dir, 0o777)
+    p, err = run(open_dir)
+    assert p["shapes"]["ready"] == p["shapes"]["total"] >= 1 and p["jit"]["compiles"] >= 1 and p["jit"]["disk_hits"] == 0
+    assert "on-disk kernel cache is off" in err
+    assert [f for f in os.listdir(open_dir)] == []
+    # (b) a directory of our own: first run compiles and publishes
+    own = tmp_path / "own"
+    p, _ = run(own)
+    assert stat.S_IMODE(os.stat(own).st_mode) == 0o700
+    files = sorted(os.listdir(own))
+    assert files and all(f.endswith(".hsaco") for f in files), files          # no scratch directory, no temp file left behind
+    for f in files:
+        raw = open(own / f, "rb").read()
+        assert raw[:4] == b"\x7fELF" and raw[4] == 2 and int.from_bytes(raw[18:20], "little") == 224
+        assert stat.S_IMODE(os.stat(own / f).st_mode) & 0o022 == 0
+    # second run: disk hits
+    p2, _ = run(own)
+    assert p2["jit"]["disk_hits"] >= 1 and p2["jit"]["compiles"] == 0
+    # a planted file of the right name that is not a code object, then a symlink of the right name: both ignored, compiled afresh
+    victim = own / files[0]
+    good = open(victim, "rb").read()
+    open(victim, "wb").write(b"#!/bin/sh\necho not a code object\n" * 40)
+    p3, _ = run(own)
+    assert p3["jit"]["compiles"] >= 1 and p3["shapes"]["ready"] == p3["shapes"]["total"]
+    assert open(victim, "rb").read()[:4] == b"\x7fELF"
+    os.remove(victim)
+    elsewhere = tmp_path / "elsewhere.hsaco"
+    open(elsewhere, "wb").write(good)
+    os.symlink(elsewhere, victim)
+    p4, _ = run(own)
+    assert p4["jit"]["compiles"] >= 1                                       # the link was not followed as a cache hit
+    assert not os.path.islink(victim)                                       # ... and the publish replaced it with a file of our own
+
+
 def test_fft4096_core_on_the_host():
     """elementary_amd/csrc/fft4096.h (the transform core of the long-partition convolver, conv_long.inc) compiled for the HOST:
     256 emulated threads, forward / inverse real transforms of 8192 samples against a double-precision DFT and one overlap-save
