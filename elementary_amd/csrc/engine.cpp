@@ -2555,7 +2555,7 @@ void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
         launchConvolveBatch(p, l, batch, arenaFloats);
         if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)l); }
     }
-    if (prof) (void)hipEventRecord(profEvent(), stream);
+    if (prof && !setOutDirect) (void)hipEventRecord(profEvent(), stream);      // (a direct-I/O set has no epilogue to bracket: two stream operations less per set)
     if (setOutDirect) {
         // the convolvers wrote the caller's buffer themselves (chooseConvDirectIo): what is left of the epilogue is the device's sample
         // clock, moved on by a parameter patch (applied in stream order with the next call's patches)
@@ -2568,7 +2568,8 @@ void Engine::enqueueBatch(const Plan& p, uint32_t batch, float* outRing) {
         if (armFlag && batch == 1u) flagArmed = true;
     } else { st.fusedEpilogues++; if (armFlag && batch == 1u) flagArmed = true; }
     debugSync("set: epilogue", batch);
-    if (prof) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)L); profSets++; profBlocks += batch; }
+    if (prof && !setOutDirect) { (void)hipEventRecord(profEvent(), stream); profSlots.push_back((uint32_t)L); }
+    if (prof) { profSets++; profBlocks += batch; if (profMs.size() <= L) profMs.resize(L + 1, 0.0); }     // (slot L = the epilogue, 0 for direct sets)
 }
 
 bool Engine::specBlockOk(const Plan& p) const { return specBlocks && p.convs.empty() && p.hosts.empty() && specReady(p); }

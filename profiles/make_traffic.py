@@ -46,29 +46,7 @@ if c2:
               open(os.path.join(here, "traffic.json"), "w"), indent=1)
     print("traffic.json", total / 1e6, "MB per set")
 
-c3 = load("c3")
-if c3:
-    names = ["elemhip_convolve_long_fft", "elemhip_convolve_long_mac", "elemhip_convolve_long_ifft", "elemhip_convolve_long_state", "elemhip_convolve_long_tail",
-             "elemhip_epilogue_batch_kernel", "elemhip_patch_kernel"]
-    per, us = {}, {}
-    for n in names:
-        rows = [r for r in c3["pmc"] if r["kernel"].startswith(n) and r.get("dispatches", 0) >= 10]
-        if rows:
-            rows.sort(key=lambda r: -r.get("hbm_bytes_per_dispatch", 0.0))
-            r = rows[0]
-            per[n] = {"hbm_bytes_per_dispatch": r.get("hbm_bytes_per_dispatch"), "fetch_bytes_corrected_x2": r.get("fetch_bytes_corrected_x2_mean"), "write_bytes": r.get("write_bytes_mean")}
-        m = mean_us(c3, n)
-        if m is not None and rows:
-            us[n] = m
-    total = sum(v["hbm_bytes_per_dispatch"] or 0.0 for v in per.values())
-    copies = {r["kernel"][:40]: r.get("hbm_bytes_per_dispatch") for r in c3["pmc"] if r["kernel"].startswith("__amd_rocclr_copy") and r.get("dispatches", 0) >= 10}
-    json.dump({"blocks_per_launch": 1024, "channels": 8, "long_partitions": 24, "hbm_bytes_per_launch_set": total, "algorithmic_bytes_per_launch_set": 1309851648,
-               "per_kernel": per, "kernel_mean_us": us, "engine_copies_per_set_not_kernels_of_the_path": copies,
-               "command_own_step_time": c3.get("command_own_step_time"), "round": tag,
-               "source": f"profiles/{tag}/c3_n1_rocprof_summary.json, separate --pmc passes of `{c3.get('command', '')}`"},
-              open(os.path.join(here, "traffic_c3.json"), "w"), indent=1)
-    print("traffic_c3.json", total / 1e6, "MB per set", us)
-
+# (C3 and the other appended configurations: profiles/make_traffic_cfgs.py -> traffic_cfgs.json)
 c4 = load("c4")
 if c4:
     isl = [r for r in c4["pmc"] if r["kernel"].startswith("elemhip_spec_island") and r.get("part") == "sets"]

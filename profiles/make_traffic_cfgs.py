@@ -24,7 +24,7 @@ def load(name):
 
 
 def own_total(j):
-    rows = [r for r in j["pmc"] if r["kernel"].startswith("elemhip_")]
+    rows = [r for r in j["pmc"] if "elemhip_" in r["kernel"] and "hbm_bytes_per_dispatch" in r]
     return sum(r["dispatches"] * r["hbm_bytes_per_dispatch"] for r in rows), {f'{r["kernel"]} [{r["grid_work_items_total"]} work-items{", " + r["part"] if r.get("part") else ""}]':
                                                                                {"dispatches": r["dispatches"], "hbm_bytes_per_dispatch": r["hbm_bytes_per_dispatch"]} for r in rows}
 
@@ -46,12 +46,12 @@ j = load("c3")
 if j:
     per = {}
     for k in ("elemhip_convolve_long_fft", "elemhip_convolve_long_mac", "elemhip_convolve_long_ifft"):
-        rows = sorted([r for r in j["pmc"] if r["kernel"].startswith(k)], key=lambda r: -r["dispatches"])
+        rows = sorted([r for r in j["pmc"] if k in r["kernel"]], key=lambda r: -r["dispatches"])
         if rows:
             per[k] = {"hbm_bytes_per_dispatch": rows[0]["hbm_bytes_per_dispatch"], "fetch_x2": rows[0]["fetch_bytes_corrected_x2_mean"], "write": rows[0]["write_bytes_mean"]}
     us = {}
     for k in per:
-        rows = sorted([r for r in j["kernel_trace"] if r["kernel"].startswith(k)], key=lambda r: -r["dispatches"])
+        rows = sorted([r for r in j["kernel_trace"] if k in r["kernel"]], key=lambda r: -r["dispatches"])
         if rows:
             us[k] = rows[0]["mean_us"]
     out["c3"] = {"hbm_bytes_per_launch": sum(v["hbm_bytes_per_dispatch"] for v in per.values()), "per": "launch set of 1024 blocks x 8 channels", "blocks_per_launch": 1024, "channels": 8,

@@ -370,9 +370,10 @@ def test_release_library_carries_no_measurement_hooks():
     rt = Runtime(48000.0, 512, device=-1)
     rt.set_option("conv_mfma", 2)                    # clamped to 1: the operand-swapped bring-up probe is gone
     rt.set_option("biquad_form", 1)
-    rt.set_option("biquad_form", 0)
+    rt.set_option("biquad_form", 5)                  # (r06: forms 0-5, every one the reference's nine IEEE operations on the same operands)
+    rt.set_option("biquad_form", 4)                  # ... back to the default
     with pytest.raises(ElemHipError):
-        rt.set_option("biquad_form", 3)
+        rt.set_option("biquad_form", 6)
     with pytest.raises(ElemHipError):
         rt.set_option("stream_ring", 0)
     # and the stripper itself: nested, #elif chains, #else branches
