@@ -472,9 +472,15 @@ def _c5_counted(rt, texts, commits, blocks_after, rate, keep=True, gc_every=16, 
     """The CHECKABLE leg: commit k, then the first block of the new graph (timed with the commit), then `blocks_after` - 1 more
     synchronous blocks; commits paced at `rate` per second of wall clock when the engine is faster than that. Every rendered block
     is kept, so the reference engine driven through the same schedule must produce the same samples."""
+    import gc as _pygc
     import numpy as np
     process = process or (lambda: rt.process(None, 2, BLOCK))
     assert rt.apply_instructions_json(texts[0]) == 0
+    # (r06: the harness's own cyclic garbage collector stays out of the latency samples — for the reference engine's leg as well; a
+    #  collection of this process's Python objects is a millisecond that neither engine spent)
+    _pygc.collect()
+    _gc_was = _pygc.isenabled()
+    _pygc.disable()
     pre = 48
     out = np.empty((pre + commits * blocks_after, 2, BLOCK), dtype=np.float32) if keep else None
     n = 0
@@ -507,6 +513,8 @@ def _c5_counted(rt, texts, commits, blocks_after, rate, keep=True, gc_every=16, 
         if k % gc_every == 0:
             gcs.append(len(rt.gc()))
     wall = time.perf_counter() - t0
+    if _gc_was:
+        _pygc.enable()
     return {"commit_to_first_block_ms": {"p50": _pct(lat, 0.5), "p99": _pct(lat, 0.99), "max": max(lat), "count": len(lat)},
             "commit_call_ms": {"p50": _pct(lat_commit, 0.5), "p99": _pct(lat_commit, 0.99)},
             "first_block_ms": {"p50": _pct(lat_block, 0.5), "p99": _pct(lat_block, 0.99)},

@@ -63,10 +63,18 @@ if j:
     out["c1"] = {"hbm_bytes_per_launch": total / calls, "per": "synchronous elemhip_process call (native host, 4000 timed calls + 1 warm-up)", "kernels": rows, "round": tag}
 j = load("c5")
 if j:
-    total, rows = own_total(j)
-    blocks = last_json("c5").get("blocks_rendered")
-    if blocks:
-        out["c5"] = {"hbm_bytes_per_launch": total / blocks, "per": f"512-frame block of the 128-voice graph (all engine kernels of the GPU legs / {blocks} blocks rendered)", "kernels": rows, "round": tag}
+    # the free-running leg renders 64-block launch sets (its block count depends on the run's speed, and a PMC pass is slow: per-dispatch
+    # means are what carries over): one set = the voice level's launch + the mixer level's + the batch epilogue, each the most-dispatched
+    # row of its kind
+    def top(pred):
+        rows = sorted([r for r in j["pmc"] if pred(r) and "hbm_bytes_per_dispatch" in r], key=lambda r: -r["dispatches"])
+        return rows[0] if rows else None
+    voice = top(lambda r: r["kernel"].startswith("elemhip_spec_island") and r["lds_bytes"] > 100000 and r.get("part") == "sets")
+    mixer = top(lambda r: r["kernel"].startswith("elemhip_spec_island") and r["lds_bytes"] < 100000 and r["grid_work_items_total"] >= 65536)
+    epi = top(lambda r: r["kernel"].startswith("elemhip_epilogue_batch_kernel") and r["grid_work_items_total"] >= 32768)
+    parts = {k: v["hbm_bytes_per_dispatch"] for k, v in (("voice level (128 voice islands)", voice), ("mixer level", mixer), ("batch epilogue", epi)) if v}
+    out["c5"] = {"hbm_bytes_per_launch": sum(parts.values()), "per": "64-block launch set of the free-running leg (128 live voices)", "blocks_per_launch": 64,
+                 "per_kernel": parts, "round": tag}
 j = load("taps")
 if j:
     total, rows = own_total(j)
