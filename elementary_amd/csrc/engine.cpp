@@ -2053,7 +2053,7 @@ int Engine::processSliceLocked(const float* const* in, size_t nIn, float* const*
 // ---- option "resident" (resident.hip) -------------------------------------------------------------------------------------------
 bool Engine::residentEligible(const Plan& p, size_t nIn, size_t nOut) const {
     if (!p.convs.empty() || !p.hosts.empty() || profileLaunches || debugSyncOn() || hGlobals.trace) return false;
-    if (!patches.empty() || !freshRecs.empty() || !recClones.empty()) return false;
+    if (!patches.empty() || !freshRecs.empty() || !recClones.empty() || deviceClockBehind) return false;   // (something flushPending still has to bring to the device)
     if (p.view.numRoots > kResidentMaxRoots || p.levelOffsets.size() < 2 || p.levelOffsets.size() - 1 > kResidentMaxLevels) return false;
     if (p.levelOffsets.back() == 0u) return false;
     return batchEligible(p, nOut, true);      // every running root's fade settled: the epilogue has no per-root state to advance

@@ -261,6 +261,42 @@ def test_a_convolver_that_sits_out_a_plan_is_repaired_when_it_comes_back(gpu_req
     assert a.describe_plan()["conv_long_sets"] >= 3
 
 
+def test_the_sample_clock_after_direct_io_sets(gpu_required):
+    """A plan of long-partition convolvers only renders its launch sets with direct I/O: no epilogue kernel advances the device's
+    sample clock, and since r06 no parameter patch per set either — the clock is caught up when something is about to read it.
+    Convolver sets, then a graph whose samples ARE the clock (`time`, `metro`: wasm/SampleTime.h, wasm/Metro.h) block at a time,
+    through a launch set, and through the opt-in resident kernel: every block against the restatement."""
+    from elementary_amd import el
+    ir = graphs.c3_impulse_response(0, 20000)
+    conv = [el.convolve({"path": "ir", "key": "x"}, el.in_({"channel": 0}))]
+    clock = [el.mul(1e-4, el.time()), el.metro({"interval": 3.0})]
+    for resident in (0, 1):
+        a, c = hip(48000.0, 512), oracle.PortRuntime(48000.0, 512)
+        a.set_option("resident", resident)
+        for rt in (a, c):
+            assert rt.add_shared_resource("ir", ir)
+        x = graphs.c3_input(1, 200 * 512)
+        k = 0
+        plan = [("render", conv), ("blocks", 16), ("blocks", 64), ("render", clock), ("one", 12), ("blocks", 16), ("one", 4),
+                ("render", conv), ("blocks", 24), ("render", clock), ("one", 6)]
+        for kind, arg in plan:
+            if kind == "render":
+                for rt in (a, c):
+                    assert rt.render(*arg)["result"] == 0
+                n_out = len(arg)
+                continue
+            ref = np.stack([c.process(x[:, (k + i) * 512:(k + i + 1) * 512], n_out, 512) for i in range(arg)])
+            if kind == "blocks":
+                got = _blocks(a, x, k, arg, n_out)
+            else:
+                got = np.stack([a.process(x[:, (k + i) * 512:(k + i + 1) * 512], n_out, 512) for i in range(arg)])
+            scale = max(1.0, float(np.abs(ref).max()))
+            err = np.abs(got.astype(np.float64) - ref).max(axis=(1, 2))
+            assert float(err.max()) <= TOL * scale, (resident, kind, arg, k, int(err.argmax()), float(err.max()))
+            k += arg
+        assert a.describe_plan()["conv_direct_io_sets"] >= 2
+
+
 def test_partial_blocks_switch_the_multi_block_path_off(gpu_required):
     """After a call of fewer than 512 frames a convolver's input block may be partly filled at a call boundary: the
     engine goes back to block-at-a-time launches for plans with convolvers (still the same samples)."""
