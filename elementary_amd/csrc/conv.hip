@@ -801,9 +801,9 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
         if (macLds <= 64u * 1024u && longMacMode == 1u)
             hipLaunchKernelGGL(elemhip_convolve_long_mac_lds, dim3(numNodes, (lfft::kBins + kLongTile - 1u) / kLongTile), block, macLds, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
         else if (longMacMode == 2u)      // (A/B: runs of 32 chunks per thread — every spectrum row is read by 1.7 workgroups instead of 2.4, at two waves per SIMD)
-        hipLaunchKernelGGL(elemhip_convolve_long_mac<32u>, dim3(numNodes, lfft::M / 256u, (chunks + 31u) / 32u), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
+        hipLaunchKernelGGL(elemhip_convolve_long_mac<32u>, dim3(numNodes, lfft::M / 256u, (chunks + 31u) / 32u), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode, 0u);
         else
-        hipLaunchKernelGGL(elemhip_convolve_long_mac<kLongRun>, dim3(numNodes, lfft::M / 256u, (chunks + kLongRun - 1u) / kLongRun), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
+        hipLaunchKernelGGL(elemhip_convolve_long_mac<kLongRun>, dim3(numNodes, lfft::M / 256u, (chunks + kLongRun - 1u) / kLongRun), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode, longMacMode == 3u ? 1u : 0u);
         hipLaunchKernelGGL(elemhip_convolve_long_ifft, dim3(numNodes, chunks), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode, inDirect, numInCh, outDirect, numOutCh);
         (void)longStateBlocks;      // (the 512-partition state — spectra ring, overlap — is made on demand: launch_convolve_fix_overlap)
     }

@@ -1613,7 +1613,7 @@ int Engine::setOption(const std::string& key, double value) {
     if (key == "resident_after") { residentAfter = (uint32_t)std::max(1.0, std::min(1e6, value)); return kOk; }
     if (key == "host_out_direct") { hostOutDirect = value != 0; return kOk; }   // elemhip_process: epilogue writes the pinned host block itself
     if (key == "conv_direct_io") { convDirectIo = value != 0; return kOk; }
-    if (key == "conv_long_mac_lds") { convLongMacMode = (uint32_t)std::max(0.0, std::min(2.0, value)); return kOk; }   // long-partition sums: 0 the register kernel over L2 (runs of 16 chunks), 1 the LDS-tiled kernel, 2 the register kernel with runs of 32 chunks
+    if (key == "conv_long_mac_lds") { convLongMacMode = (uint32_t)std::max(0.0, std::min(3.0, value)); return kOk; }   // long-partition sums: 0 the register kernel over L2 (runs of 16 chunks), 1 the LDS-tiled kernel, 2 the register kernel with runs of 32 chunks
     if (key == "conv_long") { convLong = value != 0; return kOk; }   // IRs set from now on get (or do not get) long-partition spectra; sets of older IRs keep theirs
     if (key == "conv_mfma") { convMfma = std::max(0, std::min(1, (int)value)); return kOk; }   // partition MAC of launch sets: 1 matrix cores (default), 0 packed vector FMAs
     if (key == "skip_idle_launches") { skipIdleLaunches = value != 0; dropGraphs(); return kOk; }
