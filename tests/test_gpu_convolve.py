@@ -261,6 +261,40 @@ def test_a_convolver_that_sits_out_a_plan_is_repaired_when_it_comes_back(gpu_req
     assert a.describe_plan()["conv_long_sets"] >= 3
 
 
+def test_long_partition_sets_back_to_back_carry_their_spectra(gpu_required):
+    """r06: the long-partition spectra `U` are a ring carried from set to set — a set's Q - 1 history rows are the previous set's last
+    rows, not transformed again — valid only while nothing else moved the node's block counter and the convolver state is the same one
+    (conv_long.inc, scratch header). Back-to-back sets of changing sizes (the ring wraps at different places), two nodes with IRs of
+    different length in one level (different history depths), a single block in between (the carry is off for one set), an IR swap
+    (a new state: nothing may be carried), and two engines whose scratch geometry differs (`batch_blocks` 64 and 256): every
+    stretch against the restatement."""
+    from elementary_amd import el
+    ir_a, ir_b, ir_c = graphs.c3_impulse_response(0, 96000), graphs.c3_impulse_response(1, 20000), graphs.c3_impulse_response(2, 40000)
+    roots = [el.convolve({"path": "ira", "key": "a"}, el.in_({"channel": 0})), el.convolve({"path": "irb", "key": "b"}, el.in_({"channel": 1}))]
+    steps = [("blocks", 8), ("blocks", 16), ("blocks", 8), ("blocks", 64), ("blocks", 24), ("blocks", 8), ("one", 1), ("blocks", 16), ("blocks", 16),
+             ("swap", 0), ("blocks", 8), ("blocks", 32), ("blocks", 8), ("blocks", 64)]
+    total = sum(n for kind, n in steps if kind != "swap")
+    x = graphs.c3_input(2, total * 512)
+    for batch in (64, 256):
+        a, c = hip(48000.0, 512), oracle.PortRuntime(48000.0, 512)
+        a.set_option("batch_blocks", batch)
+        for rt in (a, c):
+            assert rt.add_shared_resource("ira", ir_a) and rt.add_shared_resource("irb", ir_b) and rt.add_shared_resource("irc", ir_c)
+            assert rt.render(*roots)["result"] == 0
+        k = 0
+        for kind, n in steps:
+            if kind == "swap":
+                for rt in (a, c):
+                    assert rt.render(el.convolve({"path": "irc", "key": "a"}, el.in_({"channel": 0})), roots[1])["result"] == 0
+                continue
+            ref = np.stack([c.process(x[:, (k + i) * 512:(k + i + 1) * 512], 2, 512) for i in range(n)])
+            got = _blocks(a, x, k, n, 2) if kind == "blocks" else np.stack([a.process(x[:, (k + i) * 512:(k + i + 1) * 512], 2, 512) for i in range(n)])
+            err = np.abs(got.astype(np.float64) - ref).max(axis=(1, 2))
+            assert float(err.max()) <= TOL, (batch, kind, n, k, int(err.argmax()), float(err.max()))
+            k += n
+        assert a.describe_plan()["conv_long_sets"] >= 10
+
+
 def test_the_sample_clock_after_direct_io_sets(gpu_required):
     """A plan of long-partition convolvers only renders its launch sets with direct I/O: no epilogue kernel advances the device's
     sample clock, and since r06 no parameter patch per set either — the clock is caught up when something is about to read it.
