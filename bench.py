@@ -17,6 +17,13 @@ sum-reduced to rank 0 over RCCL inside the timed region and r
 host memory.  ``--scaling weak`` (default): every rank renders its own 256-voice graph, ``value`` = frames of all N
 graphs / max-over-ranks wall time; ``--scaling strong``: the ONE 256-voice graph is split over the ranks.
 
+Output (r06): every full record — the other configurations' (C1, C3, C4, C5, C5 shape churn, taps: a process each, after the
+headline's timed region) and then the headline's own — is printed as a JSON line of its own, tagged ``"record": <name>``; the LAST
+stdout line is ONE compact record under 4 KB (benchmarks/headline.py: metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+dtype / config / roofline / cpu_baseline / parity + a `configs` map of six numbers per configuration) — the line the driver parses.
+``--workload c4`` (BASELINE configs[3]) times the device-resident render of the jobs (`value`); the delivery of every job's samples
+into host arrays (bound by the host link) and the 256-job full-chip rate are sub-records.
+
 Launch (N > 1):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
                  --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -264,9 +271,10 @@ def run_configs(names, timeout_s: float):
 def main_c4(args) -> None:
     """BASELINE configs[3] (C4): `--instances` independent offline render jobs per GPU (1024 over 8 GPUs = 128 per GPU),
     "RCCL output gather". SURVEY.md 8(e): the unit of sharding is the whole render job, so ranks share nothing while they
-    render; the one exchange is the gather of the per-job outputs. N = 1: every job's samples are delivered to host memory
-    (elemhip_process_blocks_host). N > 1: each rank renders into HBM and the outputs of every chunk are gathered on rank 0
-    over RCCL (sharded.gather_outputs) INSIDE the timed region. Same timing protocol as the headline workload."""
+    render; the one exchange is the gather of the per-job outputs. N = 1 (r06): the timed region renders into HBM (`value` is not
+    a PCIe-inclusive rate); the delivery of every job's samples to host memory (elemhip_process_blocks_host, `--host-delivered`
+    times THAT instead) and the 256-job rate follow as sub-records. N > 1: each rank renders into HBM and the outputs of every
+    chunk are gathered on rank 0 over RCCL (sharded.gather_outputs) INSIDE the timed region. Same timing protocol as the headline."""
     import numpy as np
     import torch
     import torch.distributed as dist
