@@ -295,6 +295,51 @@ def test_long_partition_sets_back_to_back_carry_their_spectra(gpu_required):
         assert a.describe_plan()["conv_long_sets"] >= 10
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_call_sequences_through_every_convolve_path(gpu_required, seed):
+    """Seeded random streams over the convolver's three evaluations — single blocks, 512-partition sets (any size), long-partition
+    sets (multiples of 8, spectra carried between consecutive ones) — for 1-3 nodes with IRs of random lengths (some below the
+    32-partition threshold of the long path), random `batch_blocks`, an IR swap at a random place: every stretch against the
+    restatement. (The hand-written interleaving tests fix the orders somebody thought of.)"""
+    from elementary_amd import el
+    rng = np.random.default_rng(1000 + seed)
+    n_nodes = int(rng.integers(1, 4))
+    lens = [int(rng.choice([3000, 17000, 20000, 33000, 50000, 96000])) for _ in range(n_nodes)]
+    irs = [graphs.c3_impulse_response(i, lens[i]) for i in range(n_nodes)]
+    roots = [el.convolve({"path": f"ir{i}", "key": f"n{i}"}, el.in_({"channel": i})) for i in range(n_nodes)]
+    batch = int(rng.choice([32, 64, 128]))
+    steps = []
+    for _ in range(14):
+        kind = rng.choice(["long", "long", "long", "ragged", "one"])
+        if kind == "long":
+            steps.append(("blocks", int(8 * rng.integers(1, batch // 8 + 1))))
+        elif kind == "ragged":
+            steps.append(("blocks", int(rng.integers(2, 20))))
+        else:
+            steps.append(("one", int(rng.integers(1, 4))))
+    swap_at = int(rng.integers(3, 11))
+    total = sum(n for _, n in steps)
+    x = graphs.c3_input(n_nodes, total * 512)
+    a, c = hip(48000.0, 512), oracle.PortRuntime(48000.0, 512)
+    a.set_option("batch_blocks", batch)
+    for rt in (a, c):
+        for i, ir in enumerate(irs):
+            assert rt.add_shared_resource(f"ir{i}", ir)
+        assert rt.add_shared_resource("swap", graphs.c3_impulse_response(7, 24000))
+        assert rt.render(*roots)["result"] == 0
+    k = 0
+    for idx, (kind, n) in enumerate(steps):
+        if idx == swap_at:
+            new_roots = [el.convolve({"path": "swap", "key": "n0"}, el.in_({"channel": 0}))] + roots[1:]
+            for rt in (a, c):
+                assert rt.render(*new_roots)["result"] == 0
+        ref = np.stack([c.process(x[:, (k + i) * 512:(k + i + 1) * 512], n_nodes, 512) for i in range(n)])
+        got = _blocks(a, x, k, n, n_nodes) if kind == "blocks" else np.stack([a.process(x[:, (k + i) * 512:(k + i + 1) * 512], n_nodes, 512) for i in range(n)])
+        err = np.abs(got.astype(np.float64) - ref).max(axis=(1, 2))
+        assert float(err.max()) <= TOL, (seed, lens, batch, idx, kind, n, k, int(err.argmax()), float(err.max()))
+        k += n
+
+
 def test_the_sample_clock_after_direct_io_sets(gpu_required):
     """A plan of long-partition convolvers only renders its launch sets with direct I/O: no epilogue kernel advances the device's
     sample clock, and since r06 no parameter patch per set either — the clock is caught up when something is about to read it.
