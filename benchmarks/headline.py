@@ -124,6 +124,10 @@ def compact(full: dict) -> dict:
     dr = full.get("device_resident")
     if isinstance(dr, dict) and dr.get("value") is not None:
         out["device_resident"] = _pick(dr, ("value", "ms_per_step"))
+    for k in ("host_delivered", "full_chip_256_jobs"):           # (`--workload c4`: the legs behind the device-resident `value`)
+        v = full.get(k)
+        if isinstance(v, dict) and v.get("value") is not None:
+            out[k] = _pick(v, ("value", "ms_per_step", "steps"))
     cfgs = full.get("configs")
     if isinstance(cfgs, dict):
         red = {k: reduce_config(v) for k, v in cfgs.items() if isinstance(v, dict)}
