@@ -796,10 +796,10 @@ void launch_convolve_batch(hipStream_t s, const PlanView& pv, uint32_t* recs, fl
     if (longSet) {
         const uint32_t chunks = batch / 8u;
         hipLaunchKernelGGL(elemhip_convolve_long_fft, dim3(numNodes, longHistRows + chunks), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode, inDirect, numInCh);
-        // the partition sums: LDS-tiled while a tile's rows fit 64 KB of LDS (C3: 44.8 KB), else the register kernel over L2
-        const size_t macLds = ((size_t)(2u * longHistRows + 1u) + chunks + kLongTaps) * kLongTile * sizeof(c2);     // rows <= histRows + chunks, Qp <= histRows + 1 (+ rounding)
+        // the partition sums: LDS-tiled (mode 1) while a tile's rows fit 64 KB of LDS (C3: 40 KB), else the register kernel over L2
+        const size_t macLds = long_mac_tile_lds_bytes(longHistRows + 1u);      // (Qp <= histRows + 1)
         if (macLds <= 64u * 1024u && longMacMode == 1u)
-            hipLaunchKernelGGL(elemhip_convolve_long_mac_lds, dim3(numNodes, (lfft::kBins + kLongTile - 1u) / kLongTile), block, macLds, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
+            hipLaunchKernelGGL(elemhip_convolve_long_mac_lds, dim3(numNodes, lfft::M / kTileBins, (chunks + kTileRun - 1u) / kTileRun), dim3(512), macLds, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode);
         else if (longMacMode == 2u)      // (A/B: runs of 32 chunks per thread — every spectrum row is read by 1.7 workgroups instead of 2.4, at two waves per SIMD)
         hipLaunchKernelGGL(elemhip_convolve_long_mac<32u>, dim3(numNodes, lfft::M / 256u, (chunks + 31u) / 32u), block, 0, s, pv, recs, hbm, g, workBegin, arenaFloats, scratch, maxBatch, batch, longHistRows, longMode, perNode, 0u);
         else

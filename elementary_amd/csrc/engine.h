@@ -360,7 +360,7 @@ private:
     uint64_t convScratchKey = ~0ull;       // (batch_blocks, long history rows) the scratch headers were zeroed for
     std::set<int32_t> convStaleNodes;      // convolve nodes last rendered by a long-partition set: their `overlap` is made on demand (fixConvOverlaps), per node
     void fixConvOverlaps(const Plan& p);   // ... before the next 512-partition evaluation (block-at-a-time launches, sets that are no multiple of 8 blocks)
-    uint32_t convLongMacMode = 0;          // option "conv_long_mac_lds": the LDS-tiled partition sums (measured slower than the register kernel over L2: 36.6 vs 27.4 us per C3 set)
+    uint32_t convLongMacMode = 0;          // option "conv_long_mac_lds": 0 the register kernel (ships), 1 the LDS-tiled kernel (r06: 64 bins x 32 chunks; as fast, a third of the L2 traffic), 2 runs of 32, 3 zigzag
     bool convDirectIo = true;              // option "conv_direct_io": a plan of long-partition convolvers only reads the caller's input / writes the caller's output in place
     // the launch set being enqueued (enqueueBlocks -> enqueueBatch -> launchConvolveBatch): where its convolvers read / write directly
     const float* setInDirect = nullptr; float* setOutDirect = nullptr; uint32_t setNumIn = 0, setNumOut = 0;

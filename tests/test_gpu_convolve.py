@@ -340,6 +340,40 @@ def test_random_call_sequences_through_every_convolve_path(gpu_required, seed):
         k += n
 
 
+def test_long_mac_variants_agree(gpu_required):
+    """Option `conv_long_mac_lds`: the long-partition sums in their four forms — 0 the register kernel (ships), 1 the LDS-tiled kernel
+    (64 bins x 32 chunks per workgroup, rows shared through LDS), 2 runs of 32 chunks per thread, 3 odd runs walking the taps
+    oldest-first. Forms 0, 1 and 2 add every (bin, chunk)'s taps in the same order: identical bits; form 3 reorders every second
+    run: within 5e-7. Each against the restatement; sets of 64, 24 and 8 blocks (ragged last runs), two IR lengths."""
+    from elementary_amd import el
+    irs = [graphs.c3_impulse_response(0, 96000), graphs.c3_impulse_response(1, 30000)]
+    roots = [el.convolve({"path": f"ir{i}", "key": f"n{i}"}, el.in_({"channel": i})) for i in range(2)]
+    sets = [8, 64, 24, 64, 8, 40]
+    x = graphs.c3_input(2, sum(sets) * 512)
+    c = oracle.PortRuntime(48000.0, 512)
+    for i, ir in enumerate(irs):
+        assert c.add_shared_resource(f"ir{i}", ir)
+    assert c.render(*roots)["result"] == 0
+    ref = np.stack([c.process(x[:, k * 512:(k + 1) * 512], 2, 512) for k in range(sum(sets))])
+    outs = {}
+    for mode in (0, 1, 2, 3):
+        a = hip(48000.0, 512)
+        a.set_option("batch_blocks", 64)
+        a.set_option("conv_long_mac_lds", mode)
+        for i, ir in enumerate(irs):
+            assert a.add_shared_resource(f"ir{i}", ir)
+        assert a.render(*roots)["result"] == 0
+        k, got = 0, []
+        for n in sets:
+            got.append(_blocks(a, x, k, n, 2))
+            k += n
+        outs[mode] = np.concatenate(got)
+        assert float(np.abs(outs[mode].astype(np.float64) - ref).max()) <= TOL, mode
+        assert a.describe_plan()["conv_long_sets"] >= 4
+    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
+    assert float(np.abs(outs[3].astype(np.float64) - outs[0]).max()) <= 5e-7
+
+
 def test_the_sample_clock_after_direct_io_sets(gpu_required):
     """A plan of long-partition convolvers only renders its launch sets with direct I/O: no epilogue kernel advances the device's
     sample clock, and since r06 no parameter patch per set either — the clock is caught up when something is about to read it.
