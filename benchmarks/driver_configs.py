@@ -258,7 +258,9 @@ def c3(steps: int = 16, warmup: int = 2, set_blocks: int = 1024, gpu_only: bool 
         rt.process_blocks(n * set_blocks, ch, out_ptr=outs.data_ptr() + first * stride, in_ptr=xin.data_ptr(), num_inputs=ch)
     run(0, warmup)
     torch.cuda.synchronize()
-    rt.set_option("profile_launches", 1)
+    # HIP events around the convolve level of every 4th set of the timed region (an event record costs ~4 us of stream time: around every
+    # set they were 8.5 of 80 us — profiles/r06/c3_long_mac_variants.txt; ELEMHIP_C3_EVENTS_EVERY=1 / 0 for the A/B)
+    rt.set_option("profile_launches", int(os.environ.get("ELEMHIP_C3_EVENTS_EVERY", "4")))
     t0 = time.perf_counter()
     run(warmup, steps)
     torch.cuda.synchronize()
@@ -332,6 +334,7 @@ def c3(steps: int = 16, warmup: int = 2, set_blocks: int = 1024, gpu_only: bool 
         "value": BLOCK / (us * 1e-6), "unit": "samples/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "us_per_block": us,
         "blocks_per_step": set_blocks, "batch_launches": st["batch_launches"],
         "launch_us_per_step": [1e3 * v / sets for v in prof["level_ms"]], "epilogue_us_per_step": 1e3 * prof["epilogue_ms"] / sets,
+        "launch_sets_sampled_by_hip_events": prof["launch_sets"],
         "convolver": {"long_partition_sets": plan.get("conv_long_sets"), "long_partitions_enabled": plan.get("conv_long"), "long_tap_rows": plan.get("conv_max_long_tap_rows"),
                       "note": "sets of a multiple of 8 blocks: the whole IR in 4096-sample partitions (8192-point overlap-save, conv_long.inc), no 512-sample head — "
                               "every input block of a set is known before the convolve level starts"},

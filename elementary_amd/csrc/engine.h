@@ -396,6 +396,7 @@ private:
     std::vector<hipStream_t> auxStreams;   // side streams for the independent launches of one level (launchLevelBatch)
     std::vector<hipEvent_t> auxDone;
     hipEvent_t forkEvent = nullptr;
+    uint32_t profileEvery = 1, profSetCounter = 0;   // option "profile_launches" = N: events around every N-th launch set
     bool profileLaunches = false;
     std::vector<double> profMs;            // per level + epilogue, summed over the launch sets profiled so far
     uint64_t profSets = 0, profBlocks = 0;
