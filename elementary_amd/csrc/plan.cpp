@@ -1899,6 +1899,29 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
 
     const auto tUpload = std::chrono::steady_clock::now();
     p.buildUs[4] = std::chrono::duration<double, std::micro>(tUpload - tTables).count();
+    // The tables go to the device BEFORE the render lock is taken again (r06): nothing a render call touches is involved — the pool
+    // has a lock of its own, the copy runs on the null stream, the new plan is not visible to anybody yet — so what a commit still
+    // does under `mu` behind a plan build is a handful of stores (the upload was 10 of the ~12 us it held).
+    if (!dry) {
+        p.pool = tablePool;
+        p.dev = tablePool->take(host.size());
+        if (!p.dev.ptr) return nullptr;
+        if (hipMemcpy(p.dev.ptr, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        const uint8_t* d = static_cast<const uint8_t*>(p.dev.ptr);
+        p.view.islands = reinterpret_cast<const Island*>(d + oIslands);
+        p.view.levelIslands = reinterpret_cast<const uint32_t*>(d + oLevel);
+        p.view.prog = p.progHeap->dev;          // island programs live in the engine's program heap (Island::progBegin is relative to it)
+        p.view.roots = reinterpret_cast<const RootEntry*>(d + oRoots);
+        p.view.taps = reinterpret_cast<const TapEntry*>(d + oTaps);
+        p.view.convs = reinterpret_cast<const ConvDesc*>(d + oConvs);
+        p.view.convWork = reinterpret_cast<const uint32_t*>(d + oConvWork);
+        p.dSpecLists = reinterpret_cast<const uint32_t*>(d + oSpecLists);
+        p.dRestIslands = reinterpret_cast<const uint32_t*>(d + oRest);
+        p.view.numConvs = (uint32_t)p.convs.size();
+        p.view.numRoots = (uint32_t)p.roots.size();
+        p.view.numTaps = (uint32_t)p.taps.size();
+    }
+    p.buildUs[5] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tUpload).count();
     renderLock.lock();   // ---- from here on: render-side state ----
     residentStop();
     st.specShapes = (uint32_t)p.shapes.size(); st.specIslands = (uint32_t)p.specLists.size();
@@ -1909,25 +1932,6 @@ std::shared_ptr<Plan> Engine::buildPlan(std::unique_lock<std::mutex>& renderLock
         const uint32_t has = r.inlets.empty() ? 0u : 1u;
         if (shadow[r.rec * kRecDwords + rec::ROOT_HASIN] != has) writeParam(r, rec::ROOT_HASIN, has);
     }
-    if (dry) return plan;
-    p.pool = tablePool;
-    p.dev = tablePool->take(host.size());
-    if (!p.dev.ptr) return nullptr;
-    if (hipMemcpy(p.dev.ptr, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    const uint8_t* d = static_cast<const uint8_t*>(p.dev.ptr);
-    p.view.islands = reinterpret_cast<const Island*>(d + oIslands);
-    p.view.levelIslands = reinterpret_cast<const uint32_t*>(d + oLevel);
-    p.view.prog = p.progHeap->dev;          // island programs live in the engine's program heap (Island::progBegin is relative to it)
-    p.view.roots = reinterpret_cast<const RootEntry*>(d + oRoots);
-    p.view.taps = reinterpret_cast<const TapEntry*>(d + oTaps);
-    p.view.convs = reinterpret_cast<const ConvDesc*>(d + oConvs);
-    p.view.convWork = reinterpret_cast<const uint32_t*>(d + oConvWork);
-    p.dSpecLists = reinterpret_cast<const uint32_t*>(d + oSpecLists);
-    p.dRestIslands = reinterpret_cast<const uint32_t*>(d + oRest);
-    p.view.numConvs = (uint32_t)p.convs.size();
-    p.view.numRoots = (uint32_t)p.roots.size();
-    p.view.numTaps = (uint32_t)p.taps.size();
-    p.buildUs[5] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tUpload).count();
     return plan;
 }
 
